@@ -1,0 +1,166 @@
+/*
+ * nd_amd.h -- C ABI of libnd_amd.so, the MI355X (gfx950) implementation of the
+ * per-pixel compute path of jnhansen/nd.
+ *
+ * Every entry point replaces one native (or third-party native) call that the
+ * reference's Python layer makes; the reference-side binding a maintainer
+ * would add is shown in INTEGRATION.md.  All pointers named `*_dev` / data
+ * pointers are DEVICE pointers (HIP), all sizes/strides are in ELEMENTS unless
+ * they say bytes.  Calls enqueue work on `hip_stream` and return without
+ * synchronising (exceptions are noted per function).  Return value: 0 on
+ * success, a negative ND_AMD_E* code otherwise; nd_amd_last_error() returns a
+ * thread-local description.  The library never throws and never aborts.
+ *
+ * Paths are relative to the reference checkout (/root/reference).
+ */
+#ifndef ND_AMD_H
+#define ND_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ND_AMD_ABI_VERSION 1
+
+/* dtype of the `floating` fused type (nd/_change.pyx:8, nd/_filters.pyx:3) */
+#define ND_AMD_F32 0
+#define ND_AMD_F64 1
+
+#define ND_AMD_OK            0
+#define ND_AMD_EINVAL       -1   /* bad argument */
+#define ND_AMD_EWORKSPACE   -2   /* workspace missing or too small */
+#define ND_AMD_EHIP         -3   /* a HIP runtime call failed */
+#define ND_AMD_ENOSOLUTION  -4   /* nlmeans: find_weight has no solution (ValueError in the reference) */
+#define ND_AMD_EUNSUPPORTED -5   /* valid request this build does not cover */
+
+/* scipy.ndimage border modes accepted by nd_amd_correlate (nd/filters.py:226
+ * forwards **kwargs to scipy.ndimage.convolve; default 'reflect') */
+#define ND_AMD_MODE_REFLECT  0
+#define ND_AMD_MODE_CONSTANT 1
+#define ND_AMD_MODE_NEAREST  2
+#define ND_AMD_MODE_MIRROR   3
+#define ND_AMD_MODE_WRAP     4
+
+/* ids reported by nd_amd_timing_collect */
+#define ND_AMD_KERNEL_OMNIBUS_GLOBAL 1
+#define ND_AMD_KERNEL_OMNIBUS_SEARCH 2
+#define ND_AMD_KERNEL_CORRELATE      3
+#define ND_AMD_KERNEL_NLMEANS        4
+#define ND_AMD_KERNEL_BOXCAR_TILED   5
+#define ND_AMD_KERNEL_NLMEANS_TILED  6
+
+int nd_amd_abi_version(void);
+const char *nd_amd_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * OmnibusTest, dual-pol C2.
+ * Replaces  nd._change.change_detection(values, alpha, n, njobs)
+ *           nd/_change.pyx:263-287, sole caller nd/change.py:69.
+ *
+ * The reference passes one (y, x, time, 4) strided view whose last axis is
+ * [C11, C12__re, C12__im, C22] (nd/change.py:66-67); here the four variables
+ * are four plane pointers that share one set of element strides, which is
+ * what that view is in memory.  Fast path: stride_x == 1 and 16-byte aligned
+ * rows (planar [time][y][x]); any other strides run the generic kernel.
+ *
+ *   change   : uint8 (y, x, time) C-order, caller-allocated, fully overwritten
+ *              (the reference returns a fresh np.zeros array, :275).
+ *   z_out,
+ *   p_out    : optional (y, x) rasters of dtype `dtype`: the test statistic
+ *              -2 rho ln Q and the probability P of the global test over the
+ *              whole series (nd/_change.pyx:46-77, 133-151) -- values the
+ *              reference only exposes per pixel via its cpdef functions.
+ *   workspace: nd_amd_omnibus_c2_workspace_bytes() bytes of device memory,
+ *              256-byte aligned; contents are scratch.
+ * njobs has no equivalent: the whole raster is one launch.
+ * ---------------------------------------------------------------------- */
+size_t nd_amd_omnibus_c2_workspace_bytes(int64_t ny, int64_t nx, int64_t k);
+
+int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void *c12im,
+                      const void *c22, int dtype,
+                      int64_t ny, int64_t nx, int64_t k,
+                      int64_t stride_y, int64_t stride_x, int64_t stride_t,
+                      uint32_t n_looks, double alpha,
+                      uint8_t *change, void *z_out, void *p_out,
+                      void *workspace, size_t workspace_bytes,
+                      void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Kernel convolution / boxcar.
+ * Replaces  scipy.ndimage.convolve(arr, nd_kernel, output=output, **kwargs)
+ *           as called at nd/filters.py:256-267 (scipy is the reference's
+ *           third-party arithmetic for ConvolutionFilter / BoxcarFilter).
+ *
+ * The host (nd_amd/filters.py) turns the kernel into scipy's footprint: the
+ * non-zero taps (|w| > DBL_EPSILON) of the flipped kernel in C order, with
+ * per-axis input offsets.  The array is viewed as 4-D (dims[4], missing
+ * leading axes = 1) with element strides.  Per output element:
+ *   double tmp = 0; for each tap: tmp += w * (double)in[extend(i + off)];
+ *   out = (T)tmp          -- same order, double accumulation, no FMA.
+ *   offsets : host pointer, ntaps x 4 int64
+ *   weights : host pointer, ntaps double
+ * Up to 128 taps travel to the kernel as a launch argument (asynchronous,
+ * graph-capturable).  Larger footprints are copied into `taps_dev`
+ * (>= 24 * ntaps bytes of device memory, may be NULL otherwise); that path
+ * synchronises the stream once.
+ * ---------------------------------------------------------------------- */
+int nd_amd_correlate(const void *in, void *out, int dtype,
+                     const int64_t dims[4],
+                     const int64_t in_strides[4], const int64_t out_strides[4],
+                     int64_t ntaps, const int64_t *offsets, const double *weights,
+                     int mode, double cval,
+                     void *taps_dev, size_t taps_dev_bytes,
+                     void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Non-local means.
+ * Replaces  nd._filters._pixelwise_nlmeans_3d(arr, output, r, f, sigma, h, n_eff)
+ *           nd/_filters.pyx:320-420, sole caller nd/filters.py:462.
+ *
+ *   arr, out      : (N0, N1, N2, nvars) views, element strides given.
+ *   patch_mode    : 0 = what the compiled reference does on LP64 platforms:
+ *                   `range(-f[i], f[i]+1)` with an unsigned f starts at
+ *                   2^32 - f[i], so the patch loops are empty whenever any
+ *                   f[i] > 0 and every neighbour gets weight exp(0) = 1
+ *                   (nd/_filters.c:3539-3553); 1 = the signed range the
+ *                   source text intends (true patch distances).
+ *   neff_policy   : find_weight failure (nd/_filters.pyx:310-311):
+ *                   0 = self weight 0, as the shipped Cython-0.29 C does;
+ *                   1 = report ND_AMD_ENOSOLUTION, as a Cython>=3 build does.
+ *   status_dev    : device int32 the kernel sets to 1 on a find_weight
+ *                   failure (policy 1); zeroed by the call.  May be NULL for
+ *                   n_eff < 0.  The caller reads it after synchronising.
+ *   global_N,
+ *   tile_off      : for tiled (multi-GPU) use: `arr` is the tile
+ *                   [tile_off, tile_off + N) of an array of shape global_N
+ *                   that carries its halo rows, `out` likewise; only
+ *                   [core_lo, core_hi) of axis `N` is written and reflection
+ *                   happens at the GLOBAL edges.  Pass global_N = N,
+ *                   tile_off = 0, core = [0, N) for the plain call.
+ * ---------------------------------------------------------------------- */
+int nd_amd_nlmeans3d(const void *arr, void *out, int dtype,
+                     const int64_t N[3], int64_t nvars,
+                     const int64_t in_strides[4], const int64_t out_strides[4],
+                     const uint32_t r[3], const uint32_t f[3],
+                     double sigma, double h, double n_eff,
+                     int patch_mode, int neff_policy, int32_t *status_dev,
+                     const int64_t global_N[3], const int64_t tile_off[3],
+                     const int64_t core_lo[3], const int64_t core_hi[3],
+                     void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Per-kernel timing with HIP events recorded on the caller's stream
+ * (bench.py's roofline figures).  enable(capacity) pre-creates the events;
+ * collect() synchronises on them and returns (kernel id, milliseconds) pairs
+ * in launch order, then resets.  enable(0) turns timing off.
+ * ---------------------------------------------------------------------- */
+int nd_amd_timing_enable(int capacity);
+int nd_amd_timing_collect(int32_t *kernel_ids, float *ms, int max_n, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ND_AMD_H */

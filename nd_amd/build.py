@@ -1,0 +1,67 @@
+"""
+nd_amd/build.py -- compile the HIP library in-tree:  nd_amd/libnd_amd.so
+
+    python -m nd_amd.build [--force] [--verbose]
+
+One hipcc invocation per translation unit (object files under nd_amd/csrc/_build,
+git-ignored), then one link.  gfx950 only.  -ffp-contract=off is deliberate: the
+kernels reproduce the reference's rounding points, and the few places that want a
+fused multiply-add call fma() explicitly.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_build')
+LIB = os.path.join(HERE, 'libnd_amd.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+         '-fno-fast-math', '-Wall', '-Wno-unused-function']
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _deps():
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp')]
+    hdr.append(os.path.join(HERE, '..', 'include', 'nd_amd.h'))
+    hdr.append(os.path.abspath(__file__))
+    return hdr
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    os.makedirs(OBJ, exist_ok=True)
+    dep_mtime = max(os.path.getmtime(p) for p in _deps())
+    objs = []
+    rebuilt = False
+    procs = []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        if (not force and os.path.exists(obj)
+                and os.path.getmtime(obj) >= max(os.path.getmtime(src), dep_mtime)):
+            continue
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+        rebuilt = True
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed on %s' % src)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    lib = build(force='--force' in sys.argv, verbose='--verbose' in sys.argv)
+    print(lib)

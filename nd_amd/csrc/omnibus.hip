@@ -1,0 +1,670 @@
+// nd_amd/csrc/omnibus.hip -- OmnibusTest (complex-Wishart change detector), dual-pol C2,
+// for gfx950.  Replaces nd._change.change_detection (nd/_change.pyx:263-287).
+//
+// Two kernels per call:
+//
+//   omnibus_c2_global_kernel   ("pass A", HBM-bound)  one thread owns PPT adjacent pixels,
+//       streams the k x 4 planes once with 16-byte loads (coalesced along x, time outer),
+//       keeps the reference's running state (4 `floating` sums + 1 double product of
+//       determinants, nd/_change.pyx:64-69), evaluates the global test over the whole series
+//       (nd/_change.pyx:133-151), zero-fills its slice of the (y,x,time) change map with
+//       16-byte stores and appends the pixels whose global test fires to a compact list
+//       (wave ballot + one atomic per wave).
+//
+//   omnibus_c2_search_kernel   ("pass B", FP64-bound)  one lane per listed pixel, series staged
+//       in LDS ([time*4+var][lane], conflict free), runs the sequential change-point search of
+//       nd/_change.pyx:224-257.  All lanes of a wave evaluate one omnibus test per iteration
+//       (global test of segment l, or the next marginal test l..l+j) so the expensive part
+//       (two logs + the chi-square pair) stays converged across the wave.
+//
+// Numerics follow the C that Cython generates for the reference (nd/_change.c:3501-3590,
+// 6063-6091): `floating` (T) sums and determinants without FMA contraction (this TU is built
+// with -ffp-contract=off), double product of determinants, double logs, rho rounded to T,
+// z rounded to T, P1/P2 rounded to T, (P2-P1) in T, final combine in double then rounded to T,
+// decision (double)P > alpha.  The marginal tests reuse one running accumulation per segment
+// start l, which is the same sequence of additions the reference performs when it re-sums
+// ts[l:l+j] from scratch for every j.
+//
+// gsl_cdf_chisq_P(z, f) and (z, f+4) (nd/_change.pyx:147-148): f = (j-1) p^2 with p = 2 is a
+// multiple of 4, so a = f/2 = 2(j-1) is an integer and the regularised incomplete gamma
+// function has closed recurrences (see chisq_pair_int).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace nd_amd {
+
+// ---- constants of one omnibus test over j matrices (host-computed in double) ------------
+struct OmniTabEntry {
+    double m2rho;    // -2.0 * (double)(T)rho(p, j, n)        nd/_change.pyx:75-76
+    double pklogk;   // (double)(p * j) * log((double)j)      nd/_change.pyx:74
+    double omega2;   // omega2(p, j, n, rho) from double rho  nd/_change.pyx:139
+    double lgam;     // lgamma(a + 1), a = f/2 = 2 (j - 1)
+};
+
+constexpr int kTabArgs = 96;   // largest k whose table travels as a kernel argument
+struct OmniTab {
+    OmniTabEntry e[kTabArgs + 1];
+};
+
+// 1/m for the incomplete-gamma recurrences
+constexpr int kInvTab = 2048;
+struct InvTab {
+    double v[kInvTab];
+    constexpr InvTab() : v()
+    {
+        v[0] = 0.0;
+        for (int i = 1; i < kInvTab; ++i) v[i] = 1.0 / (double)i;
+    }
+};
+__constant__ InvTab c_inv = InvTab();
+
+__device__ __forceinline__ double inv_int(int m)
+{
+    return m < kInvTab ? c_inv.v[m] : 1.0 / (double)m;
+}
+
+// P1 = P(a, z/2), P2 = P(a + 2, z/2) for integer a >= 0, N values in lockstep.
+//   t_a = x^a e^-x / a!
+//   x <  a+1 :  P(a,x) = t_a * sum_{n>=0} x^n / ((a+1)...(a+n)),  P(a+2,x) = t_a * sum_{n>=2} ...
+//   x >= a+1 :  Q(a,x) = t_{a-1} * sum_{m=0}^{a-1} (a-1)...(a-m) / x^m,  Q(a+2,x) = Q(a,x) + t_a + t_{a+1}
+// Both sums have decreasing positive terms; one loop serves both.
+template <int N>
+__device__ __forceinline__ void chisq_pair_int(const double (&z)[N], int a, double lgam_a1,
+                                               double (&P1)[N], double (&P2)[N])
+{
+    double x[N], ta[N], rx[N], u1[N], term[N], sum[N];
+    bool lower[N], ok[N];
+    const double ap1 = (double)(a + 1);
+    const double inv_ap1 = inv_int(a + 1);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ok[i] = (z[i] > 0.0) && (z[i] < INFINITY);
+        x[i] = ok[i] ? 0.5 * z[i] : 1.0;
+        lower[i] = x[i] < ap1;
+        ta[i] = exp(fma((double)a, log(x[i]), -x[i]) - lgam_a1);
+        rx[i] = 1.0 / x[i];
+        u1[i] = x[i] * inv_ap1;
+        term[i] = lower[i] ? u1[i] : 1.0;
+        sum[i] = lower[i] ? 0.0 : 1.0;
+    }
+    for (int n = 1; n < 1000000; ++n) {
+        const double inv_n = inv_int(a + 1 + n);
+        const double up = (double)(a - n > 0 ? a - n : 0);
+        bool more = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double ratio = lower[i] ? x[i] * inv_n : up * rx[i];
+            term[i] = term[i] * ratio;
+            sum[i] = sum[i] + term[i];
+            more = more || (term[i] > 1e-17 * sum[i]);
+        }
+        if (!__any(more)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double p1, p2;
+        if (lower[i]) {
+            p1 = ta[i] * ((1.0 + u1[i]) + sum[i]);
+            p2 = ta[i] * sum[i];
+        } else {
+            const double qa = (ta[i] * (double)a * rx[i]) * sum[i];
+            p1 = 1.0 - qa;
+            p2 = 1.0 - (qa + ta[i] + ta[i] * u1[i]);
+        }
+        if (!ok[i]) {
+            // gsl_cdf_chisq_P: x <= 0 -> 0; NaN stays NaN; +inf -> NaN (inf - inf inside GSL's
+            // large-x branch; DESIGN.md "Residual risks")
+            p1 = p2 = (z[i] <= 0.0) ? 0.0 : NAN;
+        }
+        P1[i] = p1;
+        P2[i] = p2;
+    }
+}
+
+// ---- the reference's running state (nd/_change.pyx:53-69) -------------------------------
+template <typename T>
+struct Accum {
+    T s11, s12r, s12i, s22;
+    double prod;
+    __device__ __forceinline__ void reset()
+    {
+        s11 = 0;
+        s12r = 0;
+        s12i = 0;
+        s22 = 0;
+        prod = 1.0;
+    }
+    __device__ __forceinline__ void step(T a, T b, T c, T d)
+    {
+        const T det = (a * d) - ((b * b) + (c * c));
+        prod = prod * (double)det;
+        s11 = s11 + a;
+        s12r = s12r + b;
+        s12i = s12i + c;
+        s22 = s22 + d;
+    }
+};
+
+// z = -2 rho ln Q over j matrices (nd/_change.pyx:72-76)
+template <typename T>
+__device__ __forceinline__ T z_stat(const Accum<T> &A, int j, double nlooks, const OmniTabEntry &e)
+{
+    const T det_of_sum = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
+    const double logQ =
+        nlooks * ((e.pklogk + log(A.prod)) - ((double)j * log((double)det_of_sum)));
+    return (T)(e.m2rho * logQ);
+}
+
+// P = P1 + omega2 (P2 - P1) with the reference's rounding points (nd/_change.c:6087-6089)
+template <typename T>
+__device__ __forceinline__ T combine_P(double P1, double P2, double omega2)
+{
+    const T p1 = (T)P1, p2 = (T)P2;
+    const T d = p2 - p1;
+    return (T)((double)p1 + (omega2 * (double)d));
+}
+
+template <typename T, int N>
+struct alignas(sizeof(T) * N) Pack {
+    T v[N];
+};
+
+// =========================================================================================
+// pass A
+// =========================================================================================
+template <typename T>
+struct OmniGlobalArgs {
+    const T *c11, *c12r, *c12i, *c22;
+    int64_t nx, nrows;        // pixels per row, rows (flattened to one row when planes are contiguous)
+    int64_t sy, sx, st;       // element strides
+    int64_t blocks_per_row;
+    int k;
+    int write_tab;            // block 0 copies `tab` into tab_dev
+    double nlooks, alpha;
+    OmniTabEntry e;           // constants of the test over all k matrices
+    uint8_t *change;
+    T *z_out, *p_out;
+    uint32_t *flag_count, *flag_idx;
+    OmniTabEntry *tab_dev;
+};
+
+constexpr int kGlobalThreads = 256;
+constexpr int kTimeChunk = 4;
+
+template <typename T, int PPT>
+__global__ void __launch_bounds__(kGlobalThreads)
+omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)(kGlobalThreads * PPT);      // first pixel of the block in its row
+    const int64_t x0 = bpx0 + (int64_t)tid * PPT;
+    const int k = g.k;
+
+    if (g.write_tab && b == 0) {
+        for (int j = tid; j <= k; j += kGlobalThreads) g.tab_dev[j] = tab.e[j];
+    }
+
+    // ---- zero-fill this block's slice of the change map (np.zeros at nd/_change.pyx:275) ----
+    {
+        int64_t npx = g.nx - bpx0;
+        if (npx > kGlobalThreads * PPT) npx = kGlobalThreads * PPT;
+        uint8_t *ob = g.change + (row * g.nx + bpx0) * (int64_t)k;
+        const int64_t nb = npx * (int64_t)k;
+        int64_t head = (int64_t)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (tid < head) ob[tid] = 0;
+        const int64_t nvec = (nb - head) >> 4;
+        uint4 *v = reinterpret_cast<uint4 *>(ob + head);
+        for (int64_t i = tid; i < nvec; i += kGlobalThreads) v[i] = make_uint4(0u, 0u, 0u, 0u);
+        const int64_t tail0 = head + (nvec << 4);
+        if (tail0 + tid < nb) ob[tail0 + tid] = 0;
+    }
+
+    // ---- stream the series ----
+    Accum<T> A[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) A[i].reset();
+
+    const bool any_px = x0 < g.nx;
+    const bool full = (x0 + PPT <= g.nx);
+    const int64_t off0 = row * g.sy + x0 * g.sx;
+
+    if (any_px) {
+        for (int t0 = 0; t0 < k; t0 += kTimeChunk) {
+            Pack<T, PPT> v[kTimeChunk][4];
+#pragma unroll
+            for (int tt = 0; tt < kTimeChunk; ++tt) {
+                const int t = t0 + tt;
+                if (t < k) {
+                    const int64_t off = off0 + (int64_t)t * g.st;
+                    if (PPT == 1 || full) {
+                        if (PPT == 1) {
+                            v[tt][0].v[0] = g.c11[off];
+                            v[tt][1].v[0] = g.c12r[off];
+                            v[tt][2].v[0] = g.c12i[off];
+                            v[tt][3].v[0] = g.c22[off];
+                        } else {
+                            v[tt][0] = *reinterpret_cast<const Pack<T, PPT> *>(g.c11 + off);
+                            v[tt][1] = *reinterpret_cast<const Pack<T, PPT> *>(g.c12r + off);
+                            v[tt][2] = *reinterpret_cast<const Pack<T, PPT> *>(g.c12i + off);
+                            v[tt][3] = *reinterpret_cast<const Pack<T, PPT> *>(g.c22 + off);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < PPT; ++i) {
+                            const bool in = (x0 + i < g.nx);
+                            v[tt][0].v[i] = in ? g.c11[off + i] : (T)1;
+                            v[tt][1].v[i] = in ? g.c12r[off + i] : (T)0;
+                            v[tt][2].v[i] = in ? g.c12i[off + i] : (T)0;
+                            v[tt][3].v[i] = in ? g.c22[off + i] : (T)1;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < kTimeChunk; ++tt) {
+                if (t0 + tt < k) {
+#pragma unroll
+                    for (int i = 0; i < PPT; ++i)
+                        A[i].step(v[tt][0].v[i], v[tt][1].v[i], v[tt][2].v[i], v[tt][3].v[i]);
+                }
+            }
+        }
+    }
+
+    // ---- global test over the whole series ----
+    T z[PPT], P[PPT];
+    double zd[PPT], P1[PPT], P2[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        z[i] = z_stat<T>(A[i], k, g.nlooks, g.e);
+        zd[i] = (double)z[i];
+    }
+    chisq_pair_int<PPT>(zd, 2 * (k - 1), g.e.lgam, P1, P2);
+    bool flag[PPT];
+    unsigned nflag = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        P[i] = combine_P<T>(P1[i], P2[i], g.e.omega2);
+        flag[i] = (x0 + i < g.nx) && ((double)P[i] > g.alpha);
+        nflag += flag[i] ? 1u : 0u;
+    }
+
+    if (any_px && (g.z_out != nullptr || g.p_out != nullptr)) {
+        const int64_t pix0 = row * g.nx + x0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            if (x0 + i < g.nx) {
+                if (g.z_out) g.z_out[pix0 + i] = z[i];
+                if (g.p_out) g.p_out[pix0 + i] = P[i];
+            }
+        }
+    }
+
+    // ---- append flagged pixels to the compact list: one atomic per wave ----
+    if (__any(nflag != 0u)) {
+        unsigned long long m[PPT];
+        unsigned tot = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            m[i] = __ballot(flag[i]);
+            tot += (unsigned)__popcll(m[i]);
+        }
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(g.flag_count, tot);
+        base = __shfl(base, 0);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            if (flag[i])
+                g.flag_idx[base + (unsigned)__popcll(m[i] & lt)] =
+                    (uint32_t)(row * g.nx + x0 + i);
+            base += (unsigned)__popcll(m[i]);
+        }
+    }
+}
+
+// =========================================================================================
+// pass B
+// =========================================================================================
+template <typename T>
+struct OmniSearchArgs {
+    const T *c11, *c12r, *c12i, *c22;
+    int64_t nx;
+    int64_t sy, sx, st;
+    int k;
+    double nlooks, alpha;
+    uint8_t *change;
+    const uint32_t *flag_count, *flag_idx;
+    const OmniTabEntry *tab;
+};
+
+template <typename T, bool USE_LDS>
+__global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchArgs<T> s)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem[];
+    T *lds = reinterpret_cast<T *>(nd_smem);
+    const int lane = threadIdx.x;
+    const int k = s.k;
+    const uint32_t n = *s.flag_count;
+
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < n;
+        const int64_t pix = active ? (int64_t)s.flag_idx[idx] : 0;
+        const int64_t row = pix / s.nx;
+        const int64_t col = pix - row * s.nx;
+        const int64_t off = row * s.sy + col * s.sx;
+
+        if (USE_LDS) {
+            // stage this lane's series: lds[(t*4+v)*64 + lane]; each lane reads back only its
+            // own column, so no barrier is needed
+            for (int t = 0; t < k; ++t) {
+                const int64_t o = off + (int64_t)t * s.st;
+                lds[(t * 4 + 0) * 64 + lane] = s.c11[o];
+                lds[(t * 4 + 1) * 64 + lane] = s.c12r[o];
+                lds[(t * 4 + 2) * 64 + lane] = s.c12i[o];
+                lds[(t * 4 + 3) * 64 + lane] = s.c22[o];
+            }
+        }
+        auto load_step = [&](Accum<T> &A, int t) {
+            if (USE_LDS) {
+                A.step(lds[(t * 4 + 0) * 64 + lane], lds[(t * 4 + 1) * 64 + lane],
+                       lds[(t * 4 + 2) * 64 + lane], lds[(t * 4 + 3) * 64 + lane]);
+            } else {
+                const int64_t o = off + (int64_t)t * s.st;
+                A.step(s.c11[o], s.c12r[o], s.c12i[o], s.c22[o]);
+            }
+        };
+
+        // state machine of nd/_change.pyx:235-257; one omnibus evaluation per iteration
+        Accum<T> A;
+        A.reset();
+        int l = 0;
+        int j = 0;             // marginal state: A holds ts[l : l+j-1]
+        bool marginal = false;
+        bool done = !active;
+        uint8_t *res = s.change + pix * (int64_t)k;
+
+        while (__any(!done)) {
+            if (!done) {
+                int jj;
+                if (!marginal) {
+                    // global hypothesis H0_l over ts[l:]  (:238-240)
+                    A.reset();
+                    for (int t = l; t < k; ++t) load_step(A, t);
+                    jj = k - l;
+                } else {
+                    // next marginal hypothesis over ts[l : l+j]  (:246-248)
+                    load_step(A, l + j - 1);
+                    jj = j;
+                }
+                const OmniTabEntry e = s.tab[jj];
+                const T z = z_stat<T>(A, jj, s.nlooks, e);
+                double zd[1] = {(double)z}, P1[1], P2[1];
+                chisq_pair_int<1>(zd, 2 * (jj - 1), e.lgam, P1, P2);
+                const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                const bool change = ((double)P > s.alpha);
+                if (!marginal) {
+                    if (!change) {
+                        done = true;                       // :241-242
+                    } else {
+                        marginal = true;
+                        A.reset();
+                        load_step(A, l);                   // j = 1 carries no test
+                        j = 2;
+                    }
+                } else {
+                    const int r = j - 1;                   // :250
+                    if (change || j >= k - l) {
+                        if (change) res[l + r] = 1;        // :252
+                        l = l + r;                         // :255
+                        marginal = false;
+                        if (l >= k - 1) done = true;       // :256
+                    } else {
+                        j = j + 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+static double host_rho(double p, double k, double n)
+{
+    return (1.0 - ((((2.0 * (p * p)) - 1.0) / ((6.0 * (k - 1.0)) * p)) *
+                   ((k / n) - (1.0 / (n * k)))));
+}
+
+static double host_omega2(double p, double k, double n, double rho)
+{
+    return (((((p * p) * ((p * p) - 1.0)) / (24.0 * (rho * rho))) *
+             ((k / (n * n)) - (1.0 / ((n * k) * (n * k))))) -
+            ((((p * p) * (k - 1.0)) / 4.0) * ((1.0 - (1.0 / rho)) * (1.0 - (1.0 / rho)))));
+}
+
+template <typename T>
+static OmniTabEntry make_entry(int j, uint32_t n_looks)
+{
+    OmniTabEntry e;
+    const double p = 2.0, k = (double)j, n = (double)n_looks;
+    const double rho = host_rho(p, k, n);
+    const T rho_t = (T)rho;
+    e.m2rho = -2.0 * (double)rho_t;
+    const T pk = (T)2 * (T)j;
+    e.pklogk = (double)pk * log(k);
+    e.omega2 = host_omega2(p, k, n, rho);
+    e.lgam = lgamma((double)(2 * (j - 1)) + 1.0);
+    return e;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct OmniWorkspace {
+    size_t off_count, off_tab, off_idx, total;
+};
+
+static OmniWorkspace omni_layout(int64_t npix, int64_t k)
+{
+    OmniWorkspace w;
+    w.off_count = 0;
+    w.off_tab = 256;
+    w.off_idx = w.off_tab + align256((size_t)(k + 1) * sizeof(OmniTabEntry));
+    w.total = w.off_idx + align256((size_t)npix * sizeof(uint32_t));
+    return w;
+}
+
+template <typename T, int PPT>
+static void launch_global(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_t nblocks,
+                          hipStream_t stream)
+{
+    hipLaunchKernelGGL((omnibus_c2_global_kernel<T, PPT>), dim3((unsigned)nblocks),
+                       dim3(kGlobalThreads), 0, stream, g, tab);
+}
+
+template <typename T>
+static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im, const void *c22,
+                           int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int64_t st,
+                           uint32_t n_looks, double alpha, uint8_t *change, void *z_out,
+                           void *p_out, void *workspace, size_t workspace_bytes,
+                           hipStream_t stream)
+{
+    const int64_t npix = ny * nx;
+    const OmniWorkspace w = omni_layout(npix, k);
+    if (workspace == nullptr || workspace_bytes < w.total) {
+        set_error("nd_amd_omnibus_c2: workspace of %zu bytes needed, %zu given", w.total,
+                  workspace_bytes);
+        return ND_AMD_EWORKSPACE;
+    }
+    if (((uintptr_t)workspace & 255) != 0) {
+        set_error("nd_amd_omnibus_c2: workspace must be 256-byte aligned");
+        return ND_AMD_EINVAL;
+    }
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    uint32_t *flag_count = reinterpret_cast<uint32_t *>(ws + w.off_count);
+    OmniTabEntry *tab_dev = reinterpret_cast<OmniTabEntry *>(ws + w.off_tab);
+    uint32_t *flag_idx = reinterpret_cast<uint32_t *>(ws + w.off_idx);
+
+    // per-j constants (host, double, same expression order as nd/_change.c:2926-2975)
+    OmniTab tab;
+    memset(&tab, 0, sizeof(tab));
+    const bool tab_in_args = (k <= kTabArgs);
+    if (tab_in_args) {
+        for (int j = 1; j <= (int)k; ++j) tab.e[j] = make_entry<T>(j, n_looks);
+    } else {
+        // large k: table goes through a (pageable) host copy; not graph-capturable
+        OmniTabEntry *h = (OmniTabEntry *)malloc((size_t)(k + 1) * sizeof(OmniTabEntry));
+        if (!h) {
+            set_error("nd_amd_omnibus_c2: out of host memory");
+            return ND_AMD_EINVAL;
+        }
+        memset(h, 0, sizeof(OmniTabEntry));
+        for (int j = 1; j <= (int)k; ++j) h[j] = make_entry<T>(j, n_looks);
+        hipError_t e = hipMemcpyAsync(tab_dev, h, (size_t)(k + 1) * sizeof(OmniTabEntry),
+                                      hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        free(h);
+        ND_HIP_CHECK(e);
+    }
+
+    ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, sizeof(uint32_t), stream));
+
+    // ---- pass A ----
+    OmniGlobalArgs<T> g;
+    g.c11 = static_cast<const T *>(c11);
+    g.c12r = static_cast<const T *>(c12re);
+    g.c12i = static_cast<const T *>(c12im);
+    g.c22 = static_cast<const T *>(c22);
+    g.sy = sy;
+    g.sx = sx;
+    g.st = st;
+    g.k = (int)k;
+    g.write_tab = tab_in_args ? 1 : 0;
+    g.nlooks = (double)n_looks;
+    g.alpha = alpha;
+    g.e = make_entry<T>((int)k, n_looks);
+    g.change = change;
+    g.z_out = static_cast<T *>(z_out);
+    g.p_out = static_cast<T *>(p_out);
+    g.flag_count = flag_count;
+    g.flag_idx = flag_idx;
+    g.tab_dev = tab_dev;
+
+    constexpr int VPPT = 16 / sizeof(T);   // pixels per 16-byte load
+    const size_t es = sizeof(T);
+    const bool aligned = (sx == 1) && (((uintptr_t)c11 | (uintptr_t)c12re | (uintptr_t)c12im |
+                                        (uintptr_t)c22) & 15) == 0 &&
+                         ((sy * (int64_t)es) % 16 == 0) && ((st * (int64_t)es) % 16 == 0);
+    const bool flat = (sx == 1) && (sy == nx);
+    g.nx = flat ? npix : nx;
+    g.nrows = flat ? 1 : ny;
+    const int ppt = aligned ? VPPT : 1;
+    g.blocks_per_row = ceil_div(g.nx, (int64_t)kGlobalThreads * ppt);
+    const int64_t nblocks = g.blocks_per_row * g.nrows;
+    if (nblocks > 0x7fffffffLL) {
+        set_error("nd_amd_omnibus_c2: raster too large for one launch (%lld blocks)",
+                  (long long)nblocks);
+        return ND_AMD_EUNSUPPORTED;
+    }
+    {
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+        if (aligned)
+            launch_global<T, VPPT>(g, tab, nblocks, stream);
+        else
+            launch_global<T, 1>(g, tab, nblocks, stream);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+
+    // ---- pass B ----
+    OmniSearchArgs<T> s;
+    s.c11 = g.c11;
+    s.c12r = g.c12r;
+    s.c12i = g.c12i;
+    s.c22 = g.c22;
+    s.nx = nx;
+    s.sy = sy;
+    s.sx = sx;
+    s.st = st;
+    s.k = (int)k;
+    s.nlooks = g.nlooks;
+    s.alpha = alpha;
+    s.change = change;
+    s.flag_count = flag_count;
+    s.flag_idx = flag_idx;
+    s.tab = tab_dev;
+    const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T);
+    const bool use_lds = lds_bytes <= 64 * 1024;
+    int64_t sblocks = ceil_div(npix, 64);
+    if (sblocks > 8192) sblocks = 8192;
+    {
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
+        if (use_lds)
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, true>), dim3((unsigned)sblocks),
+                               dim3(64), lds_bytes, stream, s);
+        else
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, false>), dim3((unsigned)sblocks),
+                               dim3(64), 0, stream, s);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+    return ND_AMD_OK;
+}
+
+}  // namespace nd_amd
+
+using namespace nd_amd;
+
+extern "C" size_t nd_amd_omnibus_c2_workspace_bytes(int64_t ny, int64_t nx, int64_t k)
+{
+    if (ny < 0 || nx < 0 || k < 0) return 0;
+    return omni_layout(ny * nx, k).total;
+}
+
+extern "C" int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void *c12im,
+                                 const void *c22, int dtype, int64_t ny, int64_t nx, int64_t k,
+                                 int64_t stride_y, int64_t stride_x, int64_t stride_t,
+                                 uint32_t n_looks, double alpha, uint8_t *change, void *z_out,
+                                 void *p_out, void *workspace, size_t workspace_bytes,
+                                 void *hip_stream)
+{
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_omnibus_c2: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (ny < 0 || nx < 0 || k < 0) {
+        set_error("nd_amd_omnibus_c2: negative shape (%lld, %lld, %lld)", (long long)ny,
+                  (long long)nx, (long long)k);
+        return ND_AMD_EINVAL;
+    }
+    if (ny == 0 || nx == 0 || k == 0) return ND_AMD_OK;   // nothing to write
+    if (!c11 || !c12re || !c12im || !c22 || !change) {
+        set_error("nd_amd_omnibus_c2: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    if (n_looks == 0) {
+        set_error("nd_amd_omnibus_c2: n_looks must be >= 1");
+        return ND_AMD_EINVAL;
+    }
+    if (ny * nx >= 0xffffffffLL || k > 0x3fffffff) {
+        set_error("nd_amd_omnibus_c2: raster of %lld pixels exceeds the 32-bit pixel index",
+                  (long long)(ny * nx));
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (dtype == ND_AMD_F32)
+        return omnibus_c2_impl<float>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x,
+                                      stride_t, n_looks, alpha, change, z_out, p_out, workspace,
+                                      workspace_bytes, stream);
+    return omnibus_c2_impl<double>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x,
+                                   stride_t, n_looks, alpha, change, z_out, p_out, workspace,
+                                   workspace_bytes, stream);
+}

@@ -1,0 +1,207 @@
+"""
+nd_amd/kernels.py -- tensor-level entry points: PyTorch-ROCm tensors in, HIP
+kernels launched through the ctypes C ABI (include/nd_amd.h) on torch's current
+stream.  PyTorch is only the device-memory / stream plumbing here.
+
+Each function names the native call of the reference it stands in for:
+
+  change_detection(...)      nd._change.change_detection          nd/_change.pyx:263-287
+  correlate_footprint(...)   scipy.ndimage.convolve               nd/filters.py:256-267
+  pixelwise_nlmeans_3d(...)  nd._filters._pixelwise_nlmeans_3d    nd/_filters.pyx:320-420
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %r' % (name, type(t)))
+    if not t.is_cuda:
+        raise ValueError('%s must live on a ROCm device (got %s); nd_amd has no CPU path'
+                         % (name, t.device))
+    if t.dtype not in _DT:
+        raise TypeError('%s must be float32 or float64, got %s' % (name, t.dtype))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---------------------------------------------------------------------------
+# OmnibusTest C2
+# ---------------------------------------------------------------------------
+def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x'),
+                     stats=False):
+    """Omnibus change detection on four covariance planes.
+
+    c11, c12re, c12im, c22 : CUDA tensors of identical shape/strides/dtype whose
+        three axes are named by `dims` (any order of 'y', 'x', 'time'); the
+        reference's (y, x, time, 4) view (nd/change.py:66-67) is these four
+        tensors side by side.
+    Returns uint8 tensor (y, x, time) [, z (y, x), P (y, x)].
+    """
+    planes = (c11, c12re, c12im, c22)
+    for name, t in zip(('c11', 'c12re', 'c12im', 'c22'), planes):
+        _require_cuda(t, name)
+        if t.dim() != 3:
+            raise ValueError('%s must be 3-D, got shape %s' % (name, tuple(t.shape)))
+        if (t.shape != c11.shape or t.stride() != c11.stride() or t.dtype != c11.dtype
+                or t.device != c11.device):
+            raise ValueError('the four covariance planes must share shape, strides, '
+                             'dtype and device')
+    dims = tuple(dims)
+    if sorted(dims) != ['time', 'x', 'y']:
+        raise ValueError("dims must be a permutation of ('time', 'y', 'x')")
+    ay, ax, at = dims.index('y'), dims.index('x'), dims.index('time')
+    ny, nx, k = c11.shape[ay], c11.shape[ax], c11.shape[at]
+    sy, sx, st = c11.stride(ay), c11.stride(ax), c11.stride(at)
+    dev = c11.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        change = torch.empty((ny, nx, k), dtype=torch.uint8, device=dev)
+        z = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
+        P = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
+        if ny * nx * k > 0:
+            nbytes = L.nd_amd_omnibus_c2_workspace_bytes(ny, nx, k)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(L.nd_amd_omnibus_c2(
+                _ptr(c11), _ptr(c12re), _ptr(c12im), _ptr(c22), _DT[c11.dtype],
+                ny, nx, k, sy, sx, st, int(n), float(alpha),
+                _ptr(change), _ptr(z), _ptr(P), _ptr(ws), nbytes, _stream_ptr(dev)))
+            # keep the workspace alive until the stream has consumed it
+            ws.record_stream(torch.cuda.current_stream(dev))
+    if stats:
+        return change, z, P
+    return change
+
+
+# ---------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------
+def footprint(weights, origin=0, convolution=True):
+    """scipy.ndimage `_correlate_or_convolve` footprint of a kernel: offsets
+    (ntaps, ndim) int64 and weights (ntaps,) float64 of the taps NI_Correlate
+    visits, in its order (|w| <= DBL_EPSILON dropped)."""
+    weights = np.asarray(weights, dtype=np.float64)
+    ndim = weights.ndim
+    origins = [int(origin)] * ndim if np.isscalar(origin) else [int(o) for o in origin]
+    if len(origins) != ndim:
+        raise ValueError('origin must have one entry per kernel axis')
+    if convolution:
+        weights = weights[tuple([slice(None, None, -1)] * ndim)]
+        for ii in range(ndim):
+            origins[ii] = -origins[ii]
+            if not weights.shape[ii] & 1:
+                origins[ii] -= 1
+    for o, lenw in zip(origins, weights.shape):
+        if (lenw // 2 + o < 0) or (lenw // 2 + o >= lenw):
+            raise ValueError('invalid origin')
+    keep = np.abs(weights) > np.finfo(np.float64).eps
+    idx = np.argwhere(keep)                                  # C order
+    centre = np.array([weights.shape[d] // 2 + origins[d] for d in range(ndim)])
+    offs = (idx - centre).astype(np.int64).reshape(-1, ndim)
+    return offs, np.ascontiguousarray(weights[keep], np.float64)
+
+
+def correlate_footprint(inp, out, offsets, weights, mode='reflect', cval=0.0):
+    """out[i] = (T) sum_t weights[t] * inp[extend(i + offsets[t])], double
+    accumulation in tap order.  inp/out: CUDA tensors, same shape, ndim <= 4."""
+    _require_cuda(inp, 'inp')
+    _require_cuda(out, 'out')
+    if inp.shape != out.shape or inp.dtype != out.dtype or inp.device != out.device:
+        raise ValueError('inp and out must share shape, dtype and device')
+    if inp.dim() > 4:
+        raise NotImplementedError('nd_amd_correlate handles up to 4 dimensions')
+    if mode not in _lib.MODES:
+        raise RuntimeError('boundary mode not supported')
+    offsets = np.asarray(offsets, np.int64).reshape(-1, inp.dim())
+    weights = np.ascontiguousarray(weights, np.float64)
+    ntaps = len(weights)
+    pad = 4 - inp.dim()
+    dims = (1,) * pad + tuple(inp.shape)
+    si = (0,) * pad + tuple(inp.stride())
+    so = (0,) * pad + tuple(out.stride())
+    offs4 = np.zeros((ntaps, 4), np.int64)
+    offs4[:, pad:] = offsets
+    dev = inp.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        taps_dev = None
+        if ntaps > 128:
+            taps_dev = torch.empty(24 * ntaps, dtype=torch.uint8, device=dev)
+        _lib.check(L.nd_amd_correlate(
+            _ptr(inp), _ptr(out), _DT[inp.dtype], _lib.i64_array(dims), _lib.i64_array(si),
+            _lib.i64_array(so), ntaps,
+            offs4.ctypes.data_as(C.POINTER(C.c_int64)),
+            weights.ctypes.data_as(C.POINTER(C.c_double)),
+            _lib.MODES[mode], float(cval), _ptr(taps_dev),
+            0 if taps_dev is None else taps_dev.numel(), _stream_ptr(dev)))
+    return out
+
+
+def convolve(inp, kernel, out=None, mode='reflect', cval=0.0, origin=0):
+    """scipy.ndimage.convolve(inp, kernel, output=out, mode, cval, origin) on a
+    real CUDA tensor; kernel.ndim must equal inp.dim()."""
+    kernel = np.asarray(kernel, np.float64)
+    if kernel.ndim != inp.dim():
+        raise RuntimeError('filter weights array has incorrect shape.')
+    if out is None:
+        out = torch.empty_like(inp)
+    offs, w = footprint(kernel, origin, convolution=True)
+    return correlate_footprint(inp, out, offs, w, mode, cval)
+
+
+# ---------------------------------------------------------------------------
+# non-local means
+# ---------------------------------------------------------------------------
+def pixelwise_nlmeans_3d(arr, output, r, f, sigma, h, n_eff=-1, patch_mode=0,
+                         neff_policy=1, global_shape=None, tile_offset=None,
+                         core=None):
+    """In-place into `output` like the reference.  arr/output: CUDA tensors
+    (N0, N1, N2, nvars), any strides.
+
+    patch_mode 0 = bit-compatible with the compiled reference (LP64: patch
+    loops empty when any f > 0); 1 = true patch distances.
+    neff_policy 1 raises ValueError('No solution') like a current build of the
+    reference, 0 gives the self weight 0 of the shipped C.
+    global_shape/tile_offset/core describe a halo-carrying tile (multi-GPU).
+    """
+    _require_cuda(arr, 'arr')
+    _require_cuda(output, 'output')
+    if arr.dim() != 4 or output.shape != arr.shape or output.dtype != arr.dtype:
+        raise ValueError('arr and output must be 4-D (N0, N1, N2, nvars) and alike')
+    r = [int(v) for v in r]
+    f = [int(v) for v in f]
+    if len(r) != 3 or len(f) != 3:
+        raise ValueError('r and f must have three entries')
+    N = tuple(arr.shape[:3])
+    G = tuple(global_shape) if global_shape is not None else N
+    toff = tuple(tile_offset) if tile_offset is not None else (0, 0, 0)
+    clo = tuple(c[0] for c in core) if core is not None else (0, 0, 0)
+    chi = tuple(c[1] for c in core) if core is not None else N
+    dev = arr.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        status = None
+        if n_eff >= 0 and neff_policy == 1:
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.nd_amd_nlmeans3d(
+            _ptr(arr), _ptr(output), _DT[arr.dtype], _lib.i64_array(N), arr.shape[3],
+            _lib.i64_array(arr.stride()), _lib.i64_array(output.stride()),
+            _lib.u32_array(r), _lib.u32_array(f), float(sigma), float(h), float(n_eff),
+            int(patch_mode), int(neff_policy), _ptr(status),
+            _lib.i64_array(G), _lib.i64_array(toff), _lib.i64_array(clo),
+            _lib.i64_array(chi), _stream_ptr(dev)))
+        if status is not None and int(status.item()) != 0:
+            raise ValueError('No solution')
+    return output

@@ -1,0 +1,117 @@
+"""GPU parity of the omnibus HIP path (through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(planes_np, alpha, n, device, layout='tyx'):
+    import torch
+    from nd_amd import kernels
+    ts = [torch.from_numpy(p).to(device) for p in planes_np]
+    if layout == 'tyx':
+        dims = ('time', 'y', 'x')
+    elif layout == 'yxt':
+        ts = [t.permute(1, 2, 0).contiguous() for t in ts]
+        dims = ('y', 'x', 'time')
+    elif layout == 'yxtv':
+        # the reference's own in-memory form: one (y, x, time, 4) array
+        stacked = torch.stack(ts, dim=-1).permute(1, 2, 0, 3).contiguous()
+        ts = [stacked[..., v] for v in range(4)]
+        dims = ('y', 'x', 'time')
+    ch, z, P = kernels.change_detection(*ts, alpha=alpha, n=n, dims=dims, stats=True)
+    torch.cuda.synchronize()
+    return ch.cpu().numpy(), z.cpu().numpy(), P.cpu().numpy()
+
+
+def _run_oracle(oracle, planes_np, alpha, n):
+    planes = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes_np]   # (y, x, t)
+    return oracle.change_detection_planes(planes, alpha, n, njobs=8, stats=True)
+
+
+def _compare(got, want, rtol=1e-5):
+    ch, z, P = got
+    ch0, z0, P0 = want
+    assert ch.shape == ch0.shape and ch.dtype == np.uint8
+    nbad = int((ch != ch0).sum())
+    assert nbad == 0, '%d change-map bytes differ' % nbad
+    np.testing.assert_allclose(z, z0, rtol=rtol, atol=0, equal_nan=True)
+    np.testing.assert_allclose(P, P0, rtol=rtol, atol=1e-30, equal_nan=True)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('alpha', [0.5, 0.9, 0.99, 0.9999])
+def test_wishart_parity(oracle, device, dtype, alpha):
+    planes = synth.omnibus_stack(seed=7, k=24, ny=96, nx=128, dtype=dtype)
+    want = _run_oracle(oracle, planes, alpha, 9)
+    got = _run_gpu(planes, alpha, 9, device)
+    _compare(got, want)
+    assert want[0].sum() > 0
+
+
+@pytest.mark.parametrize('shape', [(24, 33, 77), (5, 8, 1030), (2, 3, 5), (37, 16, 64),
+                                   (1, 4, 4), (24, 1, 1), (70, 9, 12)])
+@pytest.mark.parametrize('layout', ['tyx', 'yxt', 'yxtv'])
+def test_shapes_and_layouts(oracle, device, shape, layout):
+    k, ny, nx = shape
+    planes = synth.omnibus_stack(seed=k * 1000 + nx, k=k, ny=ny, nx=nx, dtype=np.float32,
+                                 change_frac=0.2)
+    want = _run_oracle(oracle, planes, 0.9, 9)
+    got = _run_gpu(planes, 0.9, 9, device, layout)
+    _compare(got, want)
+
+
+@pytest.mark.parametrize('n', [1, 4, 9, 25])
+def test_number_of_looks(oracle, device, n):
+    planes = synth.omnibus_stack(seed=11, k=12, ny=40, nx=64, looks=max(n, 2), dtype=np.float32,
+                                 change_frac=0.1)
+    want = _run_oracle(oracle, planes, 0.95, n)
+    got = _run_gpu(planes, 0.95, n, device)
+    _compare(got, want)
+
+
+def test_reference_known_answer(oracle, device):
+    """nd/tests/test_change_omnibus.py:6-19."""
+    dims = {'y': 5, 'x': 5, 'time': 10}
+    d1 = synth.reference_test_dataset(dims, [1, 0, 0, 1], 0.1)
+    d2 = synth.reference_test_dataset(dims, [10, 0, 0, 10], 0.1)
+    ds = {v: np.concatenate([d1[v][..., :5], d2[v][..., 5:]], axis=2) for v in d1}
+    for dtype in (np.float64, np.float32):
+        planes = [np.ascontiguousarray(np.moveaxis(ds[v], -1, 0)).astype(dtype)
+                  for v in ('C11', 'C12__re', 'C12__im', 'C22')]
+        ch, z, P = _run_gpu(planes, 0.9, 9, device)
+        assert ch[:, :, 5].all()
+        assert (ch.sum(axis=2) == 1).all()
+        _compare((ch, z, P), _run_oracle(oracle, planes, 0.9, 9))
+
+
+def test_nan_path(oracle, device):
+    """nd/tests/test_change_common.py:21-32: N(0,1) data -> negative determinants -> NaN."""
+    ds = synth.reference_test_dataset({'y': 20, 'x': 30, 'time': 10}, 0, 1)
+    planes = [np.ascontiguousarray(np.moveaxis(ds[v], -1, 0))
+              for v in ('C11', 'C12__re', 'C12__im', 'C22')]
+    got = _run_gpu(planes, 0.01, 1, device)
+    want = _run_oracle(oracle, planes, 0.01, 1)
+    _compare(got, want)
+
+
+def test_degenerate_values(oracle, device):
+    """zeros (nodata), identical matrices, one zero date, infs."""
+    k, ny, nx = 8, 4, 16
+    planes = [p.copy() for p in synth.omnibus_stack(3, k, ny, nx, dtype=np.float32)]
+    for p in planes:
+        p[:, 0, 0] = 0                      # all-zero pixel
+    planes[0][:, 0, 1] = 1; planes[1][:, 0, 1] = 0; planes[2][:, 0, 1] = 0; planes[3][:, 0, 1] = 1
+    for p in planes:
+        p[3, 0, 2] = 0                      # one zero date
+    planes[0][2, 0, 3] = np.inf
+    planes[0][2, 0, 4] = np.nan
+    planes[0][:, 0, 5] *= 1e-30             # underflowing product
+    planes[3][:, 0, 5] *= 1e-30
+    planes[0][:, 0, 6] *= 1e18              # overflowing product
+    planes[3][:, 0, 6] *= 1e18
+    got = _run_gpu(planes, 0.5, 9, device)
+    want = _run_oracle(oracle, planes, 0.5, 9)
+    _compare(got, want)
