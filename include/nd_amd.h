@@ -73,11 +73,17 @@ const char *nd_amd_last_error(void);
  *              -2 rho ln Q and the probability P of the global test over the
  *              whole series (nd/_change.pyx:46-77, 133-151) -- values the
  *              reference only exposes per pixel via its cpdef functions.
- *   workspace: nd_amd_omnibus_c2_workspace_bytes() bytes of device memory,
- *              256-byte aligned; contents are scratch.
+ *   workspace: device scratch, 256-byte aligned.  It holds the list of pixels
+ *              whose global test can fire and a compact copy of their series
+ *              (so the change-point search never re-reads the planes).
+ *              nd_amd_omnibus_c2_workspace_bytes() returns the recommended
+ *              size (room for the series of 1/8 of the pixels) and, through
+ *              *min_bytes, the smallest size the call accepts; anything in
+ *              between trades speed on change-rich rasters for memory.
  * njobs has no equivalent: the whole raster is one launch.
  * ---------------------------------------------------------------------- */
-size_t nd_amd_omnibus_c2_workspace_bytes(int64_t ny, int64_t nx, int64_t k);
+size_t nd_amd_omnibus_c2_workspace_bytes(int dtype, int64_t ny, int64_t nx, int64_t k,
+                                         size_t *min_bytes);
 
 int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void *c12im,
                       const void *c22, int dtype,

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnd_amd.so')
+# ND_AMD_LIB points the loader at an alternative build of the same library (tuning experiments)
+LIB_PATH = os.environ.get('ND_AMD_LIB') or os.path.join(_HERE, 'libnd_amd.so')
 
 F32, F64 = 0, 1
 OK, EINVAL, EWORKSPACE, EHIP, ENOSOLUTION, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -48,7 +49,8 @@ def lib():
     L.nd_amd_last_error.restype = C.c_char_p
     L.nd_amd_last_error.argtypes = []
     L.nd_amd_omnibus_c2_workspace_bytes.restype = C.c_size_t
-    L.nd_amd_omnibus_c2_workspace_bytes.argtypes = [i64, i64, i64]
+    L.nd_amd_omnibus_c2_workspace_bytes.argtypes = [i32, i64, i64, i64,
+                                                    C.POINTER(C.c_size_t)]
     L.nd_amd_omnibus_c2.restype = i32
     L.nd_amd_omnibus_c2.argtypes = ([vp] * 4 + [i32] + [i64] * 6 + [C.c_uint32, dbl]
                                     + [vp, vp, vp, vp, C.c_size_t, vp])

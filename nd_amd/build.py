@@ -34,7 +34,18 @@ def _deps():
     return hdr
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
+    global OBJ, LIB
+    if out is not None:
+        LIB_ = out
+        OBJ_ = objdir or (out + '.obj')
+        force = True
+    else:
+        LIB_, OBJ_ = LIB, OBJ
+    return _build(force, verbose, extra_flags, LIB_, OBJ_)
+
+
+def _build(force, verbose, extra_flags, LIB, OBJ):
     os.makedirs(OBJ, exist_ok=True)
     dep_mtime = max(os.path.getmtime(p) for p in _deps())
     objs = []

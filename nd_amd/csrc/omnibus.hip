@@ -7,15 +7,17 @@
 //       streams the k x 4 planes once with 16-byte loads (coalesced along x, time outer),
 //       keeps the reference's running state (4 `floating` sums + 1 double product of
 //       determinants, nd/_change.pyx:64-69), evaluates the global test over the whole series
-//       (nd/_change.pyx:133-151), zero-fills its slice of the (y,x,time) change map with
-//       16-byte stores and appends the pixels whose global test fires to a compact list
-//       (wave ballot + one atomic per wave).
+//       (nd/_change.pyx:72-76: two double logs), zero-fills its slice of the (y,x,time) change
+//       map with 16-byte stores and appends every pixel whose global test CAN fire
+//       (z >= a host-computed fast-reject bound, see omni_zlo) to a compact list (wave ballot +
+//       one atomic per wave).  When the caller asks for the z / P rasters the chi-square pair
+//       is evaluated here for every pixel instead.
 //
 //   omnibus_c2_search_kernel   ("pass B", FP64-bound)  one lane per listed pixel, series staged
 //       in LDS ([time*4+var][lane], conflict free), runs the sequential change-point search of
-//       nd/_change.pyx:224-257.  All lanes of a wave evaluate one omnibus test per iteration
-//       (global test of segment l, or the next marginal test l..l+j) so the expensive part
-//       (two logs + the chi-square pair) stays converged across the wave.
+//       nd/_change.pyx:224-257.  A test whose z is below the fast-reject bound is decided at
+//       once; any other test parks the lane, and when every lane of the wave is parked or done
+//       the parked lanes evaluate their chi-square pairs together (converged FP64 loop).
 //
 // Numerics follow the C that Cython generates for the reference (nd/_change.c:3501-3590,
 // 6063-6091): `floating` (T) sums and determinants without FMA contraction (this TU is built
@@ -32,6 +34,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
 
 namespace nd_amd {
@@ -42,6 +47,7 @@ struct OmniTabEntry {
     double pklogk;   // (double)(p * j) * log((double)j)      nd/_change.pyx:74
     double omega2;   // omega2(p, j, n, rho) from double rho  nd/_change.pyx:139
     double lgam;     // lgamma(a + 1), a = f/2 = 2 (j - 1)
+    double zlo;      // fast-reject bound: z < zlo  =>  P <= alpha for certain (see omni_zlo)
 };
 
 constexpr int kTabArgs = 96;   // largest k whose table travels as a kernel argument
@@ -90,17 +96,28 @@ __device__ __forceinline__ void chisq_pair_int(const double (&z)[N], int a, doub
         term[i] = lower[i] ? u1[i] : 1.0;
         sum[i] = lower[i] ? 0.0 : 1.0;
     }
-    for (int n = 1; n < 1000000; ++n) {
-        const double inv_n = inv_int(a + 1 + n);
-        const double up = (double)(a - n > 0 ? a - n : 0);
+    // four terms per trip; the reciprocals of the next trip are fetched while this one computes
+    double inv_cur[4], inv_nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) inv_cur[u] = inv_int(a + 2 + u);
+    for (int n = 1; n < 4000000; n += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) inv_nxt[u] = inv_int(a + 6 + n - 1 + u);
         bool more = false;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double ratio = lower[i] ? x[i] * inv_n : up * rx[i];
-            term[i] = term[i] * ratio;
-            sum[i] = sum[i] + term[i];
-            more = more || (term[i] > 1e-17 * sum[i]);
+        for (int u = 0; u < 4; ++u) {
+            const int d = a - (n + u);
+            const double up = (double)(d > 0 ? d : 0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double ratio = lower[i] ? x[i] * inv_cur[u] : up * rx[i];
+                term[i] = term[i] * ratio;
+                sum[i] = sum[i] + term[i];
+                if (u == 3) more = more || (term[i] > 1e-17 * sum[i]);
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) inv_cur[u] = inv_nxt[u];
         if (!__any(more)) break;
     }
 #pragma unroll
@@ -187,14 +204,30 @@ struct OmniGlobalArgs {
     OmniTabEntry e;           // constants of the test over all k matrices
     uint8_t *change;
     T *z_out, *p_out;
-    uint32_t *flag_count, *flag_idx;
+    // The list of pixels whose global test can fire is kept in kShards independent segments
+    // (shard = block index mod kShards), each with its own counter on its own 128-byte line:
+    // one counter would serialise ~2e5 wave-level atomics per launch at ~88 per microsecond.
+    uint32_t *flag_count;     // [kShards] counters, kCounterStride words apart
+    uint32_t *flag_idx;       // [kShards][seg] pixel indices
+    uint32_t seg;             // list entries per shard
     OmniTabEntry *tab_dev;
+    T *dump;                  // [kShards][dump_cap][date][4] series of the first dump_cap pixels of a shard
+    uint32_t dump_cap;
 };
 
 constexpr int kGlobalThreads = 256;
-constexpr int kTimeChunk = 4;
+constexpr int kShards = 128;
+constexpr int kCounterStride = 32;   // uint32 words between shard counters (128 B)
+#ifndef ND_TIME_CHUNK
+#define ND_TIME_CHUNK 4
+#endif
+constexpr int kTimeChunk = ND_TIME_CHUNK;
 
-template <typename T, int PPT>
+// STATS = false: the kernel only decides which pixels CAN fire (z >= zlo) and lists them; the
+//                chi-square evaluation of those happens in pass B.
+// STATS = true : the caller wants the z / P rasters, so P is evaluated for every pixel here and
+//                the list holds exactly the pixels whose global test fires.
+template <typename T, int PPT, bool STATS>
 __global__ void __launch_bounds__(kGlobalThreads)
 omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 {
@@ -280,35 +313,42 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     }
 
     // ---- global test over the whole series ----
-    T z[PPT], P[PPT];
-    double zd[PPT], P1[PPT], P2[PPT];
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        z[i] = z_stat<T>(A[i], k, g.nlooks, g.e);
-        zd[i] = (double)z[i];
-    }
-    chisq_pair_int<PPT>(zd, 2 * (k - 1), g.e.lgam, P1, P2);
+    T z[PPT];
     bool flag[PPT];
     unsigned nflag = 0;
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        P[i] = combine_P<T>(P1[i], P2[i], g.e.omega2);
-        flag[i] = (x0 + i < g.nx) && ((double)P[i] > g.alpha);
-        nflag += flag[i] ? 1u : 0u;
-    }
+    for (int i = 0; i < PPT; ++i) z[i] = z_stat<T>(A[i], k, g.nlooks, g.e);
 
-    if (any_px && (g.z_out != nullptr || g.p_out != nullptr)) {
-        const int64_t pix0 = row * g.nx + x0;
+    if (STATS) {
+        T P[PPT];
+        double zd[PPT], P1[PPT], P2[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) zd[i] = (double)z[i];
+        chisq_pair_int<PPT>(zd, 2 * (k - 1), g.e.lgam, P1, P2);
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            if (x0 + i < g.nx) {
-                if (g.z_out) g.z_out[pix0 + i] = z[i];
-                if (g.p_out) g.p_out[pix0 + i] = P[i];
+            P[i] = combine_P<T>(P1[i], P2[i], g.e.omega2);
+            flag[i] = (x0 + i < g.nx) && ((double)P[i] > g.alpha);
+        }
+        if (any_px) {
+            const int64_t pix0 = row * g.nx + x0;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                if (x0 + i < g.nx) {
+                    if (g.z_out) g.z_out[pix0 + i] = z[i];
+                    if (g.p_out) g.p_out[pix0 + i] = P[i];
+                }
             }
         }
+    } else {
+        // z < zlo (or NaN) cannot fire; everything else is decided exactly in pass B
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) flag[i] = (x0 + i < g.nx) && ((double)z[i] >= g.e.zlo);
     }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) nflag += flag[i] ? 1u : 0u;
 
-    // ---- append flagged pixels to the compact list: one atomic per wave ----
+    // ---- append candidate pixels to the compact list: one atomic per wave ----
     if (__any(nflag != 0u)) {
         unsigned long long m[PPT];
         unsigned tot = 0;
@@ -317,16 +357,128 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
             m[i] = __ballot(flag[i]);
             tot += (unsigned)__popcll(m[i]);
         }
+        const unsigned shard = (unsigned)(b % kShards);
         unsigned base = 0;
-        if (lane == 0) base = atomicAdd(g.flag_count, tot);
+        if (lane == 0) base = atomicAdd(g.flag_count + shard * kCounterStride, tot);
         base = __shfl(base, 0);
         const unsigned long long lt = (1ull << lane) - 1ull;
+        uint32_t *list = g.flag_idx + (size_t)shard * g.seg;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             if (flag[i])
-                g.flag_idx[base + (unsigned)__popcll(m[i] & lt)] =
-                    (uint32_t)(row * g.nx + x0 + i);
+                list[base + (unsigned)__popcll(m[i] & lt)] = (uint32_t)(row * g.nx + x0 + i);
             base += (unsigned)__popcll(m[i]);
+        }
+    }
+}
+
+
+// -----------------------------------------------------------------------------------------
+// pass A, register-retaining form (k <= KMAX): one thread per pixel issues all k x 4 loads at
+// once (maximum memory-level parallelism; 4-byte loads, 256 B per wave instruction, coalesced
+// along x), then folds them in time order.  Because the series is still in registers when the
+// decision falls, a listed pixel writes it to the compact dump ([slot][date][4], 16-byte stores)
+// and pass B never has to gather it from the planes again.
+// -----------------------------------------------------------------------------------------
+template <typename T, int KMAX, bool STATS>
+__global__ void __launch_bounds__(kGlobalThreads)
+omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kGlobalThreads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+
+    // ---- issue every load of the series ----
+    T v[KMAX][4];
+    {
+        const int64_t xc = in ? x0 : g.nx - 1;          // idle lanes re-read the last pixel
+        const int64_t off0 = row * g.sy + xc * g.sx;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            if (t < k) {
+                const int64_t off = off0 + (int64_t)t * g.st;
+                v[t][0] = g.c11[off];
+                v[t][1] = g.c12r[off];
+                v[t][2] = g.c12i[off];
+                v[t][3] = g.c22[off];
+            }
+        }
+    }
+
+    if (g.write_tab && b == 0) {
+        for (int j = tid; j <= k; j += kGlobalThreads) g.tab_dev[j] = tab.e[j];
+    }
+
+    // ---- zero-fill this block's slice of the change map (np.zeros at nd/_change.pyx:275) ----
+    {
+        int64_t npx = g.nx - bpx0;
+        if (npx > kGlobalThreads) npx = kGlobalThreads;
+        uint8_t *ob = g.change + (row * g.nx + bpx0) * (int64_t)k;
+        const int64_t nb = npx * (int64_t)k;
+        int64_t head = (int64_t)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (tid < head) ob[tid] = 0;
+        const int64_t nvec = (nb - head) >> 4;
+        uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
+        for (int64_t i = tid; i < nvec; i += kGlobalThreads) vz[i] = make_uint4(0u, 0u, 0u, 0u);
+        const int64_t tail0 = head + (nvec << 4);
+        if (tail0 + tid < nb) ob[tail0 + tid] = 0;
+    }
+
+    // ---- fold in time order ----
+    Accum<T> A;
+    A.reset();
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+
+    const T z = z_stat<T>(A, k, g.nlooks, g.e);
+    bool flag;
+    if (STATS) {
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair_int<1>(zd, 2 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        flag = in && ((double)P > g.alpha);
+        if (in) {
+            const int64_t pix = row * g.nx + x0;
+            if (g.z_out) g.z_out[pix] = z;
+            if (g.p_out) g.p_out[pix] = P;
+        }
+    } else {
+        flag = in && ((double)z >= g.e.zlo);
+    }
+
+    // ---- list + dump ----
+    if (__any(flag)) {
+        const unsigned long long m = __ballot(flag);
+        const unsigned shard = (unsigned)(b % kShards);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag) {
+            const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
+            if (slot < g.dump_cap) {
+                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) {
+                    if (t < k) {
+                        Pack<T, 4> q;
+                        q.v[0] = v[t][0];
+                        q.v[1] = v[t][1];
+                        q.v[2] = v[t][2];
+                        q.v[3] = v[t][3];
+                        *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                    }
+                }
+            }
         }
     }
 }
@@ -343,7 +495,10 @@ struct OmniSearchArgs {
     double nlooks, alpha;
     uint8_t *change;
     const uint32_t *flag_count, *flag_idx;
+    uint32_t seg;
     const OmniTabEntry *tab;
+    const T *dump;
+    uint32_t dump_cap;
 };
 
 template <typename T, bool USE_LDS>
@@ -353,25 +508,42 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     T *lds = reinterpret_cast<T *>(nd_smem);
     const int lane = threadIdx.x;
     const int k = s.k;
-    const uint32_t n = *s.flag_count;
+    // blocks shard, shard + kShards, ... work through the list of one shard
+    const unsigned shard = blockIdx.x % kShards;
+    const unsigned lblock = blockIdx.x / kShards;
+    const unsigned nlblock = gridDim.x / kShards;
+    const uint32_t n = s.flag_count[shard * kCounterStride];
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
 
-    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
         const uint32_t idx = base + lane;
         const bool active = idx < n;
-        const int64_t pix = active ? (int64_t)s.flag_idx[idx] : 0;
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
         const int64_t row = pix / s.nx;
         const int64_t col = pix - row * s.nx;
         const int64_t off = row * s.sy + col * s.sx;
 
         if (USE_LDS) {
             // stage this lane's series: lds[(t*4+v)*64 + lane]; each lane reads back only its
-            // own column, so no barrier is needed
-            for (int t = 0; t < k; ++t) {
-                const int64_t o = off + (int64_t)t * s.st;
-                lds[(t * 4 + 0) * 64 + lane] = s.c11[o];
-                lds[(t * 4 + 1) * 64 + lane] = s.c12r[o];
-                lds[(t * 4 + 2) * 64 + lane] = s.c12i[o];
-                lds[(t * 4 + 3) * 64 + lane] = s.c22[o];
+            // own column, so no barrier is needed.  Source: the dump pass A wrote (one 16/32-byte
+            // load per date), or the planes for pixels beyond the dump capacity.
+            if (idx < s.dump_cap) {
+                const T *d = s.dump + ((int64_t)shard * s.dump_cap + idx) * (int64_t)(4 * k);
+                for (int t = 0; t < k; ++t) {
+                    const Pack<T, 4> q = *reinterpret_cast<const Pack<T, 4> *>(d + 4 * t);
+                    lds[(t * 4 + 0) * 64 + lane] = q.v[0];
+                    lds[(t * 4 + 1) * 64 + lane] = q.v[1];
+                    lds[(t * 4 + 2) * 64 + lane] = q.v[2];
+                    lds[(t * 4 + 3) * 64 + lane] = q.v[3];
+                }
+            } else {
+                for (int t = 0; t < k; ++t) {
+                    const int64_t o = off + (int64_t)t * s.st;
+                    lds[(t * 4 + 0) * 64 + lane] = s.c11[o];
+                    lds[(t * 4 + 1) * 64 + lane] = s.c12r[o];
+                    lds[(t * 4 + 2) * 64 + lane] = s.c12i[o];
+                    lds[(t * 4 + 3) * 64 + lane] = s.c22[o];
+                }
             }
         }
         auto load_step = [&](Accum<T> &A, int t) {
@@ -384,18 +556,46 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
             }
         };
 
-        // state machine of nd/_change.pyx:235-257; one omnibus evaluation per iteration
+        // State machine of nd/_change.pyx:235-257.  Each lane walks through its omnibus tests;
+        // a test whose z is below the fast-reject bound is decided on the spot, any other test
+        // parks the lane until every lane of the wave is parked or finished, then all parked
+        // lanes evaluate their chi-square pair together.
         Accum<T> A;
         A.reset();
         int l = 0;
         int j = 0;             // marginal state: A holds ts[l : l+j-1]
         bool marginal = false;
         bool done = !active;
+        bool parked = false;
+        int jj = 0;
+        T zp = 0;
         uint8_t *res = s.change + pix * (int64_t)k;
 
-        while (__any(!done)) {
-            if (!done) {
-                int jj;
+        auto decide = [&](bool change) {
+            if (!marginal) {
+                if (!change) {
+                    done = true;                       // :241-242
+                } else {
+                    marginal = true;
+                    A.reset();
+                    load_step(A, l);                   // j = 1 carries no test
+                    j = 2;
+                }
+            } else {
+                const int r = j - 1;                   // :250
+                if (change || j >= k - l) {
+                    if (change) res[l + r] = 1;        // :252
+                    l = l + r;                         // :255
+                    marginal = false;
+                    if (l >= k - 1) done = true;       // :256
+                } else {
+                    j = j + 1;
+                }
+            }
+        };
+
+        for (;;) {
+            while (!done && !parked) {
                 if (!marginal) {
                     // global hypothesis H0_l over ts[l:]  (:238-240)
                     A.reset();
@@ -407,31 +607,20 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     jj = j;
                 }
                 const OmniTabEntry e = s.tab[jj];
-                const T z = z_stat<T>(A, jj, s.nlooks, e);
-                double zd[1] = {(double)z}, P1[1], P2[1];
+                zp = z_stat<T>(A, jj, s.nlooks, e);
+                if ((double)zp >= e.zlo)
+                    parked = true;
+                else
+                    decide(false);                     // z < zlo or NaN: P <= alpha / P is NaN
+            }
+            if (!__any(parked)) break;
+            if (parked) {
+                const OmniTabEntry e = s.tab[jj];
+                double zd[1] = {(double)zp}, P1[1], P2[1];
                 chisq_pair_int<1>(zd, 2 * (jj - 1), e.lgam, P1, P2);
                 const T P = combine_P<T>(P1[0], P2[0], e.omega2);
-                const bool change = ((double)P > s.alpha);
-                if (!marginal) {
-                    if (!change) {
-                        done = true;                       // :241-242
-                    } else {
-                        marginal = true;
-                        A.reset();
-                        load_step(A, l);                   // j = 1 carries no test
-                        j = 2;
-                    }
-                } else {
-                    const int r = j - 1;                   // :250
-                    if (change || j >= k - l) {
-                        if (change) res[l + r] = 1;        // :252
-                        l = l + r;                         // :255
-                        marginal = false;
-                        if (l >= k - 1) done = true;       // :256
-                    } else {
-                        j = j + 1;
-                    }
-                }
+                parked = false;
+                decide((double)P > s.alpha);
             }
         }
     }
@@ -453,8 +642,80 @@ static double host_omega2(double p, double k, double n, double rho)
             ((((p * p) * (k - 1.0)) / 4.0) * ((1.0 - (1.0 / rho)) * (1.0 - (1.0 / rho)))));
 }
 
+// host twin of chisq_pair_int (N = 1, no table), used only to place the fast-reject bound
+static void host_chisq_pair(double z, int a, double lgam_a1, double *P1, double *P2)
+{
+    if (!(z > 0.0)) {
+        *P1 = *P2 = (z <= 0.0) ? 0.0 : NAN;
+        return;
+    }
+    if (!(z < INFINITY)) {
+        *P1 = *P2 = NAN;
+        return;
+    }
+    const double x = 0.5 * z;
+    const bool lower = x < (double)(a + 1);
+    const double ta = exp(((double)a * log(x) - x) - lgam_a1);
+    const double u1 = x / (double)(a + 1);
+    double term = lower ? u1 : 1.0, sum = lower ? 0.0 : 1.0;
+    for (int n = 1; n < 4000000; ++n) {
+        const int d = a - n;
+        const double ratio = lower ? x / (double)(a + 1 + n) : (double)(d > 0 ? d : 0) / x;
+        term *= ratio;
+        sum += term;
+        if (!(term > 1e-17 * sum)) break;
+    }
+    if (lower) {
+        *P1 = ta * ((1.0 + u1) + sum);
+        *P2 = ta * sum;
+    } else {
+        const double qa = (ta * (double)a / x) * sum;
+        *P1 = 1.0 - qa;
+        *P2 = 1.0 - (qa + ta + ta * u1);
+    }
+}
+
+// Fast-reject bound of the test over j matrices: a z such that every z' < zlo has
+// P(z') <= alpha for certain, so the chi-square pair need not be evaluated.
+//   P(z) = P1 + omega2 (P2 - P1) is non-decreasing in z when 0 <= omega2 <= 1 (a mixture of two
+//   chi-square CDFs).  The kernel's P differs from the exact one by the roundings to T of P1, P2,
+//   their difference and the result, plus ~1e-13 from the series: bounded by `margin` below.
+//   zlo = the z where the exact P equals alpha - margin, stepped down by 1e-9 relative.
+//   Outside 0 <= omega2 <= 1 (e.g. n = 1, small j), or for alpha - margin < 0, the bound is
+//   -inf: every non-NaN z is evaluated exactly.
 template <typename T>
-static OmniTabEntry make_entry(int j, uint32_t n_looks)
+static double omni_zlo(int j, double omega2, double lgam, double alpha)
+{
+    if (j < 2) return -INFINITY;
+    if (!(omega2 >= 0.0 && omega2 <= 1.0) || !(alpha == alpha)) return -INFINITY;
+    const double ulp = sizeof(T) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+    const double margin = 16.0 * ulp * (1.0 + 2.0 * omega2) + 1e-11;
+    const double target = alpha - margin;
+    if (target < 0.0) return -INFINITY;
+    if (target >= 1.0) return INFINITY;          // P <= 1 < alpha + margin: nothing can fire
+    const int a = 2 * (j - 1);
+    auto Pz = [&](double z) {
+        double p1, p2;
+        host_chisq_pair(z, a, lgam, &p1, &p2);
+        return p1 + omega2 * (p2 - p1);
+    };
+    double lo = 0.0, hi = 4.0 * (double)a + 64.0;
+    int guard = 0;
+    while (Pz(hi) < target && guard++ < 64) hi *= 2.0;
+    if (guard >= 64) return INFINITY;            // target unreachable in double: P never exceeds it
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (Pz(mid) < target)
+            lo = mid;
+        else
+            hi = mid;
+        if (hi - lo <= 1e-15 * hi) break;
+    }
+    return lo * (1.0 - 1e-9);
+}
+
+template <typename T>
+static OmniTabEntry make_entry(int j, uint32_t n_looks, double alpha)
 {
     OmniTabEntry e;
     const double p = 2.0, k = (double)j, n = (double)n_looks;
@@ -465,31 +726,134 @@ static OmniTabEntry make_entry(int j, uint32_t n_looks)
     e.pklogk = (double)pk * log(k);
     e.omega2 = host_omega2(p, k, n, rho);
     e.lgam = lgamma((double)(2 * (j - 1)) + 1.0);
+    // z = m2rho * logQ grows with -logQ only when rho > 0; otherwise keep the exact path
+    e.zlo = (e.m2rho < 0.0) ? omni_zlo<T>(j, e.omega2, e.lgam, alpha) : -INFINITY;
     return e;
+}
+
+// small cache of per-call tables: they depend only on (k, n_looks, alpha, dtype)
+struct TabKey {
+    int k, dtype;
+    uint32_t n;
+    double alpha;
+};
+struct TabCacheEntry {
+    TabKey key;
+    std::vector<OmniTabEntry> tab;
+};
+static std::mutex g_tab_mu;
+static std::vector<TabCacheEntry> g_tab_cache;
+
+template <typename T>
+static std::vector<OmniTabEntry> get_table(int k, uint32_t n_looks, double alpha)
+{
+    const int dtype = sizeof(T) == 4 ? ND_AMD_F32 : ND_AMD_F64;
+    {
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        for (const auto &c : g_tab_cache)
+            if (c.key.k == k && c.key.dtype == dtype && c.key.n == n_looks &&
+                memcmp(&c.key.alpha, &alpha, sizeof(double)) == 0)
+                return c.tab;
+    }
+    std::vector<OmniTabEntry> tab((size_t)k + 1);
+    memset(tab.data(), 0, tab.size() * sizeof(OmniTabEntry));
+    for (int j = 1; j <= k; ++j) tab[j] = make_entry<T>(j, n_looks, alpha);
+    {
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        if (g_tab_cache.size() >= 32) g_tab_cache.erase(g_tab_cache.begin());
+        TabCacheEntry c;
+        c.key.k = k;
+        c.key.dtype = dtype;
+        c.key.n = n_looks;
+        c.key.alpha = alpha;
+        c.tab = tab;
+        g_tab_cache.push_back(c);
+    }
+    return tab;
 }
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// workspace: [counter][per-j table][pixel list: npix x u32][dump: cap x k x 4 x T]
+// `min_total` is what the call needs; everything beyond it is used as dump capacity.  The
+// recommended size holds the series of 1/8 of the pixels (a listed pixel beyond the capacity is
+// gathered from the planes by pass B instead: slower, never wrong).
 struct OmniWorkspace {
-    size_t off_count, off_tab, off_idx, total;
+    size_t off_count, off_tab, off_idx, off_dump, min_total, recommended;
 };
 
-static OmniWorkspace omni_layout(int64_t npix, int64_t k)
+constexpr int kRetainMaxF32 = 48, kRetainMaxF64 = 24;
+
+constexpr size_t kCounterBytes = (size_t)kShards * kCounterStride * sizeof(uint32_t);
+
+// List entries per shard: an upper bound on the pixels of the blocks one shard can receive,
+// valid for both pass-A forms (256-pixel blocks, or 256*VPPT-pixel blocks with VPPT <= 4) and for
+// row-wise as well as flattened launches:
+//   ceil(nb_v / kShards) * 256 * VPPT  <=  2 * nb256 + (2 * ny + 256) * VPPT   (kShards = 128)
+static uint32_t omni_seg(int64_t npix, int64_t ny)
+{
+    static_assert(kShards == 128, "bound below assumes 128 shards");
+    const int64_t nb256 = ceil_div(npix, kGlobalThreads) + ny;
+    return (uint32_t)(2 * nb256 + (2 * ny + 256) * 4 + 256);
+}
+
+static OmniWorkspace omni_layout(int64_t npix, int64_t ny, int64_t k, size_t elem)
 {
     OmniWorkspace w;
     w.off_count = 0;
-    w.off_tab = 256;
+    w.off_tab = align256(kCounterBytes);
     w.off_idx = w.off_tab + align256((size_t)(k + 1) * sizeof(OmniTabEntry));
-    w.total = w.off_idx + align256((size_t)npix * sizeof(uint32_t));
+    w.off_dump = w.off_idx + align256((size_t)omni_seg(npix, ny) * kShards * sizeof(uint32_t));
+    w.min_total = w.off_dump;
+    const size_t per = (size_t)k * 4 * elem;
+    size_t cap = ((size_t)npix / 8 / kShards + 63) & ~(size_t)63;   // per shard
+    w.recommended = w.off_dump + align256(cap * kShards * per);
     return w;
 }
 
 template <typename T, int PPT>
 static void launch_global(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_t nblocks,
-                          hipStream_t stream)
+                          bool stats, hipStream_t stream)
 {
-    hipLaunchKernelGGL((omnibus_c2_global_kernel<T, PPT>), dim3((unsigned)nblocks),
-                       dim3(kGlobalThreads), 0, stream, g, tab);
+    if (stats)
+        hipLaunchKernelGGL((omnibus_c2_global_kernel<T, PPT, true>), dim3((unsigned)nblocks),
+                           dim3(kGlobalThreads), 0, stream, g, tab);
+    else
+        hipLaunchKernelGGL((omnibus_c2_global_kernel<T, PPT, false>), dim3((unsigned)nblocks),
+                           dim3(kGlobalThreads), 0, stream, g, tab);
+}
+
+template <typename T, int KMAX>
+static void launch_retain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_t nblocks,
+                            bool stats, hipStream_t stream)
+{
+    if (stats)
+        hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, true>), dim3((unsigned)nblocks),
+                           dim3(kGlobalThreads), 0, stream, g, tab);
+    else
+        hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, false>), dim3((unsigned)nblocks),
+                           dim3(kGlobalThreads), 0, stream, g, tab);
+}
+
+template <typename T>
+static void launch_retain(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_t nblocks,
+                          bool stats, hipStream_t stream)
+{
+    const int k = g.k;
+    if (k <= 8)
+        launch_retain_k<T, 8>(g, tab, nblocks, stats, stream);
+    else if (k <= 16)
+        launch_retain_k<T, 16>(g, tab, nblocks, stats, stream);
+    else if (k <= 24)
+        launch_retain_k<T, 24>(g, tab, nblocks, stats, stream);
+    else if (sizeof(T) == 4) {
+        if (k <= 32)
+            launch_retain_k<float, 32>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab,
+                                       nblocks, stats, stream);
+        else
+            launch_retain_k<float, 48>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab,
+                                       nblocks, stats, stream);
+    }
 }
 
 template <typename T>
@@ -500,10 +864,10 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                            hipStream_t stream)
 {
     const int64_t npix = ny * nx;
-    const OmniWorkspace w = omni_layout(npix, k);
-    if (workspace == nullptr || workspace_bytes < w.total) {
-        set_error("nd_amd_omnibus_c2: workspace of %zu bytes needed, %zu given", w.total,
-                  workspace_bytes);
+    const OmniWorkspace w = omni_layout(npix, ny, k, sizeof(T));
+    if (workspace == nullptr || workspace_bytes < w.min_total) {
+        set_error("nd_amd_omnibus_c2: workspace of at least %zu bytes needed, %zu given",
+                  w.min_total, workspace_bytes);
         return ND_AMD_EWORKSPACE;
     }
     if (((uintptr_t)workspace & 255) != 0) {
@@ -516,28 +880,21 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     uint32_t *flag_idx = reinterpret_cast<uint32_t *>(ws + w.off_idx);
 
     // per-j constants (host, double, same expression order as nd/_change.c:2926-2975)
+    const std::vector<OmniTabEntry> htab = get_table<T>((int)k, n_looks, alpha);
     OmniTab tab;
     memset(&tab, 0, sizeof(tab));
     const bool tab_in_args = (k <= kTabArgs);
     if (tab_in_args) {
-        for (int j = 1; j <= (int)k; ++j) tab.e[j] = make_entry<T>(j, n_looks);
+        memcpy(tab.e, htab.data(), htab.size() * sizeof(OmniTabEntry));
     } else {
-        // large k: table goes through a (pageable) host copy; not graph-capturable
-        OmniTabEntry *h = (OmniTabEntry *)malloc((size_t)(k + 1) * sizeof(OmniTabEntry));
-        if (!h) {
-            set_error("nd_amd_omnibus_c2: out of host memory");
-            return ND_AMD_EINVAL;
-        }
-        memset(h, 0, sizeof(OmniTabEntry));
-        for (int j = 1; j <= (int)k; ++j) h[j] = make_entry<T>(j, n_looks);
-        hipError_t e = hipMemcpyAsync(tab_dev, h, (size_t)(k + 1) * sizeof(OmniTabEntry),
+        // large k: the table goes through a pageable host copy (synchronises; not capturable)
+        hipError_t e = hipMemcpyAsync(tab_dev, htab.data(), htab.size() * sizeof(OmniTabEntry),
                                       hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        free(h);
         ND_HIP_CHECK(e);
     }
 
-    ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, sizeof(uint32_t), stream));
+    ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
 
     // ---- pass A ----
     OmniGlobalArgs<T> g;
@@ -552,13 +909,23 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     g.write_tab = tab_in_args ? 1 : 0;
     g.nlooks = (double)n_looks;
     g.alpha = alpha;
-    g.e = make_entry<T>((int)k, n_looks);
+    g.e = htab[(size_t)k];
     g.change = change;
     g.z_out = static_cast<T *>(z_out);
     g.p_out = static_cast<T *>(p_out);
     g.flag_count = flag_count;
     g.flag_idx = flag_idx;
     g.tab_dev = tab_dev;
+    const bool stats = (z_out != nullptr) || (p_out != nullptr);
+    const bool retain = k <= (sizeof(T) == 4 ? kRetainMaxF32 : kRetainMaxF64);
+    {
+        const size_t per = (size_t)k * 4 * sizeof(T);
+        size_t cap = retain ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
+        g.seg = omni_seg(npix, ny);
+        if (cap > g.seg) cap = g.seg;
+        g.dump = reinterpret_cast<T *>(ws + w.off_dump);
+        g.dump_cap = (uint32_t)cap;
+    }
 
     constexpr int VPPT = 16 / sizeof(T);   // pixels per 16-byte load
     const size_t es = sizeof(T);
@@ -568,7 +935,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     const bool flat = (sx == 1) && (sy == nx);
     g.nx = flat ? npix : nx;
     g.nrows = flat ? 1 : ny;
-    const int ppt = aligned ? VPPT : 1;
+    const int ppt = retain ? 1 : (aligned ? VPPT : 1);
     g.blocks_per_row = ceil_div(g.nx, (int64_t)kGlobalThreads * ppt);
     const int64_t nblocks = g.blocks_per_row * g.nrows;
     if (nblocks > 0x7fffffffLL) {
@@ -578,10 +945,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     }
     {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-        if (aligned)
-            launch_global<T, VPPT>(g, tab, nblocks, stream);
+        if (retain)
+            launch_retain<T>(g, tab, nblocks, stats, stream);
+        else if (aligned)
+            launch_global<T, VPPT>(g, tab, nblocks, stats, stream);
         else
-            launch_global<T, 1>(g, tab, nblocks, stream);
+            launch_global<T, 1>(g, tab, nblocks, stats, stream);
     }
     ND_HIP_CHECK(hipGetLastError());
 
@@ -601,11 +970,17 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     s.change = change;
     s.flag_count = flag_count;
     s.flag_idx = flag_idx;
+    s.seg = g.seg;
     s.tab = tab_dev;
+    s.dump = g.dump;
+    s.dump_cap = g.dump_cap;
     const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T);
     const bool use_lds = lds_bytes <= 64 * 1024;
-    int64_t sblocks = ceil_div(npix, 64);
-    if (sblocks > 8192) sblocks = 8192;
+    // kShards x (blocks per shard); a shard's blocks stride through its list
+    int64_t per_shard = ceil_div(ceil_div(npix, kShards), 64);
+    if (per_shard > 64) per_shard = 64;
+    if (per_shard < 1) per_shard = 1;
+    const int64_t sblocks = per_shard * kShards;
     {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
         if (use_lds)
@@ -623,10 +998,13 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
 
 using namespace nd_amd;
 
-extern "C" size_t nd_amd_omnibus_c2_workspace_bytes(int64_t ny, int64_t nx, int64_t k)
+extern "C" size_t nd_amd_omnibus_c2_workspace_bytes(int dtype, int64_t ny, int64_t nx, int64_t k,
+                                                    size_t *min_bytes)
 {
     if (ny < 0 || nx < 0 || k < 0) return 0;
-    return omni_layout(ny * nx, k).total;
+    const OmniWorkspace w = omni_layout(ny * nx, ny, k, dtype == ND_AMD_F64 ? 8 : 4);
+    if (min_bytes) *min_bytes = w.min_total;
+    return w.recommended;
 }
 
 extern "C" int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void *c12im,

@@ -72,7 +72,7 @@ def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x')
         z = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
         P = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
         if ny * nx * k > 0:
-            nbytes = L.nd_amd_omnibus_c2_workspace_bytes(ny, nx, k)
+            nbytes = L.nd_amd_omnibus_c2_workspace_bytes(_DT[c11.dtype], ny, nx, k, None)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(L.nd_amd_omnibus_c2(
                 _ptr(c11), _ptr(c12re), _ptr(c12im), _ptr(c22), _DT[c11.dtype],

@@ -1,0 +1,59 @@
+"""
+nd_amd/synth.py -- synthetic SAR covariance stacks generated on the device
+(bench.py and the large-size property tests).
+
+n-look complex-Wishart dual-pol samples: s1, s2 ~ CN(0, 1) per look,
+C11 = mean|s1|^2, C22 = mean|s2|^2, C12 = mean(s1 conj(s2)); a fraction of the
+pixels gets a x`factor` power step at a random date.  Layout: one float tensor
+(4, time, y, x), planes [C11, C12re, C12im, C22], x fastest.
+"""
+import torch
+
+
+# The date planes of a device stack are padded by this many elements: with a power-of-two plane
+# size (4096 x 4096 x 4 B = 64 MiB) the 96 streams a pixel block reads would otherwise start at
+# addresses that differ only above bit 26, which costs ~7 % of HBM read bandwidth on MI355X
+# (profiles/r01_probe_bandwidth.txt).
+DATE_PAD = 64
+
+
+def empty_stack(nvar, k, ny, nx, device, dtype=torch.float32, date_pad=DATE_PAD):
+    """Uninitialised planar stack (nvar, time, y, x), x fastest, each date plane
+    contiguous and `date_pad` elements apart from the next (16-byte aligned)."""
+    npix = ny * nx
+    pad = date_pad if npix % 1024 == 0 else 0
+    buf = torch.empty((nvar, k, npix + pad), dtype=dtype, device=device)
+    return buf[:, :, :npix].view(nvar, k, ny, nx)
+
+
+def wishart_c2_stack(k, ny, nx, looks=9, seed=1234, device='cuda', dtype=torch.float32,
+                     change_frac=0.01, factor=4.0, corr=0.3, date_pad=DATE_PAD):
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    out = empty_stack(4, k, ny, nx, dev, dtype, date_pad)
+    if change_frac > 0:
+        mask = torch.rand((ny, nx), generator=gen, device=dev) < change_frac
+        t0 = torch.randint(1, max(k, 2), (ny, nx), generator=gen, device=dev)
+    c = (1.0 - corr * corr) ** 0.5
+    for t in range(k):
+        c11 = torch.zeros((ny, nx), dtype=torch.float32, device=dev)
+        c22 = torch.zeros_like(c11)
+        c12r = torch.zeros_like(c11)
+        c12i = torch.zeros_like(c11)
+        for _ in range(looks):
+            a = torch.randn((4, ny, nx), generator=gen, device=dev) * (0.5 ** 0.5)
+            s1r, s1i = a[0], a[1]
+            s2r = corr * s1r + c * a[2]
+            s2i = corr * s1i + c * a[3]
+            c11 += s1r * s1r + s1i * s1i
+            c22 += s2r * s2r + s2i * s2i
+            c12r += s1r * s2r + s1i * s2i          # s1 conj(s2)
+            c12i += s1i * s2r - s1r * s2i
+        planes = [c11, c12r, c12i, c22]
+        for v in range(4):
+            p = planes[v] / looks
+            if change_frac > 0:
+                p = torch.where(mask & (t0 <= t), p * factor, p)
+            out[v, t] = p.to(dtype)
+    return out
