@@ -48,6 +48,9 @@ struct OmniTabEntry {
     double omega2;   // omega2(p, j, n, rho) from double rho  nd/_change.pyx:139
     double lgam;     // lgamma(a + 1), a = f/2 = 2 (j - 1)
     double zlo;      // fast-reject bound: z < zlo  =>  P <= alpha for certain (see omni_zlo)
+    double zlo_a;    // the same bound for z_approx (hardware f32 log2), widened by its error
+    double zhi;      // fast-accept bound: zhi < z < inf  =>  P > alpha for certain
+    double zhi_a;    // the same for z_approx
 };
 
 constexpr int kTabArgs = 96;   // largest k whose table travels as a kernel argument
@@ -173,6 +176,28 @@ __device__ __forceinline__ T z_stat(const Accum<T> &A, int j, double nlooks, con
     const double logQ =
         nlooks * ((e.pklogk + log(A.prod)) - ((double)j * log((double)det_of_sum)));
     return (T)(e.m2rho * logQ);
+}
+
+// Cheap stand-in for z_stat used only to screen: ln x = (exponent + log2(mantissa)) ln 2 with the
+// mantissa's log2 from the hardware v_log_f32 (1 ulp on [0.5, 1), i.e. <= 6e-8 absolute).  NaN,
+// +-inf and zero arguments propagate exactly as in the double evaluation, so z_approx is NaN or
+// infinite precisely when z is.  |z_approx - z| <= |m2rho| n (k+1) 1e-7; the host widens zlo_a by
+// ten times that (omni tables), so z_approx < zlo_a implies z < zlo.
+__device__ __forceinline__ double approx_ln(double x)
+{
+    int e;
+    const double m = frexp(x, &e);
+    return ((double)e + (double)__log2f((float)m)) * 0.6931471805599453;
+}
+
+template <typename T>
+__device__ __forceinline__ double z_approx(const Accum<T> &A, int j, double nlooks,
+                                           const OmniTabEntry &e)
+{
+    const T det_of_sum = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
+    const double logQ = nlooks * ((e.pklogk + approx_ln(A.prod)) -
+                                  ((double)j * approx_ln((double)det_of_sum)));
+    return e.m2rho * logQ;
 }
 
 // P = P1 + omega2 (P2 - P1) with the reference's rounding points (nd/_change.c:6087-6089)
@@ -313,13 +338,13 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     }
 
     // ---- global test over the whole series ----
-    T z[PPT];
     bool flag[PPT];
     unsigned nflag = 0;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) z[i] = z_stat<T>(A[i], k, g.nlooks, g.e);
 
     if (STATS) {
+        T z[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) z[i] = z_stat<T>(A[i], k, g.nlooks, g.e);
         T P[PPT];
         double zd[PPT], P1[PPT], P2[PPT];
 #pragma unroll
@@ -341,9 +366,10 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
             }
         }
     } else {
-        // z < zlo (or NaN) cannot fire; everything else is decided exactly in pass B
+        // z_approx < zlo_a (or NaN) cannot fire; everything else is decided exactly in pass B
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) flag[i] = (x0 + i < g.nx) && ((double)z[i] >= g.e.zlo);
+        for (int i = 0; i < PPT; ++i)
+            flag[i] = (x0 + i < g.nx) && (z_approx<T>(A[i], k, g.nlooks, g.e) >= g.e.zlo_a);
     }
 #pragma unroll
     for (int i = 0; i < PPT; ++i) nflag += flag[i] ? 1u : 0u;
@@ -438,9 +464,9 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     for (int t = 0; t < KMAX; ++t)
         if (t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
 
-    const T z = z_stat<T>(A, k, g.nlooks, g.e);
     bool flag;
     if (STATS) {
+        const T z = z_stat<T>(A, k, g.nlooks, g.e);
         double zd[1] = {(double)z}, P1[1], P2[1];
         chisq_pair_int<1>(zd, 2 * (k - 1), g.e.lgam, P1, P2);
         const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
@@ -451,7 +477,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
             if (g.p_out) g.p_out[pix] = P;
         }
     } else {
-        flag = in && ((double)z >= g.e.zlo);
+        flag = in && (z_approx<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
     }
 
     // ---- list + dump ----
@@ -508,6 +534,14 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     T *lds = reinterpret_cast<T *>(nd_smem);
     const int lane = threadIdx.x;
     const int k = s.k;
+    // per-j constants: LDS copy behind the series region (USE_LDS), else read from global
+    const OmniTabEntry *tabp = s.tab;
+    if (USE_LDS) {
+        OmniTabEntry *tl = reinterpret_cast<OmniTabEntry *>(nd_smem + (size_t)k * 4 * 64 * sizeof(T));
+        for (int j = lane; j <= k; j += 64) tl[j] = s.tab[j];
+        __syncthreads();
+        tabp = tl;
+    }
     // blocks shard, shard + kShards, ... work through the list of one shard
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards;
@@ -526,23 +560,47 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
         if (USE_LDS) {
             // stage this lane's series: lds[(t*4+v)*64 + lane]; each lane reads back only its
             // own column, so no barrier is needed.  Source: the dump pass A wrote (one 16/32-byte
-            // load per date), or the planes for pixels beyond the dump capacity.
+            // load per date, eight dates in flight), or the planes for pixels beyond the dump
+            // capacity.
             if (idx < s.dump_cap) {
                 const T *d = s.dump + ((int64_t)shard * s.dump_cap + idx) * (int64_t)(4 * k);
-                for (int t = 0; t < k; ++t) {
-                    const Pack<T, 4> q = *reinterpret_cast<const Pack<T, 4> *>(d + 4 * t);
-                    lds[(t * 4 + 0) * 64 + lane] = q.v[0];
-                    lds[(t * 4 + 1) * 64 + lane] = q.v[1];
-                    lds[(t * 4 + 2) * 64 + lane] = q.v[2];
-                    lds[(t * 4 + 3) * 64 + lane] = q.v[3];
+                for (int t0 = 0; t0 < k; t0 += 8) {
+                    Pack<T, 4> q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (t0 + u < k)
+                            q[u] = *reinterpret_cast<const Pack<T, 4> *>(d + 4 * (t0 + u));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (t0 + u < k) {
+                            const int t = t0 + u;
+                            lds[(t * 4 + 0) * 64 + lane] = q[u].v[0];
+                            lds[(t * 4 + 1) * 64 + lane] = q[u].v[1];
+                            lds[(t * 4 + 2) * 64 + lane] = q[u].v[2];
+                            lds[(t * 4 + 3) * 64 + lane] = q[u].v[3];
+                        }
                 }
             } else {
-                for (int t = 0; t < k; ++t) {
-                    const int64_t o = off + (int64_t)t * s.st;
-                    lds[(t * 4 + 0) * 64 + lane] = s.c11[o];
-                    lds[(t * 4 + 1) * 64 + lane] = s.c12r[o];
-                    lds[(t * 4 + 2) * 64 + lane] = s.c12i[o];
-                    lds[(t * 4 + 3) * 64 + lane] = s.c22[o];
+                for (int t0 = 0; t0 < k; t0 += 4) {
+                    T q[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (t0 + u < k) {
+                            const int64_t o = off + (int64_t)(t0 + u) * s.st;
+                            q[u][0] = s.c11[o];
+                            q[u][1] = s.c12r[o];
+                            q[u][2] = s.c12i[o];
+                            q[u][3] = s.c22[o];
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (t0 + u < k) {
+                            const int t = t0 + u;
+                            lds[(t * 4 + 0) * 64 + lane] = q[u][0];
+                            lds[(t * 4 + 1) * 64 + lane] = q[u][1];
+                            lds[(t * 4 + 2) * 64 + lane] = q[u][2];
+                            lds[(t * 4 + 3) * 64 + lane] = q[u][3];
+                        }
                 }
             }
         }
@@ -606,16 +664,27 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     load_step(A, l + j - 1);
                     jj = j;
                 }
-                const OmniTabEntry e = s.tab[jj];
-                zp = z_stat<T>(A, jj, s.nlooks, e);
-                if ((double)zp >= e.zlo)
+                const OmniTabEntry e = tabp[jj];
+                const double za = z_approx<T>(A, jj, s.nlooks, e);
+                // 0 = cannot fire (z < zlo, or NaN: P <= alpha / P is NaN), 1 = fires for certain
+                // (zhi < z < inf), 2 = inside the band: needs the chi-square pair
+                int verdict = 0;
+                if (za >= e.zlo_a) {
+                    verdict = 1;
+                    if (!(za > e.zhi_a && za < INFINITY)) {
+                        zp = z_stat<T>(A, jj, s.nlooks, e);
+                        const double zd = (double)zp;
+                        verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                    }
+                }
+                if (verdict == 2)
                     parked = true;
                 else
-                    decide(false);                     // z < zlo or NaN: P <= alpha / P is NaN
+                    decide(verdict == 1);
             }
             if (!__any(parked)) break;
             if (parked) {
-                const OmniTabEntry e = s.tab[jj];
+                const OmniTabEntry e = tabp[jj];
                 double zd[1] = {(double)zp}, P1[1], P2[1];
                 chisq_pair_int<1>(zd, 2 * (jj - 1), e.lgam, P1, P2);
                 const T P = combine_P<T>(P1[0], P2[0], e.omega2);
@@ -675,43 +744,61 @@ static void host_chisq_pair(double z, int a, double lgam_a1, double *P1, double 
     }
 }
 
-// Fast-reject bound of the test over j matrices: a z such that every z' < zlo has
-// P(z') <= alpha for certain, so the chi-square pair need not be evaluated.
+// Decision bounds of the test over j matrices: every z' < zlo has P(z') <= alpha for certain and
+// every finite z' > zhi has P(z') > alpha for certain, so the chi-square pair is only needed for
+// zlo <= z <= zhi (and for z = +inf, whose P is NaN).
 //   P(z) = P1 + omega2 (P2 - P1) is non-decreasing in z when 0 <= omega2 <= 1 (a mixture of two
 //   chi-square CDFs).  The kernel's P differs from the exact one by the roundings to T of P1, P2,
 //   their difference and the result, plus ~1e-13 from the series: bounded by `margin` below.
-//   zlo = the z where the exact P equals alpha - margin, stepped down by 1e-9 relative.
-//   Outside 0 <= omega2 <= 1 (e.g. n = 1, small j), or for alpha - margin < 0, the bound is
-//   -inf: every non-NaN z is evaluated exactly.
+//   zlo = the z where the exact P equals alpha - margin, stepped down by 1e-9 relative;
+//   zhi = the z where it equals alpha + margin, stepped up by 1e-9 relative.
+//   Outside 0 <= omega2 <= 1 (e.g. n = 1, small j), or when a target leaves (0, 1), the bound is
+//   -inf / +inf: every non-NaN z is evaluated exactly.
 template <typename T>
-static double omni_zlo(int j, double omega2, double lgam, double alpha)
+static void omni_bounds(int j, double omega2, double lgam, double alpha, double *zlo, double *zhi)
 {
-    if (j < 2) return -INFINITY;
-    if (!(omega2 >= 0.0 && omega2 <= 1.0) || !(alpha == alpha)) return -INFINITY;
+    *zlo = -INFINITY;    // evaluate everything exactly
+    *zhi = INFINITY;     // never accept without evaluating
+    if (j < 2) return;
+    if (!(omega2 >= 0.0 && omega2 <= 1.0) || !(alpha == alpha)) return;
     const double ulp = sizeof(T) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
     const double margin = 16.0 * ulp * (1.0 + 2.0 * omega2) + 1e-11;
-    const double target = alpha - margin;
-    if (target < 0.0) return -INFINITY;
-    if (target >= 1.0) return INFINITY;          // P <= 1 < alpha + margin: nothing can fire
     const int a = 2 * (j - 1);
     auto Pz = [&](double z) {
         double p1, p2;
         host_chisq_pair(z, a, lgam, &p1, &p2);
         return p1 + omega2 * (p2 - p1);
     };
-    double lo = 0.0, hi = 4.0 * (double)a + 64.0;
-    int guard = 0;
-    while (Pz(hi) < target && guard++ < 64) hi *= 2.0;
-    if (guard >= 64) return INFINITY;            // target unreachable in double: P never exceeds it
-    for (int it = 0; it < 200; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (Pz(mid) < target)
-            lo = mid;
+    // smallest z (to 1e-15 relative) with exact P(z) >= target, as a bracketing pair lo < hi
+    auto quantile = [&](double target, double *lo_out, double *hi_out) -> bool {
+        double lo = 0.0, hi = 4.0 * (double)a + 64.0;
+        int guard = 0;
+        while (Pz(hi) < target && guard++ < 64) hi *= 2.0;
+        if (guard >= 64) return false;
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (Pz(mid) < target)
+                lo = mid;
+            else
+                hi = mid;
+            if (hi - lo <= 1e-15 * hi) break;
+        }
+        *lo_out = lo;
+        *hi_out = hi;
+        return true;
+    };
+    double lo, hi;
+    const double tlo = alpha - margin;
+    if (tlo >= 1.0) {
+        *zlo = INFINITY;                      // P <= 1 < alpha: nothing can fire
+    } else if (tlo >= 0.0) {
+        if (quantile(tlo, &lo, &hi))
+            *zlo = lo * (1.0 - 1e-9);
         else
-            hi = mid;
-        if (hi - lo <= 1e-15 * hi) break;
+            *zlo = INFINITY;                  // target unreachable in double
     }
-    return lo * (1.0 - 1e-9);
+    const double thi = alpha + margin;
+    if (thi > 0.0 && thi < 1.0 - 1e-9 && quantile(thi, &lo, &hi)) *zhi = hi * (1.0 + 1e-9);
 }
 
 template <typename T>
@@ -727,7 +814,15 @@ static OmniTabEntry make_entry(int j, uint32_t n_looks, double alpha)
     e.omega2 = host_omega2(p, k, n, rho);
     e.lgam = lgamma((double)(2 * (j - 1)) + 1.0);
     // z = m2rho * logQ grows with -logQ only when rho > 0; otherwise keep the exact path
-    e.zlo = (e.m2rho < 0.0) ? omni_zlo<T>(j, e.omega2, e.lgam, alpha) : -INFINITY;
+    omni_bounds<T>(j, e.omega2, e.lgam, alpha, &e.zlo, &e.zhi);
+    // bounds for the f32-log2 screen: ten times its worst-case error outside [zlo, zhi]
+    const double aerr = 1e-6 * fabs(e.m2rho) * n * (k + 1.0);
+    e.zlo_a = (e.zlo > -INFINITY && e.zlo < INFINITY) ? e.zlo - (aerr + 1e-9 * fabs(e.zlo)) : e.zlo;
+    e.zhi_a = (e.zhi < INFINITY) ? e.zhi + (aerr + 1e-9 * fabs(e.zhi)) : INFINITY;
+    if (!(aerr == aerr) || !(aerr < INFINITY)) {   // rho is NaN/inf for j = 1: exact path only
+        e.zlo = e.zlo_a = -INFINITY;
+        e.zhi = e.zhi_a = INFINITY;
+    }
     return e;
 }
 
@@ -974,7 +1069,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     s.tab = tab_dev;
     s.dump = g.dump;
     s.dump_cap = g.dump_cap;
-    const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T);
+    const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T) + (size_t)(k + 1) * sizeof(OmniTabEntry);
     const bool use_lds = lds_bytes <= 64 * 1024;
     // kShards x (blocks per shard); a shard's blocks stride through its list
     int64_t per_shard = ceil_div(ceil_div(npix, kShards), 64);

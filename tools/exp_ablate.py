@@ -1,0 +1,70 @@
+"""Tuning experiment (GPU box): ablations of omnibus pass A (retain form). Builds patched copies of
+nd_amd/csrc/omnibus.hip into gpurun_out/exp and times pass A / pass B with the library's event timers."""
+import os, subprocess, sys, json, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'gpurun_out', 'exp')
+os.makedirs(OUT, exist_ok=True)
+HIPCC = '/opt/rocm/bin/hipcc'
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math']
+
+def child():
+    import torch
+    from nd_amd import _lib, kernels, synth
+    dev = torch.device('cuda:0')
+    st = synth.wishart_c2_stack(24, 4096, 4096, seed=1234, device=dev, change_frac=0.01)
+    for _ in range(3):
+        kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9)
+    _lib.timing_enable(64)
+    for _ in range(10):
+        kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9)
+    torch.cuda.synchronize()
+    kt = _lib.timing_collect()
+    a = [ms for n, ms in kt if n == 'omnibus_c2_global']
+    b = [ms for n, ms in kt if n == 'omnibus_c2_search']
+    print(json.dumps({'passA_ms': round(sum(a) / len(a), 4), 'passB_ms': round(sum(b) / len(b), 4)}))
+
+def build_variant(name, patches, extra=()):
+    d = os.path.join(OUT, 'src_' + name)
+    shutil.rmtree(d, ignore_errors=True)
+    shutil.copytree(os.path.join(ROOT, 'nd_amd', 'csrc'), d, ignore=shutil.ignore_patterns('_build'))
+    # the sources include ../../include/nd_amd.h
+    os.makedirs(os.path.join(OUT, 'include'), exist_ok=True)
+    shutil.copy(os.path.join(ROOT, 'include', 'nd_amd.h'), os.path.join(OUT, 'include', 'nd_amd.h'))
+    p = os.path.join(d, 'omnibus.hip')
+    s = open(p).read()
+    for old, new in patches:
+        assert old in s, (name, old[:60])
+        s = s.replace(old, new)
+    s = s.replace('#include "common.hpp"', '#include "common.hpp"')
+    open(p, 'w').write(s)
+    hp = os.path.join(d, 'common.hpp')
+    h = open(hp).read().replace('../../include/nd_amd.h', os.path.join(OUT, 'include', 'nd_amd.h'))
+    open(hp, 'w').write(h)
+    so = os.path.join(OUT, 'lib_%s.so' % name)
+    srcs = [os.path.join(d, f) for f in os.listdir(d) if f.endswith('.hip')]
+    subprocess.check_call([HIPCC] + FLAGS + list(extra) + ['-shared', '-o', so] + srcs)
+    return so
+
+ZERO = """        for (int64_t i = tid; i < nvec; i += kGlobalThreads) vz[i] = make_uint4(0u, 0u, 0u, 0u);"""
+LISTC = """    if (__any(flag)) {
+        const unsigned long long m = __ballot(flag);"""
+VARIANTS = {
+    'base': [],
+    'nozero': [(ZERO, "        if (nvec < 0) vz[0] = make_uint4(0u, 0u, 0u, 0u);")],
+    'nolist': [(LISTC, """    if (__any(flag) && g.k > 1000) {
+        const unsigned long long m = __ballot(flag);""")],
+    'nodump': [("            if (slot < g.dump_cap) {\n                T *d = g.dump + ((int64_t)shard", "            if (slot < g.dump_cap && g.k > 1000) {\n                T *d = g.dump + ((int64_t)shard")],
+    'noz': [("    const T z = z_stat<T>(A, k, g.nlooks, g.e);\n    bool flag;", "    const T z = (T)A.prod + A.s11 + A.s22 + A.s12r + A.s12i;\n    bool flag;")],
+}
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'child':
+        child(); sys.exit(0)
+    names = sys.argv[1:] or list(VARIANTS)
+    for name in names:
+        so = build_variant(name, VARIANTS[name])
+        env = dict(os.environ, ND_AMD_LIB=so)
+        r = subprocess.run([sys.executable, __file__, 'child'], env=env, capture_output=True, text=True)
+        print(name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-800:])
+        sys.stdout.flush()
