@@ -209,6 +209,22 @@ __device__ __forceinline__ T combine_P(double P1, double P2, double omega2)
     return (T)((double)p1 + (omega2 * (double)d));
 }
 
+// raw buffer load of one element: descriptor (SGPRs) + lane byte offset + scalar byte offset
+template <typename T>
+__device__ __forceinline__ T buffer_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ float buffer_load<float>(__amdgpu_buffer_rsrc_t rsrc, unsigned voff,
+                                                    unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+}
+template <>
+__device__ __forceinline__ double buffer_load<double>(__amdgpu_buffer_rsrc_t rsrc, unsigned voff,
+                                                      unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+}
+
 template <typename T, int N>
 struct alignas(sizeof(T) * N) Pack {
     T v[N];
@@ -406,7 +422,9 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 // decision falls, a listed pixel writes it to the compact dump ([slot][date][4], 16-byte stores)
 // and pass B never has to gather it from the planes again.
 // -----------------------------------------------------------------------------------------
-template <typename T, int KMAX, bool STATS>
+// EXACT: k == KMAX and stride_x == 1, so the per-date guards fold away, the loads issue as one
+// straight run and address a uniform base plus a 32-bit lane offset
+template <typename T, int KMAX, bool EXACT, bool STATS>
 __global__ void __launch_bounds__(kGlobalThreads)
 omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 {
@@ -422,8 +440,28 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 
     // ---- issue every load of the series ----
     T v[KMAX][4];
-    {
-        const int64_t xc = in ? x0 : g.nx - 1;          // idle lanes re-read the last pixel
+    if (EXACT) {
+        // x-contiguous planes: buffer loads through one descriptor per plane (base = first pixel
+        // of this block, uniform), a per-date scalar byte offset and a 32-bit lane offset -- no
+        // 64-bit per-lane address arithmetic, which keeps the kernel at 4 waves per SIMD.
+        const int64_t ub = row * g.sy + bpx0;
+        const unsigned lx = in ? (unsigned)tid : (unsigned)(g.nx - 1 - bpx0);   // idle lanes re-read the last pixel
+        const unsigned voff = lx * (unsigned)sizeof(T);
+        const auto r11 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c11 + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r12r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12r + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r12i = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12i + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r22 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c22 + ub), 0, 0x7fffffff, 0x00020000);
+        const unsigned sstep = (unsigned)g.st * (unsigned)sizeof(T);   // host guarantees k * st * sizeof(T) < 2^31
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const unsigned soff = (unsigned)t * sstep;
+            v[t][0] = buffer_load<T>(r11, voff, soff);
+            v[t][1] = buffer_load<T>(r12r, voff, soff);
+            v[t][2] = buffer_load<T>(r12i, voff, soff);
+            v[t][3] = buffer_load<T>(r22, voff, soff);
+        }
+    } else {
+        const int64_t xc = in ? x0 : g.nx - 1;
         const int64_t off0 = row * g.sy + xc * g.sx;
 #pragma unroll
         for (int t = 0; t < KMAX; ++t) {
@@ -441,28 +479,12 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
         for (int j = tid; j <= k; j += kGlobalThreads) g.tab_dev[j] = tab.e[j];
     }
 
-    // ---- zero-fill this block's slice of the change map (np.zeros at nd/_change.pyx:275) ----
-    {
-        int64_t npx = g.nx - bpx0;
-        if (npx > kGlobalThreads) npx = kGlobalThreads;
-        uint8_t *ob = g.change + (row * g.nx + bpx0) * (int64_t)k;
-        const int64_t nb = npx * (int64_t)k;
-        int64_t head = (int64_t)((16 - ((uintptr_t)ob & 15)) & 15);
-        if (head > nb) head = nb;
-        if (tid < head) ob[tid] = 0;
-        const int64_t nvec = (nb - head) >> 4;
-        uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
-        for (int64_t i = tid; i < nvec; i += kGlobalThreads) vz[i] = make_uint4(0u, 0u, 0u, 0u);
-        const int64_t tail0 = head + (nvec << 4);
-        if (tail0 + tid < nb) ob[tail0 + tid] = 0;
-    }
-
     // ---- fold in time order ----
     Accum<T> A;
     A.reset();
 #pragma unroll
     for (int t = 0; t < KMAX; ++t)
-        if (t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+        if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
 
     bool flag;
     if (STATS) {
@@ -495,7 +517,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
                 T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
 #pragma unroll
                 for (int t = 0; t < KMAX; ++t) {
-                    if (t < k) {
+                    if (EXACT || t < k) {
                         Pack<T, 4> q;
                         q.v[0] = v[t][0];
                         q.v[1] = v[t][1];
@@ -506,6 +528,24 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
                 }
             }
         }
+    }
+
+    // ---- zero-fill this block's slice of the change map (np.zeros at nd/_change.pyx:275).
+    // Issued last so that no wait on the loads or on the atomic above also has to wait for
+    // these stores (vmcnt retires in order). ----
+    {
+        const int64_t left = g.nx - bpx0;
+        const int npx = left > kGlobalThreads ? kGlobalThreads : (int)left;
+        uint8_t *ob = g.change + (row * g.nx + bpx0) * (int64_t)k;
+        const int nb = npx * k;                              // <= 256 * k bytes
+        int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (tid < head) ob[tid] = 0;
+        const int nvec = (nb - head) >> 4;
+        uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
+        for (int i = tid; i < nvec; i += kGlobalThreads) vz[i] = make_uint4(0u, 0u, 0u, 0u);
+        const int tail0 = head + (nvec << 4);
+        if (tail0 + tid < nb) ob[tail0 + tid] = 0;
     }
 }
 
@@ -922,12 +962,26 @@ template <typename T, int KMAX>
 static void launch_retain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_t nblocks,
                             bool stats, hipStream_t stream)
 {
-    if (stats)
-        hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, true>), dim3((unsigned)nblocks),
-                           dim3(kGlobalThreads), 0, stream, g, tab);
-    else
-        hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, false>), dim3((unsigned)nblocks),
-                           dim3(kGlobalThreads), 0, stream, g, tab);
+    const dim3 grid((unsigned)nblocks), block(kGlobalThreads);
+#ifndef ND_RETAIN_EXACT
+#define ND_RETAIN_EXACT 1
+#endif
+    if (ND_RETAIN_EXACT && g.k == KMAX && g.sx == 1 &&
+        (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0) {
+        if (stats)
+            hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, true, true>), grid, block, 0,
+                               stream, g, tab);
+        else
+            hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, true, false>), grid, block, 0,
+                               stream, g, tab);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, false, true>), grid, block, 0,
+                               stream, g, tab);
+        else
+            hipLaunchKernelGGL((omnibus_c2_retain_kernel<T, KMAX, false, false>), grid, block, 0,
+                               stream, g, tab);
+    }
 }
 
 template <typename T>

@@ -46,16 +46,12 @@ def build_variant(name, patches, extra=()):
     subprocess.check_call([HIPCC] + FLAGS + list(extra) + ['-shared', '-o', so] + srcs)
     return so
 
-ZERO = """        for (int64_t i = tid; i < nvec; i += kGlobalThreads) vz[i] = make_uint4(0u, 0u, 0u, 0u);"""
-LISTC = """    if (__any(flag)) {
-        const unsigned long long m = __ballot(flag);"""
+BUF_OLD = "            v[t][0] = buffer_load<T>(r11, voff, soff);\n            v[t][1] = buffer_load<T>(r12r, voff, soff);\n            v[t][2] = buffer_load<T>(r12i, voff, soff);\n            v[t][3] = buffer_load<T>(r22, voff, soff);"
+BUF_NEW = "            const int64_t o = ub + (int64_t)t * g.st;\n            v[t][0] = (g.c11 + o)[lx];\n            v[t][1] = (g.c12r + o)[lx];\n            v[t][2] = (g.c12i + o)[lx];\n            v[t][3] = (g.c22 + o)[lx];"
 VARIANTS = {
-    'base': [],
-    'nozero': [(ZERO, "        if (nvec < 0) vz[0] = make_uint4(0u, 0u, 0u, 0u);")],
-    'nolist': [(LISTC, """    if (__any(flag) && g.k > 1000) {
-        const unsigned long long m = __ballot(flag);""")],
-    'nodump': [("            if (slot < g.dump_cap) {\n                T *d = g.dump + ((int64_t)shard", "            if (slot < g.dump_cap && g.k > 1000) {\n                T *d = g.dump + ((int64_t)shard")],
-    'noz': [("    const T z = z_stat<T>(A, k, g.nlooks, g.e);\n    bool flag;", "    const T z = (T)A.prod + A.s11 + A.s22 + A.s12r + A.s12i;\n    bool flag;")],
+    'base_buffer_exact': [],
+    'global_exact': [(BUF_OLD, BUF_NEW)],
+    'noexact': [("#define ND_RETAIN_EXACT 1", "#define ND_RETAIN_EXACT 0")],
 }
 
 if __name__ == '__main__':
