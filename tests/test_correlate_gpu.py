@@ -1,0 +1,109 @@
+"""GPU parity of the convolution HIP path (through the C ABI) against scipy.ndimage.convolve
+(golden vectors + live scipy) and the CPU oracle.  The reference's own tests demand bit equality
+with scipy (nd/tests/test_convolution_filter.py:39-47)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'convolve_scipy.npz')
+
+
+def _gpu_convolve(a, k, device, **kw):
+    import torch
+    from nd_amd import kernels
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    out = kernels.convolve(t, k, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _cases():
+    g = np.load(GOLD)
+    return sorted({n.split('__')[0] for n in g.files if not n.startswith('complex')})
+
+
+@pytest.mark.parametrize('name', _cases())
+def test_golden_bit_exact(device, name):
+    g = np.load(GOLD)
+    a, k, want = g[name + '__in'], g[name + '__k'], g[name + '__out']
+    got = _gpu_convolve(a, k, device, mode=str(g[name + '__mode']), cval=float(g[name + '__cval']))
+    np.testing.assert_array_equal(got, want)
+
+
+def test_golden_complex(device):
+    """nd/filters.py:261-265: real and imaginary parts are convolved separately."""
+    g = np.load(GOLD)
+    z, k, want = g['complex64__in'], g['complex64__k'], g['complex64__out']
+    re = _gpu_convolve(np.real(z), k, device)
+    im = _gpu_convolve(np.imag(z), k, device)
+    np.testing.assert_array_equal(re + 1j * im, want)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('mode', ['reflect', 'constant', 'nearest', 'mirror', 'wrap'])
+def test_live_scipy_random(device, dtype, mode):
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(3)
+    for shape, kshape in [((6, 37, 41), (1, 5, 5)), ((3, 9, 130), (1, 3, 7)), ((2, 2, 17, 19), (1, 1, 4, 6)),
+                          ((33, 65), (7, 3)), ((5, 4, 3), (3, 3, 3)), ((1, 1), (3, 3)), ((7,), (5,))]:
+        a = rng.normal(size=shape).astype(dtype)
+        k = rng.normal(size=kshape)
+        want = ndi.convolve(a, k, mode=mode, cval=-1.25)
+        got = _gpu_convolve(a, k, device, mode=mode, cval=-1.25)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_origin_and_zero_taps(device):
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(4)
+    a = rng.normal(size=(20, 23)).astype(np.float32)
+    k = rng.normal(size=(5, 4))
+    k[1, 2] = 0.0                      # scipy drops |w| <= eps taps from the footprint
+    k[3, 0] = 1e-17
+    for origin in (0, (1, -1), (-2, 1)):
+        want = ndi.convolve(a, k, origin=origin)
+        got = _gpu_convolve(a, k, device, origin=origin)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_strided_views_and_oracle(oracle, device):
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(8)
+    base = rng.normal(size=(4, 30, 34)).astype(np.float32)
+    k = np.ones((1, 5, 5)) / 25.0
+    t = torch.from_numpy(base).to(device)
+    view = t.permute(1, 2, 0)                          # (y, x, time) view of planar memory
+    out = torch.empty_like(view)
+    kernels.convolve(view, k.transpose(1, 2, 0), out=out)
+    torch.cuda.synchronize()
+    want = oracle.convolve(np.ascontiguousarray(base.transpose(1, 2, 0)), k.transpose(1, 2, 0))
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+def test_large_footprint_uses_device_taps(device):
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(9)
+    a = rng.normal(size=(40, 44)).astype(np.float64)
+    k = rng.normal(size=(13, 11))                      # 143 taps > 128
+    np.testing.assert_array_equal(_gpu_convolve(a, k, device), ndi.convolve(a, k))
+
+
+def test_full_size_properties(device):
+    """Config-size checks that need no oracle: a normalised boxcar leaves a constant raster
+    unchanged (to rounding), is linear, and the identity kernel is exact."""
+    import torch
+    from nd_amd import kernels
+    t = torch.full((4, 2048, 2048), 3.25, device=device)
+    k = np.ones((1, 5, 5)) / 25.0
+    out = kernels.convolve(t, k)
+    assert float((out - 3.25).abs().max()) < 1e-6
+    x = torch.randn((2, 1024, 1024), device=device)
+    ident = np.zeros((1, 3, 3)); ident[0, 1, 1] = 1
+    assert torch.equal(kernels.convolve(x, ident), x)
+    k3 = np.arange(9, dtype=float).reshape(1, 3, 3)
+    a = kernels.convolve(x, k3)
+    b = kernels.convolve(x * 2, k3)
+    assert float((b - 2 * a).abs().max()) == 0.0      # exact: scaling by 2 commutes with rounding

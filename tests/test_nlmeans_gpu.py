@@ -1,0 +1,111 @@
+"""GPU parity of the non-local-means HIP path (through the C ABI) against the REAL reference
+kernel (golden vectors from oracle/_ref) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'nlmeans_ref.npz')
+RTOL = 1e-5      # north_star tolerance for floats; most cases are bit-exact
+
+
+def _gpu_nlm(a, r, f, sigma, h, n_eff, device, patch_mode=0, neff_policy=1, permute=None):
+    import torch
+    from nd_amd import kernels
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    if permute is not None:
+        # same logical array, different memory order (planar [var][...])
+        inv = np.argsort(permute)
+        t = t.permute(*permute).contiguous().permute(*inv)
+    out = torch.empty_like(t)
+    kernels.pixelwise_nlmeans_3d(t, out, r, f, sigma, h, n_eff, patch_mode=patch_mode,
+                                 neff_policy=neff_policy)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _cases():
+    g = np.load(GOLD)
+    return sorted({n.split('__')[0] for n in g.files if '__' in n})
+
+
+@pytest.mark.parametrize('name', _cases())
+@pytest.mark.parametrize('permute', [None, (3, 2, 0, 1)])
+def test_golden_reference(device, name, permute):
+    g = np.load(GOLD)
+    a, par, want = g[name + '__in'], g[name + '__par'], g[name + '__out']
+    r, f = par[:3].astype(int), par[3:6].astype(int)
+    got = _gpu_nlm(a, r, f, par[6], par[7], par[8], device, permute=permute)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    if (f > 0).any() and par[8] < 0:
+        # compiled-reference semantics: all weights are exactly 1 -> same f32 sums, bit for bit
+        np.testing.assert_array_equal(got, want)
+
+
+def test_patch_mode_1_pinned_through_reference(device):
+    g = np.load(GOLD)
+    a, par, want = g['pm1_in'], g['pm1_par'], g['pm1_out_interior']
+    r, f = par[:3].astype(int), par[3:6].astype(int)
+    got = _gpu_nlm(a[:, :, None, None], r, f, par[6], par[7], par[8], device, patch_mode=1)
+    m, n = r[0] + f[0], r[1] + f[1]
+    np.testing.assert_allclose(got[m:-m, n:-n, 0, 0], want, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('patch_mode', [0, 1])
+def test_oracle_random(oracle, device, dtype, patch_mode):
+    rng = np.random.default_rng(12)
+    for shape, r, f, s, h, ne in [((13, 17, 3, 2), (2, 3, 1), (1, 1, 1), 0.5, 0.7, -1),
+                                  ((24, 25, 1, 1), (4, 4, 0), (2, 2, 0), 0.3, 0.4, -1),
+                                  ((9, 8, 4, 3), (1, 2, 1), (0, 0, 0), 0.2, 0.6, -1),
+                                  ((10, 11, 2, 4), (2, 2, 0), (1, 1, 0), 1.0, 3.0, 4.0),
+                                  ((1, 16, 16, 2), (0, 2, 2), (0, 1, 1), 0.5, 0.5, -1)]:
+        a = rng.gamma(4.0, 0.25, shape).astype(dtype)
+        want = np.empty_like(a)
+        oracle.pixelwise_nlmeans_3d(a, want, r, f, s, h, ne, neff_policy=0, njobs=8,
+                                    patch_mode=patch_mode)
+        got = _gpu_nlm(a, r, f, s, h, ne, device, patch_mode=patch_mode, neff_policy=0)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+
+
+def test_zero_radius_is_identity(device):
+    """nd/tests/test_nlmeans_filter.py:17-25."""
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(20, 20, 10, 4))
+    got = _gpu_nlm(a, (0, 0, 0), (0, 0, 0), 1, 1, -1, device)
+    np.testing.assert_array_equal(got, a)
+
+
+def test_no_solution_raises(device):
+    """find_weight fails where n_eff - 1 > W^2 / W2 (nd/_filters.pyx:310-311): ValueError like a
+    current build of the reference; policy 0 gives the self weight 0 of the shipped C."""
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(12, 12, 1, 1)).astype(np.float32)
+    with pytest.raises(ValueError, match='No solution'):
+        _gpu_nlm(a, (2, 2, 0), (0, 0, 0), 0.1, 0.1, 30.0, device)
+    out = _gpu_nlm(a, (2, 2, 0), (0, 0, 0), 0.1, 0.1, 30.0, device, neff_policy=0)
+    assert out.shape == a.shape
+
+
+def test_tile_with_halo_equals_untiled(device):
+    """y-tiles that carry r+f halo rows reproduce the untiled result (the multi-GPU layout)."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(6)
+    a = rng.gamma(4.0, 0.25, (40, 21, 2, 1)).astype(np.float32)
+    r, f = (3, 2, 0), (1, 1, 0)
+    full = _gpu_nlm(a, r, f, 0.4, 0.5, -1, device, patch_mode=1)
+    halo = r[0] + f[0]
+    t = torch.from_numpy(a).to(device)
+    out = torch.zeros_like(t)
+    for lo, hi in [(0, 14), (14, 27), (27, 40)]:
+        tlo, thi = max(lo - halo, 0), min(hi + halo, 40)
+        tile = t[tlo:thi].contiguous()
+        tout = torch.empty_like(tile)
+        kernels.pixelwise_nlmeans_3d(tile, tout, r, f, 0.4, 0.5, -1, patch_mode=1,
+                                     global_shape=(40, 21, 2), tile_offset=(tlo, 0, 0),
+                                     core=((lo - tlo, hi - tlo), (0, 21), (0, 2)))
+        out[lo:hi] = tout[lo - tlo:hi - tlo]
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), full)

@@ -8,13 +8,11 @@ def run(n):
     for _ in range(n):
         out = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9)
     return out
-run(3)
-_lib.timing_enable(256)
-torch.cuda.synchronize(); time.sleep(0.05)
-t0 = time.perf_counter(); run(50); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+run(5)
+_lib.timing_enable(1024)
+torch.cuda.synchronize()
+t0 = time.perf_counter(); out = run(50); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 kt = _lib.timing_collect()
-a = [round(ms, 3) for n, ms in kt if n == 'omnibus_c2_global']
-b = [round(ms, 3) for n, ms in kt if n == 'omnibus_c2_search']
-print('wall per step ms', dt / 50 * 1e3)
-print('A', a)
-print('B', b)
+a = sum(ms for n, ms in kt if n == 'omnibus_c2_global') / 50
+b = sum(ms for n, ms in kt if n == 'omnibus_c2_search') / 50
+print('chunks', os.environ.get('ND_AMD_OMNIBUS_CHUNKS'), 'wall per step ms %.4f' % (dt / 50 * 1e3), 'sumA %.4f sumB %.4f' % (a, b), 'changes', int(out.sum().item()))
