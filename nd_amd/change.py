@@ -1,0 +1,124 @@
+"""
+nd_amd/change.py -- OmnibusTest on the GPU behind the reference's interface (nd/change.py).
+
+`OmnibusTest(ml=None, n=1, alpha=0.01, njobs=1).apply(ds)` takes a dataset in covariance-matrix
+format (variables C11, C22 real and C12 complex -- or already split into C12__re / C12__im) and
+returns a boolean DataArray `change` with dims ('y', 'x', 'time'), exactly as
+nd.change.OmnibusTest does (nd/change.py:32-116); the per-pixel work that the reference hands to
+`nd._change.change_detection` (nd/change.py:69) runs in the HIP kernels of nd_amd/csrc/omnibus.hip.
+"""
+import numpy as np
+import torch
+
+from . import _adapter, _device, _lib, kernels, synth
+from .algorithm import Algorithm, wrap_algorithm
+from .filters import BoxcarFilter
+from .io import disassemble_complex
+
+__all__ = ['ChangeDetection', 'OmnibusTest', 'omnibus', 'omnibus_statistics']
+
+_VARS = ['C11', 'C12__re', 'C12__im', 'C22']      # column order of nd/change.py:66
+
+
+class ChangeDetection(Algorithm):
+
+    njobs = 1
+
+    def __init__(self, njobs=1):
+        self.njobs = njobs
+
+
+def _covariance_planes(ds_m, device):
+    """The four variables as one planar device stack (4, time, y, x), x fastest -- the layout the
+    streaming kernel wants (coalesced along x, one plane per date)."""
+    arrs = []
+    for v in _VARS:
+        if v not in ds_m.data_vars:
+            raise KeyError("OmnibusTest needs the variables C11, C12 (or C12__re/C12__im) and "
+                           "C22; '%s' is missing" % v)
+        da = ds_m[v]
+        for d in ('y', 'x', 'time'):
+            if d not in da.dims:
+                raise ValueError("variable %s lacks dimension '%s'" % (v, d))
+        if len(da.dims) != 3:
+            raise ValueError('variable %s must have exactly the dimensions y, x, time' % v)
+        arrs.append(da.transpose('time', 'y', 'x').values)
+    dtype = np.result_type(*[_device.np_dtype(a) for a in arrs])
+    if dtype not in (np.float32, np.float64):
+        dtype = np.dtype(np.float64)           # integer / half input: the reference would refuse
+    tdtype = torch.float32 if dtype == np.float32 else torch.float64
+    k, ny, nx = arrs[0].shape
+    stack = synth.empty_stack(4, k, ny, nx, device, tdtype)
+    for i, a in enumerate(arrs):
+        stack[i].copy_(_device.to_device(a, device))
+    return stack
+
+
+def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None, stats=False):
+    ns = _adapter.namespace(ds)
+    ds.persist() if hasattr(ds, 'persist') else None
+    ds_m = disassemble_complex(ds)
+    if ml is not None:
+        ds_m = BoxcarFilter(w=ml).apply(ds_m)
+        n = ml ** 2
+    host = not any(_device.is_tensor(ds_m[v].values) for v in _VARS if v in ds_m.data_vars)
+    dev = _device.device_of(*[ds_m[v].values for v in _VARS if v in ds_m.data_vars], device=device)
+    with torch.cuda.device(dev):
+        stack = _covariance_planes(ds_m, dev)
+        res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
+                                       n=int(n), dims=('time', 'y', 'x'), stats=stats)
+    change = res[0] if stats else res
+    change = change.bool()
+    dims = ['y', 'x', 'time']
+    data = change.cpu().numpy() if host else change
+    change_arr = ns.DataArray(data, dims=dims, coords=ds.coords, attrs=ds.attrs, name='change')
+    if not stats:
+        return change_arr
+    z, P = (t.cpu().numpy() if host else t for t in res[1:])
+    return (change_arr,
+            ns.DataArray(z, dims=['y', 'x'], attrs=ds.attrs, name='z'),
+            ns.DataArray(P, dims=['y', 'x'], attrs=ds.attrs, name='P'))
+
+
+class OmnibusTest(ChangeDetection):
+    """
+    OmnibusTest
+
+    The change detection algorithm by Conradsen et al. (2015), on MI355X.
+
+    Parameters
+    ----------
+    ml : int, optional
+        Multilooking window size. By default, no multilooking is performed and
+        the dataset is assumed to already be multilooked.
+    n : int, optional
+        The number of looks in `ds`. If `ml` is specified this parameter is
+        ignored (default: 1).
+    alpha : float (0. ... 1.), optional
+        The significance level (default: 0.01).
+    kwargs : dict, optional
+        Extra keyword arguments to be applied to ``ChangeDetection.__init__``
+        (``njobs`` is accepted for compatibility: the whole raster is one GPU launch).
+    """
+
+    def __init__(self, ml=None, n=1, alpha=0.01, *args, **kwargs):
+        _lib.lib()          # ImportError when libnd_amd.so is missing, like nd/change.py:106-108
+        self.ml = ml
+        self.n = n
+        self.alpha = alpha
+        self.device = kwargs.pop('device', None)
+        super().__init__(*args, **kwargs)
+
+    def apply(self, ds):
+        return _omnibus_change_detection(ds, alpha=self.alpha, ml=self.ml, n=self.n,
+                                         njobs=self.njobs, device=self.device)
+
+
+omnibus = wrap_algorithm(OmnibusTest, 'omnibus')
+
+
+def omnibus_statistics(ds, ml=None, n=1, alpha=0.01, device=None):
+    """change map plus the rasters the reference only computes per pixel: the test statistic
+    z = -2 rho ln Q and the probability P of the global test over the whole series
+    (nd/_change.pyx:46-77, 133-151).  Returns (change, z, P)."""
+    return _omnibus_change_detection(ds, alpha=alpha, ml=ml, n=n, device=device, stats=True)

@@ -49,3 +49,26 @@ def reference_test_dataset(dims, mean, sigma, seed=42,
     for v, m in zip(var, mean):
         out[v] = np.random.normal(m, sigma, tuple(dims.values()))
     return out
+
+
+def lite_test_dataset(dims=None, var=('C11', 'C12__im', 'C12__re', 'C22'), mean=0, sigma=1,
+                      seed=42):
+    """nd.testing.generate_test_dataset (nd/testing.py:34-70) as an nd_amd.xr_lite.Dataset:
+    same seed, same draw order, same values; coordinates reduced to plain index arrays."""
+    from collections import OrderedDict
+    from nd_amd import xr_lite
+    if dims is None:
+        dims = OrderedDict([('y', 20), ('x', 20), ('time', 10)])
+    data = reference_test_dataset(dims, mean, sigma, seed, var)
+    coords = OrderedDict()
+    for name, size in dims.items():
+        if name == 'y':
+            coords[name] = np.linspace(60.0, 50.0, size)
+        elif name == 'x':
+            coords[name] = np.linspace(-10.0, 0.0, size)
+        else:
+            coords[name] = np.arange(size)
+    ds = xr_lite.Dataset(coords=coords, attrs={'attr1': 1, 'attr2': 2, 'attr3': 3})
+    for v in var:
+        ds[v] = (tuple(dims.keys()), data[v])
+    return ds

@@ -1,0 +1,270 @@
+"""The reference's own hot-path tests, re-stated against nd_amd's Algorithm classes
+(nd/tests/test_change_omnibus.py, test_change_common.py, test_convolution_filter.py,
+test_nlmeans_filter.py, test_filters_common.py).  Datasets are nd_amd.xr_lite containers
+(xarray is not installed); the arithmetic runs on the GPU through the C ABI."""
+import inspect
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ds(**kw):
+    return synth.lite_test_dataset(**kw)
+
+
+def _allclose(a, b, rtol=1e-5, atol=1e-8):
+    assert list(a.data_vars) == list(b.data_vars)
+    for v in a.data_vars:
+        assert a[v].dims == b[v].dims
+        np.testing.assert_allclose(a[v].values, b[v].values, rtol=rtol, atol=atol)
+
+
+# ---------------------------------------------------------------- change detection
+def test_change(device):
+    """nd/tests/test_change_omnibus.py:6-19"""
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    dims = OrderedDict([('y', 5), ('x', 5), ('time', 10)])
+    ds1 = _ds(dims=dims, mean=[1, 0, 0, 1], sigma=0.1).isel(time=slice(None, 5))
+    ds2 = _ds(dims=dims, mean=[10, 0, 0, 10], sigma=0.1).isel(time=slice(5, None))
+    ds = xr_lite.concat([ds1, ds2], dim='time')
+    changes = OmnibusTest(n=9, alpha=0.9).apply(ds)
+    assert changes.dims == ('y', 'x', 'time')
+    assert changes.values.dtype == np.bool_
+    assert changes.isel(time=5).all()
+    assert (changes.sum(dim='time') == 1).all()
+
+
+def test_change_input_output(device):
+    """nd/tests/test_change_common.py:21-32"""
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    ds = _ds(dims=OrderedDict([('y', 20), ('x', 30), ('time', 10)]))
+    result = OmnibusTest().apply(ds)
+    assert isinstance(result, xr_lite.DataArray)
+    assert result.name == 'change'
+    assert result.shape == (20, 30, 10)
+    assert not result.values.any()              # N(0,1) data: negative determinants -> NaN -> no change
+
+
+def test_change_function_and_complex_input(oracle, device):
+    """omnibus() wrapper == class; a complex C12 variable is split like nd/change.py:59."""
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest, omnibus
+    planes = synth.omnibus_stack(seed=5, k=9, ny=12, nx=16, dtype=np.float32, change_frac=0.2)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    ds = xr_lite.Dataset()
+    ds['C11'] = (('y', 'x', 'time'), yxt[0])
+    ds['C12'] = (('y', 'x', 'time'), (yxt[1] + 1j * yxt[2]).astype(np.complex64))
+    ds['C22'] = (('y', 'x', 'time'), yxt[3])
+    a = OmnibusTest(n=9, alpha=0.95).apply(ds)
+    b = omnibus(ds, n=9, alpha=0.95)
+    assert a.equals(b)
+    want = oracle.change_detection_planes(yxt, 0.95, 9)
+    np.testing.assert_array_equal(a.values, want.astype(bool))
+    assert want.sum() > 0
+
+
+def test_change_multilook(oracle, device):
+    """ml=w: boxcar multilooking first, then n = w**2 looks (nd/change.py:62-64)."""
+    import scipy.ndimage as ndi
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    planes = synth.omnibus_stack(seed=6, k=8, ny=24, nx=20, looks=1, dtype=np.float32,
+                                 change_frac=0.3, factor=6.0)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    ds = xr_lite.Dataset()
+    for v, a in zip(('C11', 'C12__re', 'C12__im', 'C22'), yxt):
+        ds[v] = (('y', 'x', 'time'), a)
+    got = OmnibusTest(ml=3, alpha=0.9).apply(ds)
+    k = (np.ones((3, 3)) / 9).reshape(3, 3, 1)
+    ml = [ndi.convolve(a, k) for a in yxt]
+    want = oracle.change_detection_planes(ml, 0.9, 9)
+    np.testing.assert_array_equal(got.values, want.astype(bool))
+
+
+def test_statistics_rasters(oracle, device):
+    from nd_amd import xr_lite
+    from nd_amd.change import omnibus_statistics
+    planes = synth.omnibus_stack(seed=8, k=10, ny=9, nx=14, dtype=np.float64, change_frac=0.2)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    ds = xr_lite.Dataset()
+    for v, a in zip(('C11', 'C12__re', 'C12__im', 'C22'), yxt):
+        ds[v] = (('y', 'x', 'time'), a)
+    ch, z, P = omnibus_statistics(ds, n=9, alpha=0.9)
+    ch0, z0, P0 = oracle.change_detection_planes(yxt, 0.9, 9, stats=True)
+    np.testing.assert_array_equal(ch.values, ch0.astype(bool))
+    np.testing.assert_allclose(z.values, z0, rtol=1e-5)
+    np.testing.assert_allclose(P.values, P0, rtol=1e-5, atol=1e-300)
+
+
+# ---------------------------------------------------------------- filters, common
+def _filter_classes():
+    from nd_amd.filters import BoxcarFilter, ConvolutionFilter, NLMeansFilter
+    return [ConvolutionFilter, BoxcarFilter, NLMeansFilter]
+
+
+@pytest.mark.parametrize('i', range(3))
+def test_filter_input_output(device, i):
+    """nd/tests/test_filters_common.py:20-33"""
+    from nd_amd import xr_lite
+    f = _filter_classes()[i]
+    ds = _ds(dims=OrderedDict([('y', 20), ('x', 30), ('time', 10)]))
+    result = f(dims=('y', 'x')).apply(ds)
+    assert isinstance(result, xr_lite.Dataset)
+    for v in ds.data_vars:
+        assert ds[v].dims == result[v].dims
+        assert ds[v].shape == result[v].shape
+
+
+def test_filter_signature():
+    """nd/tests/test_filters_common.py:36-41"""
+    from nd_amd.filters import GaussianFilter
+    for f in _filter_classes() + [GaussianFilter]:
+        assert list(inspect.signature(f._filter).parameters) == ['self', 'arr', 'axes', 'output']
+
+
+@pytest.mark.parametrize('i', range(3))
+def test_filter_mutable_dimension(device, i):
+    """nd/tests/test_filters_common.py:44-51"""
+    f = _filter_classes()[i]
+    ds = _ds(dims=OrderedDict([('y', 20), ('x', 30), ('time', 10)]))
+    _allclose(f(dims=('y', 'x')).apply(ds), f(dims=('x', 'y')).apply(ds))
+
+
+@pytest.mark.parametrize('i', range(3))
+@pytest.mark.parametrize('dims', [('x', 'y'), ('x', 'y', 'time')])
+def test_parallelized_filter(device, i, dims):
+    """nd/tests/test_filters_common.py:54-60: njobs=2 (halo-buffered chunks) == serial"""
+    f = _filter_classes()[i]
+    ds = _ds(dims=OrderedDict([('y', 20), ('x', 30), ('time', 10)]))
+    _allclose(f(dims=dims).apply(ds), f(dims=dims).apply(ds, njobs=2))
+
+
+def test_inplace_not_implemented(device):
+    from nd_amd.filters import BoxcarFilter
+    with pytest.raises(NotImplementedError):
+        BoxcarFilter().apply(_ds(), inplace=True)
+
+
+# ---------------------------------------------------------------- convolution
+def test_convolve_dataset_identity(device):
+    from nd_amd.filters import ConvolutionFilter
+    ds = _ds()
+    ident = np.zeros((3, 3)); ident[1, 1] = 1
+    assert ConvolutionFilter(('y', 'x'), ident).apply(ds).equals(ds)
+
+
+def test_convolve_dataset(device):
+    """nd/tests/test_convolution_filter.py:39-47: bit-equal to scipy.ndimage.convolve"""
+    import scipy.ndimage as ndi
+    from nd_amd.filters import ConvolutionFilter, _expand_kernel
+    ds = _ds()
+    np.random.seed(42)
+    kernel = np.random.rand(5, 5)
+    dims = ('y', 'x')
+    nd_kernel = _expand_kernel(kernel, dims, ds.C11.dims)
+    np.testing.assert_array_equal(ConvolutionFilter(dims, kernel).apply(ds).C11.values,
+                                  ndi.convolve(ds.C11.values, nd_kernel))
+
+
+def test_convolve_complex(device):
+    """nd/tests/test_convolution_filter.py:50-57"""
+    from nd_amd.filters import ConvolutionFilter
+    from nd_amd.io import assemble_complex
+    ds_complex = assemble_complex(_ds())
+    assert 'C12' in ds_complex and np.iscomplexobj(ds_complex['C12'].values)
+    ident = np.zeros((3, 3)); ident[1, 1] = 1
+    out = ConvolutionFilter(('y', 'x'), ident).apply(ds_complex)
+    assert out.equals(ds_complex)
+
+
+def test_boxcar(device):
+    """nd/tests/test_convolution_filter.py:60-66"""
+    from nd_amd.filters import BoxcarFilter, ConvolutionFilter, boxcar
+    ds = _ds()
+    w = 5
+    kernel = np.ones((w, w)) / w**2
+    a = BoxcarFilter(('y', 'x'), w).apply(ds)
+    assert a.equals(ConvolutionFilter(('y', 'x'), kernel).apply(ds))
+    assert a.equals(boxcar(ds, dims=('y', 'x'), w=w))
+
+
+def test_expand_kernel():
+    from nd_amd.filters import _expand_kernel
+    k = _expand_kernel(np.ones((2, 3)), ('x', 'y'), ('x', 'a', 'y', 's'))
+    assert k.shape == (2, 1, 3, 1)
+
+
+# ---------------------------------------------------------------- nlmeans
+def test_nlmeans_mean_preserved(device):
+    """nd/tests/test_nlmeans_filter.py:9-14"""
+    from nd_amd.filters import NLMeansFilter
+    ds = _ds()
+    out = NLMeansFilter(dims=('y', 'x'), r=0, f=1, sigma=2, h=2).apply(ds)
+    for v in ds.data_vars:
+        assert abs(ds[v].values.mean() - out[v].values.mean()) < 1e-3
+
+
+def test_nlmeans_zero_radius_and_empty_dim(device):
+    """nd/tests/test_nlmeans_filter.py:17-25"""
+    from nd_amd.filters import NLMeansFilter
+    ds = _ds()
+    assert ds.equals(NLMeansFilter(dims=('y', 'x'), r=0, f=1, sigma=1, h=1).apply(ds))
+    assert ds.equals(NLMeansFilter(dims=(), r=1, f=1, sigma=1, h=1).apply(ds))
+
+
+def test_nlmeans_reduce_std_and_ignore_time(device):
+    """nd/tests/test_nlmeans_filter.py:28-43"""
+    from nd_amd.filters import NLMeansFilter
+    ds = _ds()
+    out = NLMeansFilter(dims=('y', 'x', 'time'), r=(1, 1, 0), sigma=2, h=2).apply(ds)
+    for v in ds.data_vars:
+        assert out[v].values.std() < ds[v].values.std()
+    t0 = ds.isel(time=0)
+    t0_nlm = NLMeansFilter(dims=('y', 'x'), r=1, sigma=2, h=2).apply(t0)
+    for v in ds.data_vars:
+        assert np.abs(out[v].isel(time=0).values - t0_nlm[v].values).max() < 1e-8
+
+
+def test_nlmeans_matches_reference_golden(device):
+    """Dataset path == the real reference kernel on the same stacked array."""
+    import os
+    from nd_amd import xr_lite
+    from nd_amd.filters import NLMeansFilter
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'nlmeans_ref.npz'))
+    a, want = g['ds_r110_f000__in'], g['ds_r110_f000__out']       # (y, x, time, var)
+    names = ['C11', 'C12__im', 'C12__re', 'C22']
+    ds = xr_lite.Dataset()
+    for i, n in enumerate(names):
+        ds[n] = (('y', 'x', 'time'), np.ascontiguousarray(a[..., i]))
+    out = NLMeansFilter(dims=('y', 'x', 'time'), r=(1, 1, 0), f=0, sigma=0.5, h=0.7).apply(ds)
+    for i, n in enumerate(names):
+        np.testing.assert_allclose(out[n].values, want[..., i], rtol=1e-5, atol=0)
+
+
+def test_device_resident_pipeline(oracle, device):
+    """torch tensors in -> torch tensors out, no host copies: boxcar -> omnibus."""
+    import torch
+    import scipy.ndimage as ndi
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    from nd_amd.filters import BoxcarFilter
+    planes = synth.omnibus_stack(seed=9, k=6, ny=16, nx=16, looks=1, dtype=np.float32,
+                                 change_frac=0.3, factor=8.0)
+    ds = xr_lite.Dataset()
+    for v, p in zip(('C11', 'C12__re', 'C12__im', 'C22'), planes):
+        ds[v] = (('time', 'y', 'x'), torch.from_numpy(p).to(device))
+    sm = BoxcarFilter(dims=('y', 'x'), w=3).apply(ds)
+    assert sm['C11'].values.is_cuda
+    ch = OmnibusTest(n=9, alpha=0.9).apply(sm)
+    assert ch.values.is_cuda and ch.dims == ('y', 'x', 'time')
+    k = (np.ones((3, 3)) / 9).reshape(1, 3, 3)
+    ml = [np.ascontiguousarray(np.moveaxis(ndi.convolve(p, k), 0, -1)) for p in planes]
+    want = oracle.change_detection_planes(ml, 0.9, 9)
+    np.testing.assert_array_equal(ch.values.cpu().numpy(), want.astype(bool))
