@@ -128,7 +128,7 @@ int SFX(oracle_omnibus_c2)(const REAL *c11, const REAL *c12r, const REAL *c12i,
     memset(change, 0, (size_t)ny * (size_t)nx * (size_t)k);
     if (nthreads < 1) nthreads = 1;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+#pragma omp parallel for schedule(dynamic, 2) num_threads(nthreads)
 #endif
     for (iy = 0; iy < ny; iy++) {
         int64_t ix;
