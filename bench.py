@@ -51,6 +51,24 @@ def parse():
     return ap.parse_args()
 
 
+def _usable_cores():
+    """Host cores this process may actually use: CPU affinity, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = max(1, min(n, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(stack, args, npix_rows):
     """Time the CPU oracle (oracle/, a port of the reference's Cython path) on
     the first `npix_rows` rows of the same stack, all host cores."""
@@ -60,7 +78,7 @@ def cpu_baseline(stack, args, npix_rows):
     rows = min(npix_rows, stack.shape[2])
     host = stack[:, :, :rows, :].cpu().numpy()            # (4, k, rows, nx)
     planes = [np.moveaxis(host[v], 0, -1) for v in range(4)]   # (rows, nx, k) strided views
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    cores = _usable_cores()
     # warm (page-in + thread pool) on a sliver, then time
     O.change_detection_planes([p[:8] for p in planes], args.alpha, args.looks, njobs=cores)
     t0 = time.perf_counter()
