@@ -15,9 +15,9 @@
 //
 //   omnibus_c2_search_kernel   ("pass B", FP64-bound)  one lane per listed pixel, series staged
 //       in LDS ([time*4+var][lane], conflict free), runs the sequential change-point search of
-//       nd/_change.pyx:224-257.  A test whose z is below the fast-reject bound is decided at
-//       once; any other test parks the lane, and when every lane of the wave is parked or done
-//       the parked lanes evaluate their chi-square pairs together (converged FP64 loop).
+//       nd/_change.pyx:224-257 as one sweep per segment (one date and at most one test per lane
+//       and iteration, so the wave stays converged); tests are decided by host-computed bounds
+//       and only the rare in-band ones evaluate the chi-square pair.
 //
 // Numerics follow the C that Cython generates for the reference (nd/_change.c:3501-3590,
 // 6063-6091): `floating` (T) sums and determinants without FMA contraction (this TU is built
@@ -654,82 +654,73 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
             }
         };
 
-        // State machine of nd/_change.pyx:235-257.  Each lane walks through its omnibus tests;
-        // a test whose z is below the fast-reject bound is decided on the spot, any other test
-        // parks the lane until every lane of the wave is parked or finished, then all parked
-        // lanes evaluate their chi-square pair together.
+        // nd/_change.pyx:235-257 as ONE sweep per segment.  The reference first tests the global
+        // hypothesis over ts[l:], then the marginal ones over ts[l:l+j], j = 2, 3, ...; both are
+        // functions of the same running accumulation started at l (the global test is the state
+        // after the last date), so each lane sweeps t = l .. k-1 once, remembers the first date at
+        // which a marginal test fires, and commits it only if the global test -- known at the end
+        // of the sweep -- passes.  Every iteration of the wave is then the same small body (one
+        // date + at most one test per lane), whatever segment each lane is in.
         Accum<T> A;
         A.reset();
-        int l = 0;
-        int j = 0;             // marginal state: A holds ts[l : l+j-1]
-        bool marginal = false;
+        int l = 0;                 // segment start
+        int t = 0;                 // next date to fold
+        int fire_at = -1;          // first date of this segment whose marginal test fired
         bool done = !active;
-        bool parked = false;
-        int jj = 0;
-        T zp = 0;
         uint8_t *res = s.change + pix * (int64_t)k;
 
-        auto decide = [&](bool change) {
-            if (!marginal) {
-                if (!change) {
-                    done = true;                       // :241-242
-                } else {
-                    marginal = true;
-                    A.reset();
-                    load_step(A, l);                   // j = 1 carries no test
-                    j = 2;
+        while (__any(!done)) {
+            if (!done) {
+                load_step(A, t);
+                const int jj = t - l + 1;
+                const bool last = (t == k - 1);
+                // a marginal test while none has fired yet (j >= 2); at the last date the same
+                // evaluation is the global test, needed even if a marginal fired earlier
+                const bool need = (jj >= 2) && (fire_at < 0 || last);
+                bool fires = false;
+                if (need) {
+                    const OmniTabEntry e = tabp[jj];
+                    const double za = z_approx<T>(A, jj, s.nlooks, e);
+                    // 0 = cannot fire (z < zlo, or NaN), 1 = fires for certain (zhi < z < inf),
+                    // 2 = inside the band: needs the chi-square pair
+                    int verdict = 0;
+                    T zp = 0;
+                    if (za >= e.zlo_a) {
+                        verdict = 1;
+                        if (!(za > e.zhi_a && za < INFINITY)) {
+                            zp = z_stat<T>(A, jj, s.nlooks, e);
+                            const double zd = (double)zp;
+                            verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                        }
+                    }
+                    if (verdict == 2) {
+                        double zd[1] = {(double)zp}, P1[1], P2[1];
+                        chisq_pair_int<1>(zd, 2 * (jj - 1), e.lgam, P1, P2);
+                        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                        verdict = ((double)P > s.alpha) ? 1 : 0;
+                    }
+                    fires = (verdict == 1);
                 }
-            } else {
-                const int r = j - 1;                   // :250
-                if (change || j >= k - l) {
-                    if (change) res[l + r] = 1;        // :252
-                    l = l + r;                         // :255
-                    marginal = false;
-                    if (l >= k - 1) done = true;       // :256
+                if (!last) {
+                    if (fires && fire_at < 0) fire_at = t;
+                    t = t + 1;
                 } else {
-                    j = j + 1;
-                }
-            }
-        };
-
-        for (;;) {
-            while (!done && !parked) {
-                if (!marginal) {
-                    // global hypothesis H0_l over ts[l:]  (:238-240)
-                    A.reset();
-                    for (int t = l; t < k; ++t) load_step(A, t);
-                    jj = k - l;
-                } else {
-                    // next marginal hypothesis over ts[l : l+j]  (:246-248)
-                    load_step(A, l + j - 1);
-                    jj = j;
-                }
-                const OmniTabEntry e = tabp[jj];
-                const double za = z_approx<T>(A, jj, s.nlooks, e);
-                // 0 = cannot fire (z < zlo, or NaN: P <= alpha / P is NaN), 1 = fires for certain
-                // (zhi < z < inf), 2 = inside the band: needs the chi-square pair
-                int verdict = 0;
-                if (za >= e.zlo_a) {
-                    verdict = 1;
-                    if (!(za > e.zhi_a && za < INFINITY)) {
-                        zp = z_stat<T>(A, jj, s.nlooks, e);
-                        const double zd = (double)zp;
-                        verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                    // `fires` is the global test of ts[l:] (for jj == 1 there is nothing to test)
+                    if (fires && fire_at < 0) fire_at = t;
+                    if (fires && jj >= 2) {
+                        res[fire_at] = 1;                  // :252, l + r with r = j - 1
+                        l = fire_at;                       // :255
+                        if (l >= k - 1) {
+                            done = true;                   // :256
+                        } else {
+                            A.reset();
+                            t = l;
+                            fire_at = -1;
+                        }
+                    } else {
+                        done = true;                       // :241-242
                     }
                 }
-                if (verdict == 2)
-                    parked = true;
-                else
-                    decide(verdict == 1);
-            }
-            if (!__any(parked)) break;
-            if (parked) {
-                const OmniTabEntry e = tabp[jj];
-                double zd[1] = {(double)zp}, P1[1], P2[1];
-                chisq_pair_int<1>(zd, 2 * (jj - 1), e.lgam, P1, P2);
-                const T P = combine_P<T>(P1[0], P2[0], e.omega2);
-                parked = false;
-                decide((double)P > s.alpha);
             }
         }
     }
