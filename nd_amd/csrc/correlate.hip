@@ -122,6 +122,247 @@ __global__ void __launch_bounds__(256) correlate_kernel(const CorrArgs<T> a, con
     a.out[i0 * a.so[0] + i1 * a.so[1] + i2 * a.so[2] + i3 * a.so[3]] = (T)tmp;
 }
 
+// -----------------------------------------------------------------------------------------
+// LDS-tiled form for a dense KH x KW window over the last two axes (y, x) of x-contiguous planes
+// [batch][y][x] -- the layout of the device stacks, and the shape of BoxcarFilter / ConvolutionFilter
+// with dims ('y', 'x').
+//
+// A 256-thread block computes a 128 x 32 tile of outputs.  The (32+KH-1) x (128+KW-1) input window
+// is staged once into LDS as doubles with the border rule already applied (reflect / nearest /
+// mirror / wrap are separable per axis), so halo re-reads never leave the CU.  Each thread owns a
+// 4 x 4 patch of outputs and walks the input rows of its patch once: a row's 4+KW-1 values are read
+// from LDS into registers and feed every (output row, kernel row) pair they belong to.  For one
+// output the contributions still arrive kernel-row by kernel-row, left to right -- scipy's footprint
+// order -- and each is `tmp = tmp + w * v` with separate rounding of product and sum.
+// BOX: all weights equal (boxcar): the product w * v is formed once per input element at staging
+// time and the inner loop is additions only (same values, same order, half the FP64 work).
+// -----------------------------------------------------------------------------------------
+constexpr int kTileX = 128, kTileY = 32, kOX = 4, kOY = 4;
+constexpr int kMaxKH = 15;
+
+template <typename T>
+struct TiledArgs {
+    const T *in;
+    T *out;
+    int64_t ny, nx;             // plane size
+    int64_t sin_b, sin_y;       // element strides of batch and y (x stride is 1)
+    int64_t sout_b, sout_y;
+    int kh, oy0, ox0;           // window: input row = y + oy0 + i, input col = x + ox0 + j
+    int mode;
+    int tiles_x, tiles_y;
+    double w[kMaxKH * kMaxKH];  // dense KH x KW weights, row-major (0 = tap absent)
+};
+
+template <typename T, int KW, bool BOX>
+__global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T> a)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_c[];
+    double *tile = reinterpret_cast<double *>(nd_smem_c);
+    const int tid = threadIdx.x;
+    const int kh = a.kh;
+    const int tw = kTileX + KW - 1;              // staged columns
+    const int th = kTileY + kh - 1;              // staged rows
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int ty = (int)(b % a.tiles_y);
+    const int64_t batch = b / a.tiles_y;
+    const int64_t x_base = (int64_t)tx * kTileX, y_base = (int64_t)ty * kTileY;
+    const T *plane = a.in + batch * a.sin_b;
+
+    // ---- stage the window.  The border rule is separable: one source row per staged row and one
+    // source column per staged column, computed once into small LDS tables; then every thread
+    // issues all of its loads before consuming the first one (coalesced along x). ----
+    const double wbox = a.w[0];
+    constexpr int TW = kTileX + KW - 1;
+    constexpr int kMaxLoads = ((kTileY + kMaxKH - 1) * TW + 255) / 256;
+    const int n_el = th * TW;
+    int *ymap = reinterpret_cast<int *>(tile + n_el);
+    int *xmap = ymap + th;
+    for (int i = tid; i < th + TW; i += 256) {
+        if (i < th)
+            ymap[i] = (int)extend_index(y_base + a.oy0 + i, a.ny, a.mode);
+        else
+            xmap[i - th] = (int)extend_index(x_base + a.ox0 + (i - th), a.nx, a.mode);
+    }
+    __syncthreads();
+    {
+        T buf[kMaxLoads];
+#pragma unroll
+        for (int i = 0; i < kMaxLoads; ++i) {
+            const int e = tid + 256 * i;
+            if (e < n_el) {
+                const int r = e / TW, c = e - r * TW;
+                buf[i] = plane[(int64_t)ymap[r] * a.sin_y + xmap[c]];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxLoads; ++i) {
+            const int e = tid + 256 * i;
+            if (e < n_el) {
+                const double v = (double)buf[i];
+                tile[e] = BOX ? wbox * v : v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4 x 4 outputs per thread ----
+    const int lx = (tid % 32) * kOX, ly = (tid / 32) * kOY;
+    double acc[kOY][kOX];
+#pragma unroll
+    for (int oy = 0; oy < kOY; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < kOX; ++ox) acc[oy][ox] = 0.0;
+
+    for (int r = 0; r < kOY + kh - 1; ++r) {
+        double v[kOX + KW - 1];
+        const double *src = tile + (ly + r) * tw + lx;
+#pragma unroll
+        for (int c = 0; c < kOX + KW - 1; ++c) v[c] = src[c];
+#pragma unroll
+        for (int oy = 0; oy < kOY; ++oy) {
+            const int i = r - oy;                       // kernel row feeding output row oy
+            if (i >= 0 && i < kh) {
+#pragma unroll
+                for (int j = 0; j < KW; ++j) {
+                    const double w = a.w[i * KW + j];
+                    if (BOX || w != 0.0) {
+#pragma unroll
+                        for (int ox = 0; ox < kOX; ++ox) {
+                            if (BOX)
+                                acc[oy][ox] = acc[oy][ox] + v[ox + j];
+                            else
+                                acc[oy][ox] = acc[oy][ox] + w * v[ox + j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    T *oplane = a.out + batch * a.sout_b;
+#pragma unroll
+    for (int oy = 0; oy < kOY; ++oy) {
+        const int64_t y = y_base + ly + oy;
+        if (y < a.ny) {
+            T *orow = oplane + y * a.sout_y;
+            const int64_t x = x_base + lx;
+            if (x + kOX <= a.nx && ((uintptr_t)(orow + x) % (sizeof(T) * kOX)) == 0) {
+                struct alignas(sizeof(T) * kOX) Out4 {
+                    T v[kOX];
+                } o;
+#pragma unroll
+                for (int ox = 0; ox < kOX; ++ox) o.v[ox] = (T)acc[oy][ox];
+                *reinterpret_cast<Out4 *>(orow + x) = o;
+            } else {
+#pragma unroll
+                for (int ox = 0; ox < kOX; ++ox)
+                    if (x + ox < a.nx) orow[x + ox] = (T)acc[oy][ox];
+            }
+        }
+    }
+}
+
+template <typename T, int KW>
+static void launch_tiled(const TiledArgs<T> &a, bool box, int64_t nblocks, size_t lds,
+                         hipStream_t stream)
+{
+    if (box)
+        hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, true>), dim3((unsigned)nblocks), dim3(256),
+                           lds, stream, a);
+    else
+        hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false>), dim3((unsigned)nblocks),
+                           dim3(256), lds, stream, a);
+}
+
+// Try the tiled form; returns 1 if it was launched, 0 if the request does not fit it.
+template <typename T>
+static int try_tiled(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
+                     const int64_t so[4], int64_t ntaps, const int64_t *offsets,
+                     const double *weights, int mode, hipStream_t stream)
+{
+    static const bool disabled = getenv("ND_AMD_NO_TILED") != nullptr;
+    if (disabled || ntaps < 1 || mode == ND_AMD_MODE_CONSTANT) return 0;
+    if (si[3] != 1 || so[3] != 1) return 0;
+    int64_t ymin = 0, ymax = 0, xmin = 0, xmax = 0;
+    for (int64_t t = 0; t < ntaps; ++t) {
+        if (offsets[4 * t + 0] != 0 || offsets[4 * t + 1] != 0) return 0;
+        const int64_t oy = offsets[4 * t + 2], ox = offsets[4 * t + 3];
+        if (t == 0) {
+            ymin = ymax = oy;
+            xmin = xmax = ox;
+        }
+        ymin = oy < ymin ? oy : ymin;
+        ymax = oy > ymax ? oy : ymax;
+        xmin = ox < xmin ? ox : xmin;
+        xmax = ox > xmax ? ox : xmax;
+        // scipy's order is row-major over the window: the dense walk below must visit the taps
+        // in the order they were given
+        if (t > 0) {
+            const int64_t py = offsets[4 * (t - 1) + 2], px = offsets[4 * (t - 1) + 3];
+            if (oy < py || (oy == py && ox <= px)) return 0;
+        }
+    }
+    const int64_t kh = ymax - ymin + 1, kw = xmax - xmin + 1;
+    if (kh > kMaxKH || kw > kMaxKH || (kw != 1 && kw != 3 && kw != 5 && kw != 7 && kw != 9 &&
+                                        kw != 11))
+        return 0;
+    if (dims[2] < 1 || dims[3] < 1 || dims[2] > 0x7fffffffLL || dims[3] > 0x7fffffffLL) return 0;
+    // batch = dims[0] x dims[1] must be addressable with one stride
+    int64_t nb = dims[0] * dims[1], sbi, sbo;
+    if (dims[0] == 1) {
+        sbi = si[1];
+        sbo = so[1];
+    } else if (dims[1] == 1) {
+        sbi = si[0];
+        sbo = so[0];
+    } else if (si[0] == si[1] * dims[1] && so[0] == so[1] * dims[1]) {
+        sbi = si[1];
+        sbo = so[1];
+    } else {
+        return 0;
+    }
+    TiledArgs<T> a;
+    a.in = static_cast<const T *>(in);
+    a.out = static_cast<T *>(out);
+    a.ny = dims[2];
+    a.nx = dims[3];
+    a.sin_b = sbi;
+    a.sin_y = si[2];
+    a.sout_b = sbo;
+    a.sout_y = so[2];
+    a.kh = (int)kh;
+    a.oy0 = (int)ymin;
+    a.ox0 = (int)xmin;
+    a.mode = mode;
+    a.tiles_x = (int)ceil_div(dims[3], kTileX);
+    a.tiles_y = (int)ceil_div(dims[2], kTileY);
+    for (int i = 0; i < kMaxKH * kMaxKH; ++i) a.w[i] = 0.0;
+    bool box = (ntaps == kh * kw);
+    for (int64_t t = 0; t < ntaps; ++t) {
+        a.w[(offsets[4 * t + 2] - ymin) * kw + (offsets[4 * t + 3] - xmin)] = weights[t];
+        if (weights[t] != weights[0]) box = false;
+    }
+    const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * nb;
+    if (nblocks > 0x7fffffffLL || nblocks < 1) return 0;
+    const size_t lds = (size_t)(kTileY + kh - 1) * (size_t)(kTileX + kw - 1) * sizeof(double) +
+                       (size_t)((kTileY + kh - 1) + (kTileX + kw - 1)) * sizeof(int);
+    if (lds > 64 * 1024) return 0;
+    {
+        KernelTimer timer(ND_AMD_KERNEL_BOXCAR_TILED, stream);
+        switch (kw) {
+        case 1: launch_tiled<T, 1>(a, box, nblocks, lds, stream); break;
+        case 3: launch_tiled<T, 3>(a, box, nblocks, lds, stream); break;
+        case 5: launch_tiled<T, 5>(a, box, nblocks, lds, stream); break;
+        case 7: launch_tiled<T, 7>(a, box, nblocks, lds, stream); break;
+        case 9: launch_tiled<T, 9>(a, box, nblocks, lds, stream); break;
+        default: launch_tiled<T, 11>(a, box, nblocks, lds, stream); break;
+        }
+    }
+    return 1;
+}
+
 template <typename T>
 static int correlate_impl(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
                           const int64_t so[4], int64_t ntaps, const int64_t *offsets,
@@ -155,6 +396,10 @@ static int correlate_impl(const void *in, void *out, const int64_t dims[4], cons
     a.cval = cval;
     a.taps_dev = nullptr;
     if (a.total == 0) return ND_AMD_OK;
+    if (try_tiled<T>(in, out, dims, si, so, ntaps, offsets, weights, mode, stream)) {
+        ND_HIP_CHECK(hipGetLastError());
+        return ND_AMD_OK;
+    }
 
     TapsByValue tv;
     memset(&tv, 0, sizeof(tv));

@@ -151,12 +151,34 @@ def correlate_footprint(inp, out, offsets, weights, mode='reflect', cval=0.0):
 
 def convolve(inp, kernel, out=None, mode='reflect', cval=0.0, origin=0):
     """scipy.ndimage.convolve(inp, kernel, output=out, mode, cval, origin) on a
-    real CUDA tensor; kernel.ndim must equal inp.dim()."""
+    real CUDA tensor; kernel.ndim must equal inp.dim().
+
+    A window over (at most) two axes runs in the LDS-tiled kernel, which wants those axes last
+    and the last one contiguous.  When the array is laid out differently -- the reference's
+    datasets are (y, x, time) with time fastest -- it is transposed on the device first and the
+    result transposed back; the tap order over the window axes, hence the result, is unchanged.
+    """
     kernel = np.asarray(kernel, np.float64)
     if kernel.ndim != inp.dim():
         raise RuntimeError('filter weights array has incorrect shape.')
     if out is None:
         out = torch.empty_like(inp)
+    nd = inp.dim()
+    span = [d for d in range(nd) if kernel.shape[d] > 1]
+    tail = list(range(nd - len(span), nd))
+    if (0 < len(span) <= 2 and nd <= 4 and mode != 'constant'
+            and (span != tail or inp.stride(-1) != 1 or out.stride(-1) != 1)
+            and inp.numel() >= (1 << 16)):
+        perm = [d for d in range(nd) if d not in span] + span
+        origins = [int(origin)] * nd if np.isscalar(origin) else [int(o) for o in origin]
+        t = inp.permute(*perm).contiguous()
+        k = np.transpose(kernel, perm)
+        o = torch.empty_like(t)
+        offs, w = footprint(k, [origins[d] for d in perm], convolution=True)
+        correlate_footprint(t, o, offs, w, mode, cval)
+        inv = [perm.index(d) for d in range(nd)]
+        out.copy_(o.permute(*inv))
+        return out
     offs, w = footprint(kernel, origin, convolution=True)
     return correlate_footprint(inp, out, offs, w, mode, cval)
 

@@ -107,3 +107,31 @@ def test_full_size_properties(device):
     a = kernels.convolve(x, k3)
     b = kernels.convolve(x * 2, k3)
     assert float((b - 2 * a).abs().max()) == 0.0      # exact: scaling by 2 commutes with rounding
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_reference_layout_goes_through_transpose_path(device, dtype):
+    """(y, x, time) arrays with a (w, w, 1) kernel -- the reference's own layout -- are transposed
+    on the device for the tiled kernel; the result must still be bit-equal to scipy."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(21)
+    a = rng.normal(size=(300, 260, 3)).astype(dtype)           # > 2^16 elements
+    for k in (np.ones((5, 5, 1)) / 25.0, rng.normal(size=(3, 7, 1)), rng.normal(size=(4, 3, 1))):
+        np.testing.assert_array_equal(_gpu_convolve(a, k, device), ndi.convolve(a, k))
+    b = rng.normal(size=(260, 2, 300)).astype(dtype)           # window over axes 0 and 2
+    k = rng.normal(size=(5, 1, 3))
+    np.testing.assert_array_equal(_gpu_convolve(b, k, device, mode='mirror'),
+                                  ndi.convolve(b, k, mode='mirror'))
+
+
+def test_tiled_edges_and_tiny_planes(device):
+    """Tile borders (128 x 32 tiles), planes smaller than the window, all separable modes."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(22)
+    for shape in [(2, 33, 129), (1, 65, 257), (3, 2, 3), (1, 1, 300), (2, 31, 127)]:
+        a = rng.normal(size=shape).astype(np.float32)
+        for kshape in [(1, 5, 5), (1, 11, 3), (1, 1, 7), (1, 9, 1)]:
+            k = rng.normal(size=kshape)
+            for mode in ('reflect', 'nearest', 'mirror', 'wrap'):
+                np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode),
+                                              ndi.convolve(a, k, mode=mode))
