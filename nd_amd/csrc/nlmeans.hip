@@ -19,6 +19,7 @@
 // (Py_ssize_t)(unsigned)(-f[i]) = 2^32 - f[i] and therefore do not execute when f[i] > 0
 // (nd/_filters.c:3539-3553); patch_mode 1 starts them at -f[i].
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -151,6 +152,404 @@ __global__ void __launch_bounds__(256) nlmeans_generic_kernel(const NlmArgs<T> a
     }
 }
 
+// =========================================================================================
+// LDS-tiled forms for the common 2-D case: search and patch windows over axes 0 and 1 only
+// (r[2] = f[2] = 0, every index of axis 2 filtered on its own), axis 1 contiguous in memory
+// (planar [var][time][y][x] stacks viewed as (y, x, time, var)), float32.
+//
+// A block of 256 threads owns a 64 x TY tile of one axis-2 slice.  The tile plus its (r+f) halo is
+// staged once per variable into LDS with the reference's whole-sample reflection (`_idx`) already
+// applied in GLOBAL coordinates, so every later access is a plain LDS read at
+// (row + dy, col + dx).
+//
+// patch_mode 0 with f > 0 (what the compiled reference computes): every neighbour weight is
+//   exactly exp(-0) = 1, so the output is the running float32 sum of the window in the
+//   reference's visiting order (rows outer, columns inner, centre last) divided by the count.
+//   nlmeans_window_kernel: each thread owns 4 adjacent pixels of a row and reads each window row
+//   once into registers.
+// patch_mode 1 (true patch distances): nlmeans_patch_kernel.  Each thread owns one column of
+//   TYW rows.  For a search offset (dy, dx) the squared difference summed over one patch ROW
+//   (2F+1 columns, float32) is computed once per image row, and the patch sum is a sliding sum
+//   of 2F+1 such rows down the column (double): O(2F+1) work per (pixel, offset) instead of
+//   (2F+1)^2, no barrier inside the offset loop.  The neighbour weight is
+//   exp(-max(d2/norm - 2 sigma^2, 0)/h^2) with d2 differing from the reference's double sum by
+//   <= ~1e-6 relative (float32 row sums) -- inside the 1e-5 budget; weighted sums keep the
+//   reference's order and per-step rounding to float32.
+// =========================================================================================
+struct NlmTiledArgs {
+    const float *arr;
+    float *out;
+    int64_t N0, N1, N2;        // tile shape (axis 0 = rows, axis 1 = contiguous columns, axis 2 = slices)
+    int64_t G0, G1;            // global extents of axes 0, 1
+    int64_t off0, off1;        // tile offset in global coordinates
+    int64_t clo0, chi0, clo1, chi1, clo2, chi2;   // written range
+    int64_t si0, si2, si3;     // input strides (axis 1 stride is 1)
+    int64_t so0, so2, so3;
+    int r0, r1, f0, f1;
+    int nvars;
+    int tiles_x, tiles_y;
+    float dsq_norm;
+    double two_sigma2, h2, n_eff;
+    int neff_policy;
+    int32_t *status;
+};
+
+__device__ __forceinline__ int nlm_reflect_i(int64_t i, int64_t shape)
+{
+    if (i < 0) return (int)(-i);
+    if (i >= shape) return (int)(2 * shape - 2 - i);
+    return (int)i;
+}
+
+// stage (rows x cols) of variable v, slice i2, top-left global coordinate (gy0, gx0), into lds
+__device__ __forceinline__ void nlm_stage(const NlmTiledArgs &a, float *lds, int *ymap, int *xmap,
+                                          int rows, int cols, int64_t gy0, int64_t gx0, int64_t i2,
+                                          int v, int tid)
+{
+    for (int i = tid; i < rows + cols; i += 256) {
+        // Positions that feed a written pixel reflect into the tile (checked on the host); the
+        // clamps only keep the staging of never-used corner positions inside the allocation.
+        if (i < rows) {
+            int m = nlm_reflect_i(gy0 + i, a.G0) - (int)a.off0;
+            m = m < 0 ? 0 : (m >= (int)a.N0 ? (int)a.N0 - 1 : m);
+            ymap[i] = m;
+        } else {
+            int m = nlm_reflect_i(gx0 + (i - rows), a.G1) - (int)a.off1;
+            m = m < 0 ? 0 : (m >= (int)a.N1 ? (int)a.N1 - 1 : m);
+            xmap[i - rows] = m;
+        }
+    }
+    __syncthreads();
+    const float *base = a.arr + i2 * a.si2 + (int64_t)v * a.si3;
+    const int n = rows * cols;
+    for (int e0 = 0; e0 < n; e0 += 256 * 8) {
+        float buf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256 + tid;
+            if (e < n) {
+                const int rr = e / cols, cc = e - rr * cols;
+                buf[u] = base[(int64_t)ymap[rr] * a.si0 + xmap[cc]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256 + tid;
+            if (e < n) lds[e] = buf[u];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double nlm_self_weight(double total_weight, double total_sq_weight,
+                                                  double max_weight, double n_eff, int policy,
+                                                  int32_t *status, bool *fail)
+{
+    *fail = false;
+    if (n_eff < 0) {
+        if (max_weight == 0) max_weight = 1;
+        return max_weight;
+    }
+    const double n = n_eff;
+    bool err = (total_sq_weight == 0);
+    if (!err) err = (n - 1.0) > ((total_weight * total_weight) / total_sq_weight);
+    if (!err) err = ((n - 1.0) == 0);
+    if (err) {
+        if (policy == 1) {
+            if (status) atomicExch(status, 1);
+            *fail = true;
+        }
+        return 0.0;
+    }
+    const double rt = sqrt(((((n * total_weight) * total_weight) - ((n * n) * total_sq_weight)) +
+                            (n * total_sq_weight)));
+    return (total_weight + rt) / (n - 1.0);
+}
+
+// ---- patch_mode 0, f > 0: uniform weights ------------------------------------------------
+constexpr int kWinTX = 128, kWinTY = 32;     // 4 px per thread along x, 32 x 8 threads -> 128 x 8 ... x4 rows
+
+template <int R1MAX>
+__global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs a)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_n[];
+    const int tid = threadIdx.x;
+    const int r0 = a.r0, r1 = a.r1;
+    const int cols = kWinTX + 2 * r1, rows = kWinTY + 2 * r0;
+    float *lds = reinterpret_cast<float *>(nd_smem_n);
+    int *ymap = reinterpret_cast<int *>(lds + rows * cols);
+    int *xmap = ymap + rows;
+
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int ty = (int)(b % a.tiles_y);
+    const int64_t i2 = a.clo2 + b / a.tiles_y;
+    const int64_t y0 = a.clo0 + (int64_t)ty * kWinTY, x0 = a.clo1 + (int64_t)tx * kWinTX;
+
+    const int lx = (tid % 32) * 4, ly = (tid / 32) * 4;          // 4 x 4 pixels per thread
+    const double nq = (double)((2 * r0 + 1) * (2 * r1 + 1) - 1);
+    bool fail;
+    const double wself = nlm_self_weight(nq, nq, nq > 0 ? 1.0 : 0.0, a.n_eff, a.neff_policy,
+                                         a.status, &fail);
+    const double total = nq + wself;
+
+    for (int v = 0; v < a.nvars; ++v) {
+        __syncthreads();
+        nlm_stage(a, lds, ymap, xmap, rows, cols, a.off0 + y0 - r0, a.off1 + x0 - r1, i2, v, tid);
+#pragma unroll
+        for (int py = 0; py < 4; ++py) {
+            const int yy = ly + py;
+            float ws[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int dy = 0; dy < 2 * r0 + 1; ++dy) {
+                const float *row = lds + (yy + dy) * cols + lx;
+                // window columns 0 .. 2 r1 for pixel 0, shifted by i for pixel i
+                float w[2 * R1MAX + 4];
+#pragma unroll
+                for (int c = 0; c < 2 * R1MAX + 4; ++c)
+                    if (c < 2 * r1 + 4) w[c] = row[c];
+                const bool centre_row = (dy == r0);
+#pragma unroll
+                for (int dx = 0; dx < 2 * R1MAX + 1; ++dx) {
+                    if (dx < 2 * r1 + 1 && !(centre_row && dx == r1)) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ws[i] = ws[i] + w[dx + i];
+                    }
+                }
+            }
+            const int64_t y = y0 + yy;
+            if (y < a.chi0 && !fail) {
+                const float *crow = lds + (yy + r0) * cols + lx + r1;
+                float *o = a.out + i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t x = x0 + lx + i;
+                    if (x < a.chi1) {
+                        // self term last (nd/_filters.pyx:417-420), weights are exactly 1 / wself
+                        const float s = (float)((double)ws[i] + (wself * (double)crow[i]));
+                        o[x] = (float)((double)s / total);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- patch_mode 1: sliding patch-row sums ---------------------------------------------------
+template <int F, int V, int TYW, bool NEFF>
+__global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_n[];
+    constexpr int TX = 64, TY = 4 * TYW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r0 = a.r0, r1 = a.r1;
+    const int halo0 = r0 + F, halo1 = r1 + F;
+    const int cols = TX + 2 * halo1, rows = TY + 2 * halo0;
+    float *lds = reinterpret_cast<float *>(nd_smem_n);               // [V][rows][cols]
+    int *ymap = reinterpret_cast<int *>(lds + V * rows * cols);
+    int *xmap = ymap + rows;
+
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int ty = (int)(b % a.tiles_y);
+    const int64_t i2 = a.clo2 + b / a.tiles_y;
+    const int64_t y0 = a.clo0 + (int64_t)ty * TY, x0 = a.clo1 + (int64_t)tx * TX;
+
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        __syncthreads();
+        nlm_stage(a, lds + v * rows * cols, ymap, xmap, rows, cols, a.off0 + y0 - halo0,
+                  a.off1 + x0 - halo1, i2, v, tid);
+    }
+
+    // this thread: column `lane`, rows wave*TYW .. wave*TYW + TYW - 1 of the tile
+    const int cx = halo1 + lane;                 // LDS column of the pixel
+    const int cy0 = halo0 + wave * TYW;          // LDS row of the first pixel
+    double tw[TYW], tsq[NEFF ? TYW : 1];
+    float wmax[TYW];
+    float ws[TYW][V];
+#pragma unroll
+    for (int p = 0; p < TYW; ++p) {
+        tw[p] = 0.0;
+        if (NEFF) tsq[p] = 0.0;
+        wmax[p] = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) ws[p][v] = 0.f;
+    }
+    // the reference divides; multiplying by the reciprocals differs by <= 1 ulp of a double
+    const double inv_norm = 1.0 / (double)a.dsq_norm;
+    const double neg_inv_h2 = -1.0 / a.h2;
+
+    for (int dy = -r0; dy <= r0; ++dy) {
+        for (int dx = -r1; dx <= r1; ++dx) {
+            if (dy == 0 && dx == 0) continue;
+            double S = 0.0;
+            double H[TYW + 2 * F];
+#pragma unroll
+            for (int s = 0; s < TYW + 2 * F; ++s) {
+                // patch-row sum of squared differences at image row (cy0 - F + s)
+                const int rr = cy0 - F + s;
+                float hs = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float *pa = lds + v * rows * cols + rr * cols + cx - F;
+                    const float *qa = pa + dy * cols + dx;
+#pragma unroll
+                    for (int j = 0; j < 2 * F + 1; ++j) {
+                        const float df = pa[j] - qa[j];
+                        hs = hs + df * df;
+                    }
+                }
+                H[s] = (double)hs;
+                S = S + H[s];
+                if (s >= 2 * F + 1) S = S - H[s - 2 * F - 1];
+                if (s >= 2 * F) {
+                    const int p = s - 2 * F;
+                    const double d2 = S * inv_norm;
+                    const double t = d2 - a.two_sigma2;
+                    const double m = (0.0 > t) ? 0.0 : t;
+                    const float w = __expf((float)(m * neg_inv_h2));
+                    tw[p] = tw[p] + (double)w;
+                    if (NEFF) tsq[p] = tsq[p] + (double)w * (double)w;
+                    wmax[p] = w > wmax[p] ? w : wmax[p];
+                    const int qr = cy0 + p + dy, qc = cx + dx;
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        ws[p][v] = (float)((double)ws[p][v] +
+                                           ((double)w * (double)lds[v * rows * cols + qr * cols + qc]));
+                }
+            }
+        }
+    }
+
+    const int64_t x = x0 + lane;
+#pragma unroll
+    for (int p = 0; p < TYW; ++p) {
+        const int64_t y = y0 + wave * TYW + p;
+        if (y < a.chi0 && x < a.chi1) {
+            bool fail;
+            const double wself = nlm_self_weight(tw[p], NEFF ? tsq[p] : 0.0, (double)wmax[p],
+                                                 a.n_eff, a.neff_policy, a.status, &fail);
+            if (!fail) {
+                const double total = tw[p] + wself;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float c = lds[v * rows * cols + (cy0 + p) * cols + cx];
+                    const float sfin = (float)((double)ws[p][v] + (wself * (double)c));
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] =
+                        (float)((double)sfin / total);
+                }
+            }
+        }
+    }
+}
+
+template <int F, int V>
+static void launch_patch(const NlmTiledArgs &a, int64_t nslices, size_t lds, hipStream_t stream)
+{
+    constexpr int TYW = (V == 1) ? 16 : 8;
+    const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nslices;
+    if (a.n_eff >= 0)
+        hipLaunchKernelGGL((nlmeans_patch_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256),
+                           lds, stream, a);
+    else
+        hipLaunchKernelGGL((nlmeans_patch_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256),
+                           lds, stream, a);
+}
+
+template <int F>
+static bool launch_patch_v(const NlmTiledArgs &a, int64_t nslices, size_t lds, hipStream_t stream)
+{
+    switch (a.nvars) {
+    case 1: launch_patch<F, 1>(a, nslices, lds, stream); return true;
+    case 2: launch_patch<F, 2>(a, nslices, lds, stream); return true;
+    case 3: launch_patch<F, 3>(a, nslices, lds, stream); return true;
+    case 4: launch_patch<F, 4>(a, nslices, lds, stream); return true;
+    }
+    return false;
+}
+
+// Try a tiled form; 1 = launched, 0 = not applicable.
+static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[3], int64_t nvars,
+                         const int64_t si[4], const int64_t so[4], const uint32_t r[3],
+                         const uint32_t f[3], double sigma, double h, double n_eff, int patch_mode,
+                         int neff_policy, int32_t *status_dev, const int64_t G[3],
+                         const int64_t toff[3], const int64_t clo[3], const int64_t chi[3],
+                         hipStream_t stream)
+{
+    static const bool disabled = getenv("ND_AMD_NO_TILED") != nullptr;
+    if (disabled || dtype != ND_AMD_F32) return 0;
+    if (r[2] != 0 || f[2] != 0) return 0;
+    if (si[1] != 1 || so[1] != 1) return 0;
+    if (r[0] == 0 && r[1] == 0) return 0;
+    if (nvars < 1) return 0;
+    for (int d = 0; d < 2; ++d)
+        if (G[d] > 0x3fffffff || N[d] > 0x3fffffff) return 0;
+    NlmTiledArgs a;
+    a.arr = static_cast<const float *>(arr);
+    a.out = static_cast<float *>(out);
+    a.N0 = N[0]; a.N1 = N[1]; a.N2 = N[2];
+    a.G0 = G[0]; a.G1 = G[1];
+    a.off0 = toff[0]; a.off1 = toff[1];
+    a.clo0 = clo[0]; a.chi0 = chi[0]; a.clo1 = clo[1]; a.chi1 = chi[1]; a.clo2 = clo[2]; a.chi2 = chi[2];
+    a.si0 = si[0]; a.si2 = si[2]; a.si3 = si[3];
+    a.so0 = so[0]; a.so2 = so[2]; a.so3 = so[3];
+    a.r0 = (int)r[0]; a.r1 = (int)r[1]; a.f0 = (int)f[0]; a.f1 = (int)f[1];
+    a.nvars = (int)nvars;
+    a.dsq_norm = (float)((((uint32_t)nvars * (2u * f[0] + 1u)) * (2u * f[1] + 1u)) * 1u);
+    a.two_sigma2 = 2.0 * (sigma * sigma);
+    a.h2 = h * h;
+    a.n_eff = n_eff;
+    a.neff_policy = neff_policy;
+    a.status = status_dev;
+    const int64_t ey = chi[0] - clo[0], ex = chi[1] - clo[1], nsl = chi[2] - clo[2];
+    if (ey < 1 || ex < 1 || nsl < 1) return 0;
+
+    const bool uniform = (patch_mode == 0) && (f[0] > 0 || f[1] > 0);
+    if (uniform) {
+        // weight exp(-max(0 - 2 sigma^2, 0) / h^2) must be exactly 1
+        if (!(sigma == sigma) || !(h == h) || h == 0.0 || !(sigma * sigma < INFINITY)) return 0;
+        if (r[1] > 16) return 0;
+        a.tiles_x = (int)ceil_div(ex, kWinTX);
+        a.tiles_y = (int)ceil_div(ey, kWinTY);
+        const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nsl;
+        const size_t rows = kWinTY + 2 * r[0], cols = kWinTX + 2 * r[1];
+        const size_t lds = rows * cols * sizeof(float) + (rows + cols) * sizeof(int);
+        if (lds > 64 * 1024 || nb > 0x7fffffffLL) return 0;
+        KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
+        if (r[1] <= 4)
+            hipLaunchKernelGGL((nlmeans_window_kernel<4>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        else if (r[1] <= 10)
+            hipLaunchKernelGGL((nlmeans_window_kernel<10>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        else
+            hipLaunchKernelGGL((nlmeans_window_kernel<16>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        return 1;
+    }
+    // true patch distances (patch_mode 1, or f = 0 in either mode: the loops run once)
+    const uint32_t F0 = (patch_mode == 1) ? f[0] : 0u, F1 = (patch_mode == 1) ? f[1] : 0u;
+    if (patch_mode == 0 && (f[0] != 0 || f[1] != 0)) return 0;
+    if (F0 != F1 || F0 > 3 || nvars > 4) return 0;
+    const int tyw = (nvars == 1) ? 16 : 8;
+    a.tiles_x = (int)ceil_div(ex, 64);
+    a.tiles_y = (int)ceil_div(ey, 4 * tyw);
+    const size_t cols = 64 + 2 * (r[1] + F0);
+    const size_t rows = 4 * tyw + 2 * (r[0] + F0);
+    const size_t lds = (size_t)nvars * rows * cols * sizeof(float) + (rows + cols) * sizeof(int);
+    if (lds > 64 * 1024) return 0;
+    if ((int64_t)a.tiles_x * a.tiles_y * nsl > 0x7fffffffLL) return 0;
+    KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
+    bool ok = false;
+    switch (F0) {
+    case 0: ok = launch_patch_v<0>(a, nsl, lds, stream); break;
+    case 1: ok = launch_patch_v<1>(a, nsl, lds, stream); break;
+    case 2: ok = launch_patch_v<2>(a, nsl, lds, stream); break;
+    default: ok = launch_patch_v<3>(a, nsl, lds, stream); break;
+    }
+    return ok ? 1 : 0;
+}
+
 template <typename T>
 static int nlmeans_impl(const void *arr, void *out, const int64_t N[3], int64_t nvars,
                         const int64_t si[4], const int64_t so[4], const uint32_t r[3],
@@ -216,6 +615,13 @@ static int nlmeans_impl(const void *arr, void *out, const int64_t N[3], int64_t 
     a.status = status_dev;
     if (status_dev) ND_HIP_CHECK(hipMemsetAsync(status_dev, 0, sizeof(int32_t), stream));
     if (a.total == 0) return ND_AMD_OK;
+
+    if (nlm_try_tiled(arr, out, sizeof(T) == 4 ? ND_AMD_F32 : ND_AMD_F64, N, nvars, si, so, r, f,
+                      sigma, h, n_eff, patch_mode, neff_policy, status_dev, G, toff, clo, chi,
+                      stream)) {
+        ND_HIP_CHECK(hipGetLastError());
+        return ND_AMD_OK;
+    }
 
     // lanes along the axis with the smallest non-trivial input stride
     int ord[3] = {0, 1, 2};

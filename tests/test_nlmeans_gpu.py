@@ -109,3 +109,55 @@ def test_tile_with_halo_equals_untiled(device):
         out[lo:hi] = tout[lo - tlo:hi - tlo]
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), full)
+
+
+@pytest.mark.parametrize('patch_mode', [0, 1])
+@pytest.mark.parametrize('case', [
+    ((70, 131, 2, 1), (3, 4, 0), (1, 1, 0), 0.5, 0.5, -1),
+    ((65, 64, 1, 1), (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1),
+    ((33, 40, 3, 2), (2, 3, 0), (2, 2, 0), 0.4, 0.6, -1),
+    ((40, 70, 2, 4), (3, 2, 0), (1, 1, 0), 0.5, 0.5, -1),
+    ((64, 64, 1, 3), (1, 1, 0), (0, 0, 0), 0.3, 0.4, -1),
+    ((50, 66, 2, 1), (4, 4, 0), (1, 1, 0), 0.8, 2.0, 6.0),
+    ((30, 30, 1, 1), (0, 5, 0), (0, 2, 0), 0.5, 0.5, -1),
+])
+def test_tiled_kernels_planar_layout(oracle, device, patch_mode, case):
+    """Planar [var][time][y][x] memory viewed as (y, x, time, var): the LDS-tiled kernels
+    (uniform-weight window sums in patch_mode 0, sliding patch sums in patch_mode 1)."""
+    shape, r, f, s, h, ne = case
+    rng = np.random.default_rng(41)
+    a = rng.gamma(4.0, 0.25, shape).astype(np.float32)
+    want = np.empty_like(a)
+    oracle.pixelwise_nlmeans_3d(a, want, r, f, s, h, ne, neff_policy=0, njobs=8, patch_mode=patch_mode)
+    got = _gpu_nlm(a, r, f, s, h, ne, device, patch_mode=patch_mode, neff_policy=0,
+                   permute=(3, 2, 0, 1))
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=0)
+    if patch_mode == 0 and max(f) > 0 and ne < 0:
+        np.testing.assert_array_equal(got, want)        # unit weights: bit-exact sums
+
+
+def test_tiled_halo_tile_equals_untiled(device):
+    """Tiled kernels with global_shape / tile_offset / core (multi-GPU row blocks)."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(43)
+    full_np = rng.gamma(4.0, 0.25, (1, 2, 96, 70)).astype(np.float32)     # (var, t, y, x)
+    t = torch.from_numpy(full_np).to(device)
+    r, f = (4, 3, 0), (2, 2, 0)
+    for pm in (0, 1):
+        ref = torch.empty_like(t)
+        kernels.pixelwise_nlmeans_3d(t.permute(2, 3, 1, 0), ref.permute(2, 3, 1, 0), r, f, 0.4, 0.5,
+                                     -1, patch_mode=pm)
+        halo = r[0] + f[0]
+        out = torch.zeros_like(t)
+        for lo, hi in [(0, 30), (30, 66), (66, 96)]:
+            tlo, thi = max(lo - halo, 0), min(hi + halo, 96)
+            tile = t[:, :, tlo:thi].contiguous()
+            tout = torch.empty_like(tile)
+            kernels.pixelwise_nlmeans_3d(tile.permute(2, 3, 1, 0), tout.permute(2, 3, 1, 0), r, f,
+                                         0.4, 0.5, -1, patch_mode=pm, global_shape=(96, 70, 2),
+                                         tile_offset=(tlo, 0, 0),
+                                         core=((lo - tlo, hi - tlo), (0, 70), (0, 2)))
+            out[:, :, lo:hi] = tout[:, :, lo - tlo:hi - tlo]
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
