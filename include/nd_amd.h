@@ -51,6 +51,7 @@ extern "C" {
 #define ND_AMD_KERNEL_NLMEANS        4
 #define ND_AMD_KERNEL_BOXCAR_TILED   5
 #define ND_AMD_KERNEL_NLMEANS_TILED  6
+#define ND_AMD_KERNEL_CORRELATE1D    7
 
 int nd_amd_abi_version(void);
 const char *nd_amd_last_error(void);
@@ -120,6 +121,26 @@ int nd_amd_correlate(const void *in, void *out, int dtype,
                      int mode, double cval,
                      void *taps_dev, size_t taps_dev_bytes,
                      void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * 1-D correlation along one axis -- the building block of GaussianFilter.
+ * Replaces  scipy.ndimage.correlate1d(input, weights, axis, output, mode, cval, 0)
+ *           which scipy.ndimage.gaussian_filter1d calls once per filtered axis
+ *           (reference call site nd/filters.py:365-378).
+ *
+ * scipy's NI_Correlate1D arithmetic, restated: with the weights centred at
+ * size1 = n/2, an odd-length kernel that is symmetric to DBL_EPSILON gives
+ *   out = x[0] w[0];  for j = -size1..-1:  out += (x[j] + x[-j]) * w[j]
+ * (anti-symmetric: x[j] - x[-j]); any other kernel
+ *   out = x[size2] w[size2];  for j = -size1..size2-1:  out += x[j] * w[j]
+ * all in double, cast to the array dtype on store.  `in` and `out` must not
+ * overlap.  weights: host pointer, n <= 255 doubles.
+ * ---------------------------------------------------------------------- */
+int nd_amd_correlate1d(const void *in, void *out, int dtype,
+                       const int64_t dims[4],
+                       const int64_t in_strides[4], const int64_t out_strides[4],
+                       int axis, int nweights, const double *weights,
+                       int mode, double cval, void *hip_stream);
 
 /* ------------------------------------------------------------------------
  * Non-local means.

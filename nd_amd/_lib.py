@@ -16,12 +16,12 @@ OK, EINVAL, EWORKSPACE, EHIP, ENOSOLUTION, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 MODES = {'reflect': 0, 'constant': 1, 'nearest': 2, 'mirror': 3, 'wrap': 4,
          'grid-constant': 1, 'grid-mirror': 0, 'grid-wrap': 4}
 KERNEL_NAMES = {1: 'omnibus_c2_global', 2: 'omnibus_c2_search', 3: 'correlate',
-                4: 'nlmeans', 5: 'boxcar_tiled', 6: 'nlmeans_tiled'}
+                4: 'nlmeans', 5: 'boxcar_tiled', 6: 'nlmeans_tiled', 7: 'correlate1d'}
 
 # every symbol include/nd_amd.h declares
 SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_omnibus_c2_workspace_bytes', 'nd_amd_omnibus_c2',
-           'nd_amd_correlate', 'nd_amd_nlmeans3d',
+           'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_nlmeans3d',
            'nd_amd_timing_enable', 'nd_amd_timing_collect')
 
 _lib = None
@@ -58,6 +58,9 @@ def lib():
     L.nd_amd_correlate.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(i64), i64, C.POINTER(i64),
                                    C.POINTER(dbl), i32, dbl, vp, C.c_size_t, vp]
+    L.nd_amd_correlate1d.restype = i32
+    L.nd_amd_correlate1d.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
+                                     i32, i32, C.POINTER(dbl), i32, dbl, vp]
     L.nd_amd_nlmeans3d.restype = i32
     L.nd_amd_nlmeans3d.argtypes = [vp, vp, i32, C.POINTER(i64), i64, C.POINTER(i64),
                                    C.POINTER(i64), C.POINTER(C.c_uint32),

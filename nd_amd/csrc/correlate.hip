@@ -11,6 +11,7 @@
 //
 // Generic kernel: one thread per output element of a 4-D strided view, last axis fastest across
 // lanes.  Interior elements (no tap leaves the array) use precomputed linear tap offsets.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -449,9 +450,189 @@ static int correlate_impl(const void *in, void *out, const int64_t dims[4], cons
     return ND_AMD_OK;
 }
 
+// -----------------------------------------------------------------------------------------
+// NI_Correlate1D along one axis (GaussianFilter).  One thread per output element of the 4-D
+// view, last axis fastest across lanes whatever the filtered axis is.
+// -----------------------------------------------------------------------------------------
+constexpr int kMaxW1D = 255;
+
+// Line extension of NI_ExtendLine (ni_support.c), which the 1-D filters use: exactly periodic
+// for any distance from the array (unlike the offset table of the N-D correlate).
+//   reflect  d c b a | a b c d | d c b a      (period 2n)
+//   mirror     d c b | a b c d | c b a        (period 2n - 2)
+//   wrap     a b c d | a b c d | a b c d      nearest: edge value      constant: cval (-1)
+__device__ __forceinline__ int64_t extend_line(int64_t cc, int64_t len, int mode)
+{
+    if (cc >= 0 && cc < len) return cc;
+    switch (mode) {
+    case ND_AMD_MODE_REFLECT: {
+        const int64_t p = 2 * len;
+        int64_t m = cc % p;
+        if (m < 0) m += p;
+        return m < len ? m : p - 1 - m;
+    }
+    case ND_AMD_MODE_CONSTANT:
+        return -1;
+    case ND_AMD_MODE_NEAREST:
+        return cc < 0 ? 0 : len - 1;
+    case ND_AMD_MODE_MIRROR: {
+        if (len <= 1) return 0;
+        const int64_t p = 2 * len - 2;
+        int64_t m = cc % p;
+        if (m < 0) m += p;
+        return m < len ? m : p - m;
+    }
+    case ND_AMD_MODE_WRAP: {
+        int64_t m = cc % len;
+        if (m < 0) m += len;
+        return m;
+    }
+    }
+    return -1;
+}
+
+template <typename T>
+struct Corr1dArgs {
+    const T *in;
+    T *out;
+    int64_t A[4], si[4], so[4];
+    int64_t total;
+    int axis, n, size1, size2, symmetric, mode;
+    double cval;
+    double w[kMaxW1D];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) correlate1d_kernel(const Corr1dArgs<T> a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.total) return;
+    int64_t i[4];
+    int64_t rem = idx;
+    i[3] = rem % a.A[3];
+    rem /= a.A[3];
+    i[2] = rem % a.A[2];
+    rem /= a.A[2];
+    i[1] = rem % a.A[1];
+    i[0] = rem / a.A[1];
+    const int64_t len = a.A[a.axis], sax = a.si[a.axis], pos = i[a.axis];
+    const int64_t base = i[0] * a.si[0] + i[1] * a.si[1] + i[2] * a.si[2] + i[3] * a.si[3] - pos * sax;
+    auto x = [&](int64_t j) -> double {
+        const int64_t q = extend_line(pos + j, len, a.mode);
+        return q < 0 ? a.cval : (double)a.in[base + q * sax];
+    };
+    const double *fw = a.w + a.size1;
+    double o;
+    if (a.symmetric > 0) {
+        o = x(0) * fw[0];
+        for (int j = -a.size1; j < 0; ++j) o = o + (x(j) + x(-j)) * fw[j];
+    } else if (a.symmetric < 0) {
+        o = x(0) * fw[0];
+        for (int j = -a.size1; j < 0; ++j) o = o + (x(j) - x(-j)) * fw[j];
+    } else {
+        o = x(a.size2) * fw[a.size2];
+        for (int j = -a.size1; j < a.size2; ++j) o = o + x(j) * fw[j];
+    }
+    a.out[i[0] * a.so[0] + i[1] * a.so[1] + i[2] * a.so[2] + i[3] * a.so[3]] = (T)o;
+}
+
+template <typename T>
+static int correlate1d_impl(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
+                            const int64_t so[4], int axis, int n, const double *weights, int mode,
+                            double cval, hipStream_t stream)
+{
+    Corr1dArgs<T> a;
+    a.in = static_cast<const T *>(in);
+    a.out = static_cast<T *>(out);
+    a.total = 1;
+    for (int d = 0; d < 4; ++d) {
+        a.A[d] = dims[d];
+        a.si[d] = si[d];
+        a.so[d] = so[d];
+        a.total *= dims[d];
+    }
+    a.axis = axis;
+    a.n = n;
+    a.size1 = n / 2;
+    a.size2 = n - a.size1 - 1;
+    a.mode = mode;
+    a.cval = cval;
+    for (int j = 0; j < kMaxW1D; ++j) a.w[j] = j < n ? weights[j] : 0.0;
+    // symmetry test of NI_Correlate1D
+    a.symmetric = 0;
+    if (n & 1) {
+        a.symmetric = 1;
+        for (int ii = 1; ii <= n / 2; ++ii)
+            if (fabs(weights[ii + a.size1] - weights[a.size1 - ii]) > 2.220446049250313e-16) {
+                a.symmetric = 0;
+                break;
+            }
+        if (a.symmetric == 0) {
+            a.symmetric = -1;
+            for (int ii = 1; ii <= n / 2; ++ii)
+                if (fabs(weights[a.size1 + ii] + weights[a.size1 - ii]) > 2.220446049250313e-16) {
+                    a.symmetric = 0;
+                    break;
+                }
+        }
+    }
+    if (a.total == 0) return ND_AMD_OK;
+    const int64_t nblocks = ceil_div(a.total, 256);
+    if (nblocks > 0x7fffffffLL) {
+        set_error("nd_amd_correlate1d: array too large for one launch");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    {
+        KernelTimer timer(ND_AMD_KERNEL_CORRELATE1D, stream);
+        hipLaunchKernelGGL((correlate1d_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, stream, a);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+    return ND_AMD_OK;
+}
+
 }  // namespace nd_amd
 
 using namespace nd_amd;
+
+extern "C" int nd_amd_correlate1d(const void *in, void *out, int dtype, const int64_t dims[4],
+                                  const int64_t in_strides[4], const int64_t out_strides[4],
+                                  int axis, int nweights, const double *weights, int mode,
+                                  double cval, void *hip_stream)
+{
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_correlate1d: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (!dims || !in_strides || !out_strides || !weights || axis < 0 || axis > 3 || nweights < 1) {
+        set_error("nd_amd_correlate1d: bad argument");
+        return ND_AMD_EINVAL;
+    }
+    if (nweights > kMaxW1D) {
+        set_error("nd_amd_correlate1d: %d weights exceed the limit of %d", nweights, kMaxW1D);
+        return ND_AMD_EUNSUPPORTED;
+    }
+    if (mode < 0 || mode > 4) {
+        set_error("nd_amd_correlate1d: unknown border mode %d", mode);
+        return ND_AMD_EINVAL;
+    }
+    for (int d = 0; d < 4; ++d)
+        if (dims[d] < 0) {
+            set_error("nd_amd_correlate1d: negative dimension");
+            return ND_AMD_EINVAL;
+        }
+    if (dims[0] * dims[1] * dims[2] * dims[3] == 0) return ND_AMD_OK;
+    if (!in || !out || in == out) {
+        set_error("nd_amd_correlate1d: null or aliased data pointers");
+        return ND_AMD_EINVAL;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (dtype == ND_AMD_F32)
+        return correlate1d_impl<float>(in, out, dims, in_strides, out_strides, axis, nweights,
+                                       weights, mode, cval, stream);
+    return correlate1d_impl<double>(in, out, dims, in_strides, out_strides, axis, nweights, weights,
+                                    mode, cval, stream);
+}
+
 
 extern "C" int nd_amd_correlate(const void *in, void *out, int dtype, const int64_t dims[4],
                                 const int64_t in_strides[4], const int64_t out_strides[4],

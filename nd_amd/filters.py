@@ -7,8 +7,8 @@ nd_amd/filters.py -- the reference's filter classes (nd/filters.py) with the ari
   ConvolutionFilter  scipy.ndimage.convolve semantics (nd/filters.py:205-267) -> nd_amd_correlate
   BoxcarFilter       ones/w**N kernel (nd/filters.py:277-298)
   NLMeansFilter      nd/filters.py:388-466 -> nd_amd_nlmeans3d
-  GaussianFilter     nd/filters.py:308-378 -- separable scipy.ndimage.gaussian_filter; next on the
-                     list, not on the GPU yet.
+  GaussianFilter     nd/filters.py:308-378 -> scipy.ndimage.gaussian_filter restated as one
+                     nd_amd_correlate1d pass per filtered axis
 
 Arrays may be numpy (copied to the device and back: the drop-in case) or torch ROCm tensors
 (device-resident pipelines, no host copies).
@@ -280,9 +280,24 @@ class GaussianFilter(Filter):
         return int(4.0 * sigma + 0.5)
 
     def _filter(self, arr, axes, output):
-        raise NotImplementedError(
-            'GaussianFilter has no GPU kernel yet (SURVEY.md section 8f, rank 1); '
-            'ConvolutionFilter, BoxcarFilter and NLMeansFilter are available.')
+        unknown = set(self.kwargs) - {'mode', 'cval', 'truncate'}
+        if unknown:
+            raise TypeError('unsupported scipy.ndimage.gaussian_filter arguments: %s'
+                            % sorted(unknown))
+        ndsigma = [0] * arr.ndim
+        for ax, s in zip(axes, self.sigma):
+            ndsigma[ax] = s
+        dev = _device.device_of(arr, output)
+        with torch.cuda.device(dev):
+            t = _device.to_device(arr, dev)
+            if _device.np_dtype(arr) not in (np.float32, np.float64):
+                raise TypeError('GaussianFilter on the GPU supports float32/float64 arrays')
+            out_t = output if _device.is_tensor(output) else torch.empty_like(t)
+            if out_t.data_ptr() == t.data_ptr():
+                t = t.clone()
+            kernels.gaussian_filter(t, ndsigma, out=out_t, **self.kwargs)
+            if out_t is not output:
+                _device.write_back(out_t, output)
 
 
 gaussian = wrap_algorithm(GaussianFilter, 'gaussian')

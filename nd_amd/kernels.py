@@ -183,6 +183,70 @@ def convolve(inp, kernel, out=None, mode='reflect', cval=0.0, origin=0):
     return correlate_footprint(inp, out, offs, w, mode, cval)
 
 
+def correlate1d(inp, weights, axis, out, mode='reflect', cval=0.0):
+    """scipy.ndimage.correlate1d(inp, weights, axis, out, mode, cval, origin=0) on a real CUDA
+    tensor (ndim <= 4); `out` must not alias `inp`."""
+    _require_cuda(inp, 'inp')
+    _require_cuda(out, 'out')
+    if inp.shape != out.shape or inp.dtype != out.dtype or inp.device != out.device:
+        raise ValueError('inp and out must share shape, dtype and device')
+    if inp.dim() > 4:
+        raise NotImplementedError('nd_amd_correlate1d handles up to 4 dimensions')
+    if mode not in _lib.MODES:
+        raise RuntimeError('boundary mode not supported')
+    weights = np.ascontiguousarray(weights, np.float64)
+    pad = 4 - inp.dim()
+    axis = axis % inp.dim()
+    dev = inp.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nd_amd_correlate1d(
+            _ptr(inp), _ptr(out), _DT[inp.dtype], _lib.i64_array((1,) * pad + tuple(inp.shape)),
+            _lib.i64_array((0,) * pad + tuple(inp.stride())),
+            _lib.i64_array((0,) * pad + tuple(out.stride())), axis + pad, len(weights),
+            weights.ctypes.data_as(C.POINTER(C.c_double)), _lib.MODES[mode], float(cval),
+            _stream_ptr(dev)))
+    return out
+
+
+def _gaussian_kernel1d(sigma, radius):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, order=0, radius)."""
+    sigma2 = sigma * sigma
+    x = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x ** 2)
+    return phi_x / phi_x.sum()
+
+
+def gaussian_filter(inp, sigma, out=None, mode='reflect', cval=0.0, truncate=4.0):
+    """scipy.ndimage.gaussian_filter(inp, sigma, output=out, mode, cval, truncate): one
+    correlate1d pass per axis with sigma > 1e-15, each pass reading the previous pass's result
+    in the array dtype (scipy filters `output` in place from the second axis on)."""
+    if out is None:
+        out = torch.empty_like(inp)
+    nd = inp.dim()
+    sigmas = [float(sigma)] * nd if np.isscalar(sigma) else [float(s) for s in sigma]
+    if len(sigmas) != nd:
+        raise RuntimeError('sequence argument must have length equal to input rank')
+    axes = [(ax, sd) for ax, sd in enumerate(sigmas) if sd > 1e-15]
+    if not axes:
+        out.copy_(inp)
+        return out
+    src = inp
+    bufs = [out, None]
+    for n_done, (ax, sd) in enumerate(axes):
+        lw = int(truncate * sd + 0.5)
+        weights = _gaussian_kernel1d(sd, lw)[::-1]
+        # the last pass must land in `out`; alternate between `out` and one scratch tensor
+        remaining = len(axes) - n_done
+        dst = out if remaining % 2 == 1 else None
+        if dst is None:
+            if bufs[1] is None:
+                bufs[1] = torch.empty_like(out)
+            dst = bufs[1]
+        correlate1d(src, weights, ax, dst, mode, cval)
+        src = dst
+    return out
+
+
 # ---------------------------------------------------------------------------
 # non-local means
 # ---------------------------------------------------------------------------
