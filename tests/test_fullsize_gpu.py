@@ -1,0 +1,100 @@
+"""Checks at BASELINE.json's full size (24 dates x 4096 x 4096, the benchmark stack itself): the
+oracle on a random sample of pixels and on whole rows of the same raster, plus size-independent
+properties (row-chunk invariance, a constant series never changes, a strong injected step is found
+at its date, the reference-layout view gives the same map)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K, NY, NX = 24, 4096, 4096
+
+
+@pytest.fixture(scope='module')
+def stack(device):
+    import torch
+    from nd_amd import synth
+    s = synth.wishart_c2_stack(K, NY, NX, looks=9, seed=1234, device=device, change_frac=0.01)
+    torch.cuda.synchronize()
+    return s
+
+
+@pytest.fixture(scope='module')
+def full_map(stack):
+    import torch
+    from nd_amd import kernels
+    ch = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=0.99, n=9)
+    torch.cuda.synchronize()
+    return ch
+
+
+def test_sampled_pixels_and_rows_match_oracle(oracle, stack, full_map):
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(5)
+    idx = torch.randint(0, NY * NX, (150000,), generator=g)
+    rows = torch.tensor([0, 1, 2047, 4095])
+    idx = torch.cat([idx, (rows[:, None] * NX + torch.arange(NX)[None]).reshape(-1)])
+    dev_idx = idx.to(stack.device)
+    flat = stack.reshape(4, K, NY * NX)
+    sample = flat[:, :, dev_idx].cpu().numpy()                     # (4, K, n)
+    planes = [np.ascontiguousarray(sample[v].T)[None] for v in range(4)]     # (1, n, K)
+    want = oracle.change_detection_planes(planes, 0.99, 9, njobs=8)[0]
+    got = full_map.reshape(NY * NX, K)[dev_idx].cpu().numpy()
+    assert got.shape == want.shape
+    nbad = int((got != want).sum())
+    assert nbad == 0, '%d of %d sampled change-map bytes differ' % (nbad, got.size)
+    frac = (want.sum(axis=1) > 0).mean()
+    assert 0.005 < frac < 0.05                                    # ~1 % injected + ~1 % false alarms
+
+
+def test_row_chunks_give_the_same_map(stack, full_map):
+    import torch
+    from nd_amd import kernels
+    for r0, r1 in [(0, 1000), (1000, 1001), (3000, 4096)]:
+        part = kernels.change_detection(stack[0][:, r0:r1], stack[1][:, r0:r1], stack[2][:, r0:r1],
+                                        stack[3][:, r0:r1], alpha=0.99, n=9)
+        assert torch.equal(part, full_map[r0:r1])
+
+
+def test_reference_layout_view_gives_the_same_map(stack, full_map):
+    """(y, x, time) strided views of the same memory: the generic-stride path."""
+    import torch
+    from nd_amd import kernels
+    sub = [stack[v][:, 100:164].permute(1, 2, 0) for v in range(4)]           # (y, x, time) views
+    got = kernels.change_detection(*sub, alpha=0.99, n=9, dims=('y', 'x', 'time'))
+    assert torch.equal(got, full_map[100:164])
+
+
+def test_constant_series_and_strong_step(device):
+    import torch
+    from nd_amd import kernels, synth
+    k, ny, nx = 24, 512, 4096
+    st = synth.empty_stack(4, k, ny, nx, device)
+    st[0].fill_(1.0); st[1].fill_(0.1); st[2].fill_(-0.05); st[3].fill_(0.7)
+    ch = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.5, n=9)
+    assert int(ch.sum()) == 0                  # identical matrices: z = -0, P = 0
+    st[0][13:] *= 50.0
+    st[3][13:] *= 50.0
+    st[1][13:] *= 50.0
+    st[2][13:] *= 50.0
+    ch = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9)
+    assert bool(ch[:, :, 13].all())
+    assert int(ch.sum()) == ny * nx
+
+
+def test_large_k_paths(oracle, device):
+    """k beyond the register-retaining kernel (streaming + gather) and beyond the by-value table."""
+    import torch
+    from nd_amd import kernels
+    from tests import synth as tsynth
+    for k, ny, nx in [(56, 12, 260), (100, 6, 64), (130, 3, 40)]:
+        planes = tsynth.omnibus_stack(seed=k, k=k, ny=ny, nx=nx, dtype=np.float32, change_frac=0.3)
+        ts = [torch.from_numpy(p).to(device) for p in planes]
+        ch, z, P = kernels.change_detection(*ts, alpha=0.9, n=9, stats=True)
+        ch2 = kernels.change_detection(*ts, alpha=0.9, n=9)
+        yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+        want, z0, P0 = oracle.change_detection_planes(yxt, 0.9, 9, njobs=8, stats=True)
+        np.testing.assert_array_equal(ch.cpu().numpy(), want)
+        np.testing.assert_array_equal(ch2.cpu().numpy(), want)
+        np.testing.assert_allclose(z.cpu().numpy(), z0, rtol=1e-5)
+        np.testing.assert_allclose(P.cpu().numpy(), P0, rtol=1e-5, atol=1e-30)
