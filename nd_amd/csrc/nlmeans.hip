@@ -425,10 +425,19 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
     }
 
     const int64_t x = x0 + lane;
+    // Pixels whose largest float32 weight is (nearly) zero: the reference's double weights are
+    // still non-zero there and decide the self weight and the (denormal) sums, so those pixels
+    // are recomputed below exactly as the reference does.  Elsewhere weights under 1e-30 of the
+    // maximum cannot move the result by 1e-8.
+    unsigned exact_mask = 0;
 #pragma unroll
     for (int p = 0; p < TYW; ++p) {
         const int64_t y = y0 + wave * TYW + p;
         if (y < a.chi0 && x < a.chi1) {
+            if (!(wmax[p] >= 1e-30f)) {
+                exact_mask |= 1u << p;
+                continue;
+            }
             bool fail;
             const double wself = nlm_self_weight(tw[p], NEFF ? tsq[p] : 0.0, (double)wmax[p],
                                                  a.n_eff, a.neff_policy, a.status, &fail);
@@ -438,6 +447,56 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
                 for (int v = 0; v < V; ++v) {
                     const float c = lds[v * rows * cols + (cy0 + p) * cols + cx];
                     const float sfin = (float)((double)ws[p][v] + (wself * (double)c));
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] =
+                        (float)((double)sfin / total);
+                }
+            }
+        }
+    }
+    if (__any(exact_mask != 0u)) {
+        for (int p = 0; p < TYW; ++p) {
+            if (!((exact_mask >> p) & 1u)) continue;
+            // nd/_filters.pyx:363-420 for this one pixel, from the staged tile
+            const int py = cy0 + p;
+            double t_w = 0.0, t_sq = 0.0, m_w = 0.0;
+            float wsum[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) wsum[v] = 0.f;
+            for (int dy = -r0; dy <= r0; ++dy)
+                for (int dx = -r1; dx <= r1; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    double dsq = 0.0;
+                    for (int i = -F; i <= F; ++i)
+                        for (int j = -F; j <= F; ++j)
+#pragma unroll
+                            for (int v = 0; v < V; ++v) {
+                                const float *base = lds + v * rows * cols;
+                                const float df = base[(py + i) * cols + cx + j] -
+                                                 base[(py + dy + i) * cols + cx + dx + j];
+                                const float sq = df * df;
+                                dsq = dsq + (double)sq;
+                            }
+                    dsq = dsq / (double)a.dsq_norm;
+                    const double t = dsq - a.two_sigma2;
+                    const double m = (0.0 > t) ? 0.0 : t;
+                    const double w = exp((-m) / a.h2);
+                    t_w = t_w + w;
+                    t_sq = t_sq + (w * w);
+                    if (w > m_w) m_w = w;
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        wsum[v] = (float)((double)wsum[v] +
+                                          (w * (double)lds[v * rows * cols + (py + dy) * cols + cx + dx]));
+                }
+            bool fail;
+            const double wself = nlm_self_weight(t_w, t_sq, m_w, a.n_eff, a.neff_policy, a.status, &fail);
+            if (!fail) {
+                const double total = t_w + wself;
+                const int64_t y = y0 + wave * TYW + p;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float c = lds[v * rows * cols + py * cols + cx];
+                    const float sfin = (float)((double)wsum[v] + (wself * (double)c));
                     a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] =
                         (float)((double)sfin / total);
                 }

@@ -109,20 +109,43 @@ def boxcar_rows(stack, w, group=None):
 
 
 def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group=None):
-    """NLMeansFilter(dims=('y','x')) on a row-sharded planar stack (var, time, y_local, x): joint
-    weights over the variables, every date filtered on its own (r_time = 0), the halo rows
-    exchanged once for all variables and dates.  Reflection happens at the global edges."""
+    """NLMeansFilter on a row-sharded planar stack (var, time, y_local, x), joint weights over the
+    variables.  r, f: (time, y, x) radii like NLMeansFilter(dims=('time', 'y', 'x')).  The halo
+    rows (r_y + f_y) are exchanged once for all variables and dates; reflection happens at the
+    global edges.  With r_time = 0 every date is filtered on its own by the LDS-tiled kernels."""
     from . import kernels
-    ry, rx = int(r[0]), int(r[1])
-    fy, fx = int(f[0]), int(f[1])
+    rt, ry, rx = (int(v) for v in r)
+    ft, fy, fx = (int(v) for v in f)
     halo = ry + fy
     r0, _ = my_rows(global_ny, group)
     ext, lo, hi = exchange_halo(stack, halo, 2, group)
     nvar, k, ny_ext, nx = ext.shape
-    arr = ext.permute(2, 3, 1, 0)                   # (y, x, time, var) view of planar memory
     out = torch.empty_like(ext)
-    kernels.pixelwise_nlmeans_3d(
-        arr, out.permute(2, 3, 1, 0), (ry, rx, 0), (fy, fx, 0), sigma, h, n_eff,
-        patch_mode=patch_mode, global_shape=(global_ny, nx, k), tile_offset=(r0 - lo, 0, 0),
-        core=((lo, ny_ext - hi), (0, nx), (0, k)))
+    if rt == 0 and ft == 0:
+        # (y, x, time, var) view of planar memory: x contiguous
+        kernels.pixelwise_nlmeans_3d(
+            ext.permute(2, 3, 1, 0), out.permute(2, 3, 1, 0), (ry, rx, 0), (fy, fx, 0), sigma, h,
+            n_eff, patch_mode=patch_mode, global_shape=(global_ny, nx, k),
+            tile_offset=(r0 - lo, 0, 0), core=((lo, ny_ext - hi), (0, nx), (0, k)))
+    else:
+        kernels.pixelwise_nlmeans_3d(
+            ext.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), (rt, ry, rx), (ft, fy, fx), sigma, h,
+            n_eff, patch_mode=patch_mode, global_shape=(k, global_ny, nx),
+            tile_offset=(0, r0 - lo, 0), core=((0, k), (lo, ny_ext - hi), (0, nx)))
     return trim(out, lo, hi, 2)
+
+
+def omnibus_rows(stack, alpha, n, stats=False):
+    """OmnibusTest on this rank's rows of a planar stack (4, time, y_local, x): per pixel, no
+    exchange."""
+    from . import kernels
+    return kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha, n=n,
+                                    dims=('time', 'y', 'x'), stats=stats)
+
+
+def nlmeans_then_omnibus(stack, global_ny, r, f, sigma, h, alpha, n, n_eff=-1, patch_mode=0,
+                         group=None):
+    """The tutorial pipeline (examples/tutorial_s1.ipynb cells 11 and 15) on a row-sharded stack:
+    one halo exchange -> non-local means on tile+halo -> omnibus test on the tile's own rows."""
+    filtered = nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff, patch_mode, group)
+    return omnibus_rows(filtered, alpha, n)

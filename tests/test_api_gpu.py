@@ -267,3 +267,40 @@ def test_device_resident_pipeline(oracle, device):
     ml = [np.ascontiguousarray(np.moveaxis(ndi.convolve(p, k), 0, -1)) for p in planes]
     want = oracle.change_detection_planes(ml, 0.9, 9)
     np.testing.assert_array_equal(ch.values.cpu().numpy(), want.astype(bool))
+
+
+def test_row_tile_pipeline_matches_unsharded(oracle, device):
+    """tiles.nlmeans_then_omnibus on manual row tiles (what each rank of a multi-GPU run does,
+    minus the exchange, which tests/test_tiles_gloo.py covers) == the unsharded pipeline."""
+    import torch
+    from nd_amd import kernels, tiles
+    planes = synth.omnibus_stack(seed=12, k=8, ny=60, nx=72, looks=4, dtype=np.float32,
+                                 change_frac=0.2, factor=5.0)
+    stack = torch.from_numpy(np.stack(planes)).to(device)              # (4, k, y, x)
+    r, f = (0, 3, 3), (0, 1, 1)
+    full_f = tiles.nlmeans_rows(stack, 60, r, f, 0.5, 2.0, patch_mode=1)
+    full_ch = tiles.omnibus_rows(full_f, 0.9, 16)
+    # unsharded reference through the oracle: nlmeans (patch_mode 1) per date, then omnibus
+    a = np.ascontiguousarray(np.stack(planes).transpose(2, 3, 1, 0))   # (y, x, t, var)
+    want_f = np.empty_like(a)
+    oracle.pixelwise_nlmeans_3d(a, want_f, (3, 3, 0), (1, 1, 0), 0.5, 2.0, -1, njobs=8, patch_mode=1)
+    # signed variables cross zero: tolerance relative to the data scale
+    np.testing.assert_allclose(full_f.permute(2, 3, 1, 0).cpu().numpy(), want_f, rtol=1e-5,
+                               atol=1e-5 * float(np.abs(a).max()))
+    # manual sharding with halos and global coordinates
+    halo = 4
+    out = torch.zeros_like(full_ch)
+    for lo, hi in tiles.row_partition(60, 3):
+        tlo, thi = max(lo - halo, 0), min(hi + halo, 60)
+        ext = stack[:, :, tlo:thi].contiguous()
+        fo = torch.empty_like(ext)
+        kernels.pixelwise_nlmeans_3d(ext.permute(2, 3, 1, 0), fo.permute(2, 3, 1, 0), (3, 3, 0),
+                                     (1, 1, 0), 0.5, 2.0, -1, patch_mode=1,
+                                     global_shape=(60, 72, 8), tile_offset=(tlo, 0, 0),
+                                     core=((lo - tlo, hi - tlo), (0, 72), (0, 8)))
+        core = fo[:, :, lo - tlo:hi - tlo].contiguous()
+        out[lo:hi] = tiles.omnibus_rows(core, 0.9, 16)
+    assert torch.equal(out, full_ch)
+    # 3-D search window (tutorial form) runs through the generic kernel
+    f3 = tiles.nlmeans_rows(stack, 60, (1, 2, 2), (0, 0, 0), 0.5, 2.0)
+    assert f3.shape == stack.shape and bool(torch.isfinite(f3).all())

@@ -161,3 +161,16 @@ def test_tiled_halo_tile_equals_untiled(device):
             out[:, :, lo:hi] = tout[:, :, lo - tlo:hi - tlo]
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+def test_tiny_weights_follow_the_reference(oracle, device):
+    """h far too small: every neighbour weight underflows float32 but not double.  The reference
+    then still uses max(weight) (a denormal-scale double) as self weight and its float32 weighted
+    sums underflow to 0; the tiled kernel must take the same path, not the 'all weights zero' one."""
+    rng = np.random.default_rng(44)
+    a = rng.gamma(4.0, 0.25, (40, 70, 1, 1)).astype(np.float32)
+    for s, h in [(0.1, 0.05), (0.05, 0.02)]:
+        want = np.empty_like(a)
+        oracle.pixelwise_nlmeans_3d(a, want, (3, 3, 0), (1, 1, 0), s, h, -1, njobs=8, patch_mode=1)
+        got = _gpu_nlm(a, (3, 3, 0), (1, 1, 0), s, h, -1, device, patch_mode=1, permute=(3, 2, 0, 1))
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
