@@ -46,12 +46,18 @@ def build_variant(name, patches, extra=()):
     subprocess.check_call([HIPCC] + FLAGS + list(extra) + ['-shared', '-o', so] + srcs)
     return so
 
-BUF_OLD = "            v[t][0] = buffer_load<T>(r11, voff, soff);\n            v[t][1] = buffer_load<T>(r12r, voff, soff);\n            v[t][2] = buffer_load<T>(r12i, voff, soff);\n            v[t][3] = buffer_load<T>(r22, voff, soff);"
-BUF_NEW = "            const int64_t o = ub + (int64_t)t * g.st;\n            v[t][0] = (g.c11 + o)[lx];\n            v[t][1] = (g.c12r + o)[lx];\n            v[t][2] = (g.c12i + o)[lx];\n            v[t][3] = (g.c22 + o)[lx];"
+NT_LOAD = [("__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0)", "__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 2)")]
+ZF_OLD = "        for (int i = tid; i < nvec; i += kGlobalThreads) vz[i] = make_uint4(0u, 0u, 0u, 0u);"
+ZF_NT = """        for (int i = tid; i < nvec; i += kGlobalThreads) {
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            u4 zz = {0u, 0u, 0u, 0u};
+            __builtin_nontemporal_store(zz, reinterpret_cast<u4 *>(vz + i));
+        }"""
 VARIANTS = {
-    'base_buffer_exact': [],
-    'global_exact': [(BUF_OLD, BUF_NEW)],
-    'noexact': [("#define ND_RETAIN_EXACT 1", "#define ND_RETAIN_EXACT 0")],
+    'base': [],
+    'nt_load': NT_LOAD,
+    'nt_zero': [(ZF_OLD, ZF_NT)],
+    'nt_both': NT_LOAD + [(ZF_OLD, ZF_NT)],
 }
 
 if __name__ == '__main__':
