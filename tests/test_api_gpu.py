@@ -304,3 +304,20 @@ def test_row_tile_pipeline_matches_unsharded(oracle, device):
     # 3-D search window (tutorial form) runs through the generic kernel
     f3 = tiles.nlmeans_rows(stack, 60, (1, 2, 2), (0, 0, 0), 0.5, 2.0)
     assert f3.shape == stack.shape and bool(torch.isfinite(f3).all())
+
+
+def test_complex_torch_tensors_stay_on_device(oracle, device):
+    """C12 as a complex64 ROCm tensor: split into C12__re / C12__im on the device
+    (nd/change.py:59 / nd/io.py:26-69 for device-resident data)."""
+    import torch
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    planes = synth.omnibus_stack(seed=15, k=7, ny=10, nx=12, dtype=np.float32, change_frac=0.3)
+    ds = xr_lite.Dataset()
+    ds['C11'] = (('time', 'y', 'x'), torch.from_numpy(planes[0]).to(device))
+    ds['C12'] = (('time', 'y', 'x'), torch.complex(torch.from_numpy(planes[1]), torch.from_numpy(planes[2])).to(device))
+    ds['C22'] = (('time', 'y', 'x'), torch.from_numpy(planes[3]).to(device))
+    ch = OmnibusTest(n=9, alpha=0.9).apply(ds)
+    assert ch.values.is_cuda
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    np.testing.assert_array_equal(ch.values.cpu().numpy(), oracle.change_detection_planes(yxt, 0.9, 9).astype(bool))

@@ -46,18 +46,16 @@ def build_variant(name, patches, extra=()):
     subprocess.check_call([HIPCC] + FLAGS + list(extra) + ['-shared', '-o', so] + srcs)
     return so
 
-NT_LOAD = [("__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0)", "__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 2)")]
-ZF_OLD = "        for (int i = tid; i < nvec; i += kGlobalThreads) vz[i] = make_uint4(0u, 0u, 0u, 0u);"
-ZF_NT = """        for (int i = tid; i < nvec; i += kGlobalThreads) {
-            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-            u4 zz = {0u, 0u, 0u, 0u};
-            __builtin_nontemporal_store(zz, reinterpret_cast<u4 *>(vz + i));
-        }"""
+LISTC = """    if (__any(flag)) {
+        const unsigned long long m = __ballot(flag);
+        const unsigned shard = (unsigned)(b % kShards);"""
 VARIANTS = {
     'base': [],
-    'nt_load': NT_LOAD,
-    'nt_zero': [(ZF_OLD, ZF_NT)],
-    'nt_both': NT_LOAD + [(ZF_OLD, ZF_NT)],
+    'nozero': [("        for (int i = tid; i < nvec; i += kGlobalThreads) store_zero16_nt(vz + i);", "        if (nvec < 0) store_zero16_nt(vz);")],
+    'nolist': [(LISTC, """    if (__any(flag) && g.k > 1000) {
+        const unsigned long long m = __ballot(flag);
+        const unsigned shard = (unsigned)(b % kShards);""")],
+    'nodump': [("            if (slot < g.dump_cap) {\n                T *d = g.dump + ((int64_t)shard", "            if (slot < g.dump_cap && g.k > 1000) {\n                T *d = g.dump + ((int64_t)shard")],
 }
 
 if __name__ == '__main__':
