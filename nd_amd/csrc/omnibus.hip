@@ -29,120 +29,10 @@
 //
 // gsl_cdf_chisq_P(z, f) and (z, f+4) (nd/_change.pyx:147-148): f = (j-1) p^2 with p = 2 is a
 // multiple of 4, so a = f/2 = 2(j-1) is an integer and the regularised incomplete gamma
-// function has closed recurrences (see chisq_pair_int).
-#include <math.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <mutex>
-#include <vector>
-
-#include "common.hpp"
+// function has closed recurrences (chisq_pair in omnibus_common.hpp).
+#include "omnibus_common.hpp"
 
 namespace nd_amd {
-
-// ---- constants of one omnibus test over j matrices (host-computed in double) ------------
-struct OmniTabEntry {
-    double m2rho;    // -2.0 * (double)(T)rho(p, j, n)        nd/_change.pyx:75-76
-    double pklogk;   // (double)(p * j) * log((double)j)      nd/_change.pyx:74
-    double omega2;   // omega2(p, j, n, rho) from double rho  nd/_change.pyx:139
-    double lgam;     // lgamma(a + 1), a = f/2 = 2 (j - 1)
-    double zlo;      // fast-reject bound: z < zlo  =>  P <= alpha for certain (see omni_zlo)
-    double zlo_a;    // the same bound for z_approx (hardware f32 log2), widened by its error
-    double zhi;      // fast-accept bound: zhi < z < inf  =>  P > alpha for certain
-    double zhi_a;    // the same for z_approx
-};
-
-constexpr int kTabArgs = 96;   // largest k whose table travels as a kernel argument
-struct OmniTab {
-    OmniTabEntry e[kTabArgs + 1];
-};
-
-// 1/m for the incomplete-gamma recurrences
-constexpr int kInvTab = 2048;
-struct InvTab {
-    double v[kInvTab];
-    constexpr InvTab() : v()
-    {
-        v[0] = 0.0;
-        for (int i = 1; i < kInvTab; ++i) v[i] = 1.0 / (double)i;
-    }
-};
-__constant__ InvTab c_inv = InvTab();
-
-__device__ __forceinline__ double inv_int(int m)
-{
-    return m < kInvTab ? c_inv.v[m] : 1.0 / (double)m;
-}
-
-// P1 = P(a, z/2), P2 = P(a + 2, z/2) for integer a >= 0, N values in lockstep.
-//   t_a = x^a e^-x / a!
-//   x <  a+1 :  P(a,x) = t_a * sum_{n>=0} x^n / ((a+1)...(a+n)),  P(a+2,x) = t_a * sum_{n>=2} ...
-//   x >= a+1 :  Q(a,x) = t_{a-1} * sum_{m=0}^{a-1} (a-1)...(a-m) / x^m,  Q(a+2,x) = Q(a,x) + t_a + t_{a+1}
-// Both sums have decreasing positive terms; one loop serves both.
-template <int N>
-__device__ __forceinline__ void chisq_pair_int(const double (&z)[N], int a, double lgam_a1,
-                                               double (&P1)[N], double (&P2)[N])
-{
-    double x[N], ta[N], rx[N], u1[N], term[N], sum[N];
-    bool lower[N], ok[N];
-    const double ap1 = (double)(a + 1);
-    const double inv_ap1 = inv_int(a + 1);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        ok[i] = (z[i] > 0.0) && (z[i] < INFINITY);
-        x[i] = ok[i] ? 0.5 * z[i] : 1.0;
-        lower[i] = x[i] < ap1;
-        ta[i] = exp(fma((double)a, log(x[i]), -x[i]) - lgam_a1);
-        rx[i] = 1.0 / x[i];
-        u1[i] = x[i] * inv_ap1;
-        term[i] = lower[i] ? u1[i] : 1.0;
-        sum[i] = lower[i] ? 0.0 : 1.0;
-    }
-    // four terms per trip; the reciprocals of the next trip are fetched while this one computes
-    double inv_cur[4], inv_nxt[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) inv_cur[u] = inv_int(a + 2 + u);
-    for (int n = 1; n < 4000000; n += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) inv_nxt[u] = inv_int(a + 6 + n - 1 + u);
-        bool more = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int d = a - (n + u);
-            const double up = (double)(d > 0 ? d : 0);
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const double ratio = lower[i] ? x[i] * inv_cur[u] : up * rx[i];
-                term[i] = term[i] * ratio;
-                sum[i] = sum[i] + term[i];
-                if (u == 3) more = more || (term[i] > 1e-17 * sum[i]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) inv_cur[u] = inv_nxt[u];
-        if (!__any(more)) break;
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double p1, p2;
-        if (lower[i]) {
-            p1 = ta[i] * ((1.0 + u1[i]) + sum[i]);
-            p2 = ta[i] * sum[i];
-        } else {
-            const double qa = (ta[i] * (double)a * rx[i]) * sum[i];
-            p1 = 1.0 - qa;
-            p2 = 1.0 - (qa + ta[i] + ta[i] * u1[i]);
-        }
-        if (!ok[i]) {
-            // gsl_cdf_chisq_P: x <= 0 -> 0; NaN stays NaN; +inf -> NaN (inf - inf inside GSL's
-            // large-x branch; DESIGN.md "Residual risks")
-            p1 = p2 = (z[i] <= 0.0) ? 0.0 : NAN;
-        }
-        P1[i] = p1;
-        P2[i] = p2;
-    }
-}
 
 // ---- the reference's running state (nd/_change.pyx:53-69) -------------------------------
 template <typename T>
@@ -178,18 +68,8 @@ __device__ __forceinline__ T z_stat(const Accum<T> &A, int j, double nlooks, con
     return (T)(e.m2rho * logQ);
 }
 
-// Cheap stand-in for z_stat used only to screen: ln x = (exponent + log2(mantissa)) ln 2 with the
-// mantissa's log2 from the hardware v_log_f32 (1 ulp on [0.5, 1), i.e. <= 6e-8 absolute).  NaN,
-// +-inf and zero arguments propagate exactly as in the double evaluation, so z_approx is NaN or
-// infinite precisely when z is.  |z_approx - z| <= |m2rho| n (k+1) 1e-7; the host widens zlo_a by
-// ten times that (omni tables), so z_approx < zlo_a implies z < zlo.
-__device__ __forceinline__ double approx_ln(double x)
-{
-    int e;
-    const double m = frexp(x, &e);
-    return ((double)e + (double)__log2f((float)m)) * 0.6931471805599453;
-}
-
+// Screen statistic: z from approx_ln.  |z_approx - z| <= |m2rho| n (k+1) 1e-7; the host widens
+// zlo_a / zhi_a by ten times that, so z_approx < zlo_a implies z < zlo (omni tables).
 template <typename T>
 __device__ __forceinline__ double z_approx(const Accum<T> &A, int j, double nlooks,
                                            const OmniTabEntry &e)
@@ -198,15 +78,6 @@ __device__ __forceinline__ double z_approx(const Accum<T> &A, int j, double nloo
     const double logQ = nlooks * ((e.pklogk + approx_ln(A.prod)) -
                                   ((double)j * approx_ln((double)det_of_sum)));
     return e.m2rho * logQ;
-}
-
-// P = P1 + omega2 (P2 - P1) with the reference's rounding points (nd/_change.c:6087-6089)
-template <typename T>
-__device__ __forceinline__ T combine_P(double P1, double P2, double omega2)
-{
-    const T p1 = (T)P1, p2 = (T)P2;
-    const T d = p2 - p1;
-    return (T)((double)p1 + (omega2 * (double)d));
 }
 
 // The input planes are read exactly once and the change map is written once: both bypass the
@@ -377,7 +248,7 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
         double zd[PPT], P1[PPT], P2[PPT];
 #pragma unroll
         for (int i = 0; i < PPT; ++i) zd[i] = (double)z[i];
-        chisq_pair_int<PPT>(zd, 2 * (k - 1), g.e.lgam, P1, P2);
+        chisq_pair<PPT>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             P[i] = combine_P<T>(P1[i], P2[i], g.e.omega2);
@@ -502,7 +373,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     if (STATS) {
         const T z = z_stat<T>(A, k, g.nlooks, g.e);
         double zd[1] = {(double)z}, P1[1], P2[1];
-        chisq_pair_int<1>(zd, 2 * (k - 1), g.e.lgam, P1, P2);
+        chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
         const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
         flag = in && ((double)P > g.alpha);
         if (in) {
@@ -707,7 +578,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     }
                     if (verdict == 2) {
                         double zd[1] = {(double)zp}, P1[1], P2[1];
-                        chisq_pair_int<1>(zd, 2 * (jj - 1), e.lgam, P1, P2);
+                        chisq_pair<1>(zd, 4 * (jj - 1), e.lgam, P1, P2);
                         const T P = combine_P<T>(P1[0], P2[0], e.omega2);
                         verdict = ((double)P > s.alpha) ? 1 : 0;
                     }
@@ -741,176 +612,36 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
 // =========================================================================================
 // host side
 // =========================================================================================
-static double host_rho(double p, double k, double n)
+std::vector<OmniTabEntry> get_table_impl(int k, uint32_t n_looks, double alpha, int dtype, int pol)
 {
-    return (1.0 - ((((2.0 * (p * p)) - 1.0) / ((6.0 * (k - 1.0)) * p)) *
-                   ((k / n) - (1.0 / (n * k)))));
-}
-
-static double host_omega2(double p, double k, double n, double rho)
-{
-    return (((((p * p) * ((p * p) - 1.0)) / (24.0 * (rho * rho))) *
-             ((k / (n * n)) - (1.0 / ((n * k) * (n * k))))) -
-            ((((p * p) * (k - 1.0)) / 4.0) * ((1.0 - (1.0 / rho)) * (1.0 - (1.0 / rho)))));
-}
-
-// host twin of chisq_pair_int (N = 1, no table), used only to place the fast-reject bound
-static void host_chisq_pair(double z, int a, double lgam_a1, double *P1, double *P2)
-{
-    if (!(z > 0.0)) {
-        *P1 = *P2 = (z <= 0.0) ? 0.0 : NAN;
-        return;
-    }
-    if (!(z < INFINITY)) {
-        *P1 = *P2 = NAN;
-        return;
-    }
-    const double x = 0.5 * z;
-    const bool lower = x < (double)(a + 1);
-    const double ta = exp(((double)a * log(x) - x) - lgam_a1);
-    const double u1 = x / (double)(a + 1);
-    double term = lower ? u1 : 1.0, sum = lower ? 0.0 : 1.0;
-    for (int n = 1; n < 4000000; ++n) {
-        const int d = a - n;
-        const double ratio = lower ? x / (double)(a + 1 + n) : (double)(d > 0 ? d : 0) / x;
-        term *= ratio;
-        sum += term;
-        if (!(term > 1e-17 * sum)) break;
-    }
-    if (lower) {
-        *P1 = ta * ((1.0 + u1) + sum);
-        *P2 = ta * sum;
-    } else {
-        const double qa = (ta * (double)a / x) * sum;
-        *P1 = 1.0 - qa;
-        *P2 = 1.0 - (qa + ta + ta * u1);
-    }
-}
-
-// Decision bounds of the test over j matrices: every z' < zlo has P(z') <= alpha for certain and
-// every finite z' > zhi has P(z') > alpha for certain, so the chi-square pair is only needed for
-// zlo <= z <= zhi (and for z = +inf, whose P is NaN).
-//   P(z) = P1 + omega2 (P2 - P1) is non-decreasing in z when 0 <= omega2 <= 1 (a mixture of two
-//   chi-square CDFs).  The kernel's P differs from the exact one by the roundings to T of P1, P2,
-//   their difference and the result, plus ~1e-13 from the series: bounded by `margin` below.
-//   zlo = the z where the exact P equals alpha - margin, stepped down by 1e-9 relative;
-//   zhi = the z where it equals alpha + margin, stepped up by 1e-9 relative.
-//   Outside 0 <= omega2 <= 1 (e.g. n = 1, small j), or when a target leaves (0, 1), the bound is
-//   -inf / +inf: every non-NaN z is evaluated exactly.
-template <typename T>
-static void omni_bounds(int j, double omega2, double lgam, double alpha, double *zlo, double *zhi)
-{
-    *zlo = -INFINITY;    // evaluate everything exactly
-    *zhi = INFINITY;     // never accept without evaluating
-    if (j < 2) return;
-    if (!(omega2 >= 0.0 && omega2 <= 1.0) || !(alpha == alpha)) return;
-    const double ulp = sizeof(T) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
-    const double margin = 16.0 * ulp * (1.0 + 2.0 * omega2) + 1e-11;
-    const int a = 2 * (j - 1);
-    auto Pz = [&](double z) {
-        double p1, p2;
-        host_chisq_pair(z, a, lgam, &p1, &p2);
-        return p1 + omega2 * (p2 - p1);
-    };
-    // smallest z (to 1e-15 relative) with exact P(z) >= target, as a bracketing pair lo < hi
-    auto quantile = [&](double target, double *lo_out, double *hi_out) -> bool {
-        double lo = 0.0, hi = 4.0 * (double)a + 64.0;
-        int guard = 0;
-        while (Pz(hi) < target && guard++ < 64) hi *= 2.0;
-        if (guard >= 64) return false;
-        for (int it = 0; it < 200; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (Pz(mid) < target)
-                lo = mid;
-            else
-                hi = mid;
-            if (hi - lo <= 1e-15 * hi) break;
-        }
-        *lo_out = lo;
-        *hi_out = hi;
-        return true;
-    };
-    double lo, hi;
-    const double tlo = alpha - margin;
-    if (tlo >= 1.0) {
-        *zlo = INFINITY;                      // P <= 1 < alpha: nothing can fire
-    } else if (tlo >= 0.0) {
-        if (quantile(tlo, &lo, &hi))
-            *zlo = lo * (1.0 - 1e-9);
-        else
-            *zlo = INFINITY;                  // target unreachable in double
-    }
-    const double thi = alpha + margin;
-    if (thi > 0.0 && thi < 1.0 - 1e-9 && quantile(thi, &lo, &hi)) *zhi = hi * (1.0 + 1e-9);
-}
-
-template <typename T>
-static OmniTabEntry make_entry(int j, uint32_t n_looks, double alpha)
-{
-    OmniTabEntry e;
-    const double p = 2.0, k = (double)j, n = (double)n_looks;
-    const double rho = host_rho(p, k, n);
-    const T rho_t = (T)rho;
-    e.m2rho = -2.0 * (double)rho_t;
-    const T pk = (T)2 * (T)j;
-    e.pklogk = (double)pk * log(k);
-    e.omega2 = host_omega2(p, k, n, rho);
-    e.lgam = lgamma((double)(2 * (j - 1)) + 1.0);
-    // z = m2rho * logQ grows with -logQ only when rho > 0; otherwise keep the exact path
-    omni_bounds<T>(j, e.omega2, e.lgam, alpha, &e.zlo, &e.zhi);
-    // bounds for the f32-log2 screen: ten times its worst-case error outside [zlo, zhi]
-    const double aerr = 1e-6 * fabs(e.m2rho) * n * (k + 1.0);
-    e.zlo_a = (e.zlo > -INFINITY && e.zlo < INFINITY) ? e.zlo - (aerr + 1e-9 * fabs(e.zlo)) : e.zlo;
-    e.zhi_a = (e.zhi < INFINITY) ? e.zhi + (aerr + 1e-9 * fabs(e.zhi)) : INFINITY;
-    if (!(aerr == aerr) || !(aerr < INFINITY)) {   // rho is NaN/inf for j = 1: exact path only
-        e.zlo = e.zlo_a = -INFINITY;
-        e.zhi = e.zhi_a = INFINITY;
-    }
-    return e;
-}
-
-// small cache of per-call tables: they depend only on (k, n_looks, alpha, dtype)
-struct TabKey {
-    int k, dtype;
-    uint32_t n;
-    double alpha;
-};
-struct TabCacheEntry {
-    TabKey key;
-    std::vector<OmniTabEntry> tab;
-};
-static std::mutex g_tab_mu;
-static std::vector<TabCacheEntry> g_tab_cache;
-
-template <typename T>
-static std::vector<OmniTabEntry> get_table(int k, uint32_t n_looks, double alpha)
-{
-    const int dtype = sizeof(T) == 4 ? ND_AMD_F32 : ND_AMD_F64;
+    static std::mutex mu;
+    static std::vector<TabCacheEntry> cache;
     {
-        std::lock_guard<std::mutex> lk(g_tab_mu);
-        for (const auto &c : g_tab_cache)
-            if (c.key.k == k && c.key.dtype == dtype && c.key.n == n_looks &&
+        std::lock_guard<std::mutex> lk(mu);
+        for (const auto &c : cache)
+            if (c.key.k == k && c.key.dtype == dtype && c.key.pol == pol && c.key.n == n_looks &&
                 memcmp(&c.key.alpha, &alpha, sizeof(double)) == 0)
                 return c.tab;
     }
     std::vector<OmniTabEntry> tab((size_t)k + 1);
     memset(tab.data(), 0, tab.size() * sizeof(OmniTabEntry));
-    for (int j = 1; j <= k; ++j) tab[j] = make_entry<T>(j, n_looks, alpha);
+    for (int j = 1; j <= k; ++j)
+        tab[j] = dtype == ND_AMD_F32 ? make_entry<float>(j, n_looks, alpha, pol)
+                                     : make_entry<double>(j, n_looks, alpha, pol);
     {
-        std::lock_guard<std::mutex> lk(g_tab_mu);
-        if (g_tab_cache.size() >= 32) g_tab_cache.erase(g_tab_cache.begin());
+        std::lock_guard<std::mutex> lk(mu);
+        if (cache.size() >= 32) cache.erase(cache.begin());
         TabCacheEntry c;
         c.key.k = k;
         c.key.dtype = dtype;
+        c.key.pol = pol;
         c.key.n = n_looks;
         c.key.alpha = alpha;
         c.tab = tab;
-        g_tab_cache.push_back(c);
+        cache.push_back(c);
     }
     return tab;
 }
-
-static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // workspace: [counter][per-j table][pixel list: npix x u32][dump: cap x k x 4 x T]
 // `min_total` is what the call needs; everything beyond it is used as dump capacity.  The
@@ -1032,7 +763,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     uint32_t *flag_idx = reinterpret_cast<uint32_t *>(ws + w.off_idx);
 
     // per-j constants (host, double, same expression order as nd/_change.c:2926-2975)
-    const std::vector<OmniTabEntry> htab = get_table<T>((int)k, n_looks, alpha);
+    const std::vector<OmniTabEntry> htab = get_table<T>((int)k, n_looks, alpha, 2);
     OmniTab tab;
     memset(&tab, 0, sizeof(tab));
     const bool tab_in_args = (k <= kTabArgs);

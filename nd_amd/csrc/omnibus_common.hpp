@@ -1,0 +1,305 @@
+// nd_amd/csrc/omnibus_common.hpp -- pieces shared by the dual-pol (omnibus.hip) and full-pol
+// (omnibus_c3.hip) omnibus kernels: the per-test constant table, the chi-square pair, the
+// approximate logarithm of the screen, and the host code that builds the table (rho, omega2,
+// decision bounds).  p = 2 follows nd/_change.pyx:20-39, 133-151 to the letter; p = 3 is the same
+// formulas with p = 3 (the reference hard-codes p = 2, nd/_change.pyx:51,99,135).
+#pragma once
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace nd_amd {
+
+// ---- constants of one omnibus test over j matrices (host-computed in double) ------------
+struct OmniTabEntry {
+    double m2rho;    // -2.0 * (double)(T)rho(p, j, n)        nd/_change.pyx:75-76
+    double pklogk;   // (double)(p * j) * log((double)j)      nd/_change.pyx:74
+    double omega2;   // omega2(p, j, n, rho) from double rho  nd/_change.pyx:139
+    double lgam;     // lgamma(a + 1), a = f/2 = (j - 1) p^2 / 2
+    double zlo;      // fast-reject bound: z < zlo  =>  P <= alpha for certain (see omni_bounds)
+    double zlo_a;    // the same bound for z_approx (hardware f32 log2), widened by its error
+    double zhi;      // fast-accept bound: zhi < z < inf  =>  P > alpha for certain
+    double zhi_a;    // the same for z_approx
+};
+
+constexpr int kTabArgs = 96;   // largest k whose table travels as a kernel argument
+struct OmniTab {
+    OmniTabEntry e[kTabArgs + 1];
+};
+
+// 2/m, i.e. the reciprocal of the (half-)integer m/2, for the incomplete-gamma recurrences.
+// For even m this is bit-for-bit 1/(m/2).
+constexpr int kInvTab = 4096;
+struct InvTab {
+    double v[kInvTab];
+    constexpr InvTab() : v()
+    {
+        v[0] = 0.0;
+        for (int i = 1; i < kInvTab; ++i) v[i] = 2.0 / (double)i;
+    }
+};
+static __constant__ InvTab c_inv2 = InvTab();
+
+__device__ __forceinline__ double inv_half(int m2)   // 1 / (m2 / 2)
+{
+    return m2 < kInvTab ? c_inv2.v[m2] : 2.0 / (double)m2;
+}
+
+// P1 = P(a, z/2), P2 = P(a + 2, z/2) for a = a2/2 (integer or half-integer), N values in lockstep.
+//   t_a = x^a e^-x / Gamma(a+1)
+//   x <  a+1 :  P(a,x) = t_a * sum_{n>=0} x^n / ((a+1)...(a+n)),  P(a+2,x) = t_a * sum_{n>=2} ...
+//   x >= a+1 :  Q(a,x) = t_{a-1} * sum_m (a-1)...(a-m) / x^m  over the factors >= 1
+//               (+ erfc(sqrt x) when a is a half-integer),     Q(a+2,x) = Q(a,x) + t_a + t_{a+1}
+// Both sums have decreasing positive terms; one loop serves both, four terms per trip, the
+// reciprocals of the next trip fetched while this one computes.
+// a2 = 4 (j-1) for dual pol (a integer: the gsl_cdf_chisq_P(z, f), (z, f+4) pair of
+// nd/_change.pyx:147-148), 9 (j-1) for full pol.
+template <int N>
+__device__ __forceinline__ void chisq_pair(const double (&z)[N], int a2, double lgam_a1,
+                                           double (&P1)[N], double (&P2)[N])
+{
+    double x[N], ta[N], rx[N], u1[N], term[N], sum[N];
+    bool lower[N], ok[N];
+    const double a = 0.5 * (double)a2;
+    const double ap1 = a + 1.0;
+    const double inv_ap1 = inv_half(a2 + 2);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ok[i] = (z[i] > 0.0) && (z[i] < INFINITY);
+        x[i] = ok[i] ? 0.5 * z[i] : 1.0;
+        lower[i] = x[i] < ap1;
+        ta[i] = exp(fma(a, log(x[i]), -x[i]) - lgam_a1);
+        rx[i] = 1.0 / x[i];
+        u1[i] = x[i] * inv_ap1;
+        term[i] = lower[i] ? u1[i] : 1.0;
+        sum[i] = lower[i] ? 0.0 : 1.0;
+    }
+    double inv_cur[4], inv_nxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) inv_cur[u] = inv_half(a2 + 4 + 2 * u);
+    for (int n = 1; n < 4000000; n += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) inv_nxt[u] = inv_half(a2 + 2 * (n + 4 + u) + 2);
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d2 = a2 - 2 * (n + u);                 // 2 (a - m)
+            const double up = d2 >= 2 ? 0.5 * (double)d2 : 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double ratio = lower[i] ? x[i] * inv_cur[u] : up * rx[i];
+                term[i] = term[i] * ratio;
+                sum[i] = sum[i] + term[i];
+                if (u == 3) more = more || (term[i] > 1e-17 * sum[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) inv_cur[u] = inv_nxt[u];
+        if (!__any(more)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double p1, p2;
+        if (lower[i]) {
+            p1 = ta[i] * ((1.0 + u1[i]) + sum[i]);
+            p2 = ta[i] * sum[i];
+        } else {
+            double qa = (ta[i] * a * rx[i]) * sum[i];
+            if (a2 & 1) qa = qa + erfc(sqrt(x[i]));
+            p1 = 1.0 - qa;
+            p2 = 1.0 - (qa + ta[i] + ta[i] * u1[i]);
+        }
+        if (!ok[i]) {
+            // gsl_cdf_chisq_P: x <= 0 -> 0; NaN stays NaN; +inf -> NaN (inf - inf inside GSL's
+            // large-x branch; DESIGN.md "Residual risks")
+            p1 = p2 = (z[i] <= 0.0) ? 0.0 : NAN;
+        }
+        P1[i] = p1;
+        P2[i] = p2;
+    }
+}
+
+// Cheap stand-in for ln used only to screen: ln x = (exponent + log2(mantissa)) ln 2 with the
+// mantissa's log2 from the hardware v_log_f32 (1 ulp on [0.5, 1), i.e. <= 6e-8 absolute).  NaN,
+// +-inf and zero arguments propagate exactly as in the double evaluation, so an approximate z is
+// NaN or infinite precisely when the exact one is.
+__device__ __forceinline__ double approx_ln(double x)
+{
+    int e;
+    const double m = frexp(x, &e);
+    return ((double)e + (double)__log2f((float)m)) * 0.6931471805599453;
+}
+
+// P = P1 + omega2 (P2 - P1) with the reference's rounding points (nd/_change.c:6087-6089)
+template <typename T>
+__device__ __forceinline__ T combine_P(double P1, double P2, double omega2)
+{
+    const T p1 = (T)P1, p2 = (T)P2;
+    const T d = p2 - p1;
+    return (T)((double)p1 + (omega2 * (double)d));
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+static inline double host_rho(double p, double k, double n)
+{
+    return (1.0 - ((((2.0 * (p * p)) - 1.0) / ((6.0 * (k - 1.0)) * p)) *
+                   ((k / n) - (1.0 / (n * k)))));
+}
+
+static inline double host_omega2(double p, double k, double n, double rho)
+{
+    return (((((p * p) * ((p * p) - 1.0)) / (24.0 * (rho * rho))) *
+             ((k / (n * n)) - (1.0 / ((n * k) * (n * k))))) -
+            ((((p * p) * (k - 1.0)) / 4.0) * ((1.0 - (1.0 / rho)) * (1.0 - (1.0 / rho)))));
+}
+
+// host twin of chisq_pair (N = 1, no table), used only to place the decision bounds
+static inline void host_chisq_pair(double z, int a2, double lgam_a1, double *P1, double *P2)
+{
+    if (!(z > 0.0)) {
+        *P1 = *P2 = (z <= 0.0) ? 0.0 : NAN;
+        return;
+    }
+    if (!(z < INFINITY)) {
+        *P1 = *P2 = NAN;
+        return;
+    }
+    const double a = 0.5 * (double)a2;
+    const double x = 0.5 * z;
+    const bool lower = x < a + 1.0;
+    const double ta = exp((a * log(x) - x) - lgam_a1);
+    const double u1 = x / (a + 1.0);
+    double term = lower ? u1 : 1.0, sum = lower ? 0.0 : 1.0;
+    for (int n = 1; n < 4000000; ++n) {
+        const int d2 = a2 - 2 * n;
+        const double ratio = lower ? x / (a + 1.0 + (double)n) : (d2 >= 2 ? 0.5 * (double)d2 : 0.0) / x;
+        term *= ratio;
+        sum += term;
+        if (!(term > 1e-17 * sum)) break;
+    }
+    if (lower) {
+        *P1 = ta * ((1.0 + u1) + sum);
+        *P2 = ta * sum;
+    } else {
+        double qa = (ta * a / x) * sum;
+        if (a2 & 1) qa += erfc(sqrt(x));
+        *P1 = 1.0 - qa;
+        *P2 = 1.0 - (qa + ta + ta * u1);
+    }
+}
+
+// Decision bounds of the test over j matrices: every z' < zlo has P(z') <= alpha for certain and
+// every finite z' > zhi has P(z') > alpha for certain, so the chi-square pair is only needed for
+// zlo <= z <= zhi (and for z = +inf, whose P is NaN).
+//   P(z) = P1 + omega2 (P2 - P1) is non-decreasing in z when 0 <= omega2 <= 1 (a mixture of two
+//   chi-square CDFs).  The kernel's P differs from the exact one by the roundings to T of P1, P2,
+//   their difference and the result, plus ~1e-13 from the series: bounded by `margin` below.
+//   zlo = the z where the exact P equals alpha - margin, stepped down by 1e-9 relative;
+//   zhi = the z where it equals alpha + margin, stepped up by 1e-9 relative.
+//   Outside 0 <= omega2 <= 1 (e.g. n = 1, small j), or when a target leaves (0, 1), the bound is
+//   -inf / +inf: every non-NaN z is evaluated exactly.
+template <typename T>
+static void omni_bounds(int j, int a2, double omega2, double lgam, double alpha, double *zlo,
+                        double *zhi)
+{
+    *zlo = -INFINITY;    // evaluate everything exactly
+    *zhi = INFINITY;     // never accept without evaluating
+    if (j < 2) return;
+    if (!(omega2 >= 0.0 && omega2 <= 1.0) || !(alpha == alpha)) return;
+    const double ulp = sizeof(T) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
+    const double margin = 16.0 * ulp * (1.0 + 2.0 * omega2) + 1e-11;
+    auto Pz = [&](double z) {
+        double p1, p2;
+        host_chisq_pair(z, a2, lgam, &p1, &p2);
+        return p1 + omega2 * (p2 - p1);
+    };
+    // smallest z (to 1e-15 relative) with exact P(z) >= target, as a bracketing pair lo < hi
+    auto quantile = [&](double target, double *lo_out, double *hi_out) -> bool {
+        double lo = 0.0, hi = 2.0 * (double)a2 + 64.0;
+        int guard = 0;
+        while (Pz(hi) < target && guard++ < 64) hi *= 2.0;
+        if (guard >= 64) return false;
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (Pz(mid) < target)
+                lo = mid;
+            else
+                hi = mid;
+            if (hi - lo <= 1e-15 * hi) break;
+        }
+        *lo_out = lo;
+        *hi_out = hi;
+        return true;
+    };
+    double lo, hi;
+    const double tlo = alpha - margin;
+    if (tlo >= 1.0) {
+        *zlo = INFINITY;                      // P <= 1 < alpha: nothing can fire
+    } else if (tlo >= 0.0) {
+        if (quantile(tlo, &lo, &hi))
+            *zlo = lo * (1.0 - 1e-9);
+        else
+            *zlo = INFINITY;                  // target unreachable in double
+    }
+    const double thi = alpha + margin;
+    if (thi > 0.0 && thi < 1.0 - 1e-9 && quantile(thi, &lo, &hi)) *zhi = hi * (1.0 + 1e-9);
+}
+
+// a2 = 2a = f = (j - 1) p^2
+static inline int omni_a2(int j, int p) { return (j - 1) * p * p; }
+
+template <typename T>
+static OmniTabEntry make_entry(int j, uint32_t n_looks, double alpha, int pol)
+{
+    OmniTabEntry e;
+    const double p = (double)pol, k = (double)j, n = (double)n_looks;
+    const double rho = host_rho(p, k, n);
+    const T rho_t = (T)rho;
+    e.m2rho = -2.0 * (double)rho_t;
+    const T pk = (T)pol * (T)j;                       // `p * k` in `floating`, nd/_change.c:3580
+    e.pklogk = (double)pk * log(k);
+    e.omega2 = host_omega2(p, k, n, rho);
+    const int a2 = omni_a2(j, pol);
+    e.lgam = lgamma(0.5 * (double)a2 + 1.0);
+    omni_bounds<T>(j, a2, e.omega2, e.lgam, alpha, &e.zlo, &e.zhi);
+    // bounds for the f32-log2 screen: ten times its worst-case error outside [zlo, zhi]
+    // (|z_approx - z| <= |m2rho| n (j + 1) 1e-7)
+    const double aerr = 1e-6 * fabs(e.m2rho) * n * (k + 1.0);
+    e.zlo_a = (e.zlo > -INFINITY && e.zlo < INFINITY) ? e.zlo - (aerr + 1e-9 * fabs(e.zlo)) : e.zlo;
+    e.zhi_a = (e.zhi < INFINITY) ? e.zhi + (aerr + 1e-9 * fabs(e.zhi)) : INFINITY;
+    if (!(aerr == aerr) || !(aerr < INFINITY)) {   // rho is NaN/inf for j = 1: exact path only
+        e.zlo = e.zlo_a = -INFINITY;
+        e.zhi = e.zhi_a = INFINITY;
+    }
+    return e;
+}
+
+// small cache of per-call tables: they depend only on (k, n_looks, alpha, dtype, p)
+struct TabKey {
+    int k, dtype, pol;
+    uint32_t n;
+    double alpha;
+};
+struct TabCacheEntry {
+    TabKey key;
+    std::vector<OmniTabEntry> tab;
+};
+std::vector<OmniTabEntry> get_table_impl(int k, uint32_t n_looks, double alpha, int dtype, int pol);
+
+template <typename T>
+static std::vector<OmniTabEntry> get_table(int k, uint32_t n_looks, double alpha, int pol)
+{
+    return get_table_impl(k, n_looks, alpha, sizeof(T) == 4 ? ND_AMD_F32 : ND_AMD_F64, pol);
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace nd_amd
