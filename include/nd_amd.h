@@ -96,6 +96,25 @@ int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void *c12im,
                       void *hip_stream);
 
 /* ------------------------------------------------------------------------
+ * OmnibusTest, full-pol C3 (3 x 3 complex Hermitian) -- EXTENSION.
+ * The reference has no full-pol implementation (p = 2 is hard-coded,
+ * nd/_change.pyx:51, 99, 135); this is the same algorithm with p = 3 and the
+ * generic `_f`, `_rho`, `_omega2` of nd/_change.pyx:20-39 (BASELINE.json
+ * config "OmnibusTest full-pol C3").  planes[9], all with the same element
+ * strides: C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im.
+ * Everything else as nd_amd_omnibus_c2; k <= 96.
+ * ---------------------------------------------------------------------- */
+size_t nd_amd_omnibus_c3_workspace_bytes(int64_t ny, int64_t nx, int64_t k);
+
+int nd_amd_omnibus_c3(const void *const planes[9], int dtype,
+                      int64_t ny, int64_t nx, int64_t k,
+                      int64_t stride_y, int64_t stride_x, int64_t stride_t,
+                      uint32_t n_looks, double alpha,
+                      uint8_t *change, void *z_out, void *p_out,
+                      void *workspace, size_t workspace_bytes,
+                      void *hip_stream);
+
+/* ------------------------------------------------------------------------
  * Kernel convolution / boxcar.
  * Replaces  scipy.ndimage.convolve(arr, nd_kernel, output=output, **kwargs)
  *           as called at nd/filters.py:256-267 (scipy is the reference's

@@ -1,0 +1,422 @@
+// nd_amd/csrc/omnibus_c3.hip -- OmnibusTest for full-pol (3 x 3 complex Hermitian) covariance
+// stacks on gfx950: BASELINE.json config "OmnibusTest full-pol C3, 48t x 8192 x 8192".
+//
+// EXTENSION: the reference implements dual pol only (p = 2 is hard-coded, nd/_change.pyx:51, 99,
+// 135).  This applies the same algorithm (nd/_change.pyx:46-77, 133-151, 224-257) with p = 3: the
+// generic formulas `_f`, `_rho`, `_omega2` (nd/_change.pyx:20-39), the same rounding points, and
+// det C = abc - a|z|^2 - b|y|^2 - c|x|^2 + 2 Re(x z conj(y)) evaluated left to right in `floating`.
+// There is no reference implementation to compare with: parity is pinned only against this
+// repository's own generic-p oracle (oracle/nd_oracle_impl.h) -- DESIGN.md marks it UNPINNED.
+//
+// Planes (all sharing one set of element strides):
+//   [C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im]
+// 1728 B per pixel at k = 48 float32: no register retention; pass A streams the planes in chunks
+// of dates (4-byte non-temporal loads, one pixel per thread, coalesced along x), screens
+// z_approx against the host bound and lists the pixels that can fire; pass B gathers a listed
+// pixel's series (LDS-staged when it fits) and runs the same one-sweep-per-segment search as the
+// dual-pol kernel.  f = 9 (j-1) is odd for even j, so a = f/2 can be a half-integer: the
+// chi-square pair handles both (omnibus_common.hpp).
+#include "omnibus_common.hpp"
+
+namespace nd_amd {
+
+constexpr int kC3Threads = 256;
+constexpr int kC3Shards = 128;
+constexpr int kC3CounterStride = 32;
+constexpr int kC3Chunk = 4;          // dates per load chunk in pass A
+constexpr size_t kC3CounterBytes = (size_t)kC3Shards * kC3CounterStride * sizeof(uint32_t);
+
+template <typename T>
+__device__ __forceinline__ T det3(const T (&v)[9])
+{
+    const T a = v[0], b = v[1], c = v[2];
+    const T xr = v[3], xi = v[4], yr = v[5], yi = v[6], zr = v[7], zi = v[8];
+    const T re = (((xr * zr) - (xi * zi)) * yr) + (((xr * zi) + (xi * zr)) * yi);
+    return (((((a * b) * c) - (a * ((zr * zr) + (zi * zi)))) - (b * ((yr * yr) + (yi * yi)))) -
+            (c * ((xr * xr) + (xi * xi)))) +
+           ((T)2 * re);
+}
+
+template <typename T>
+struct Accum3 {
+    T s[9];
+    double prod;
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) s[c] = 0;
+        prod = 1.0;
+    }
+    __device__ __forceinline__ void step(const T (&v)[9])
+    {
+        prod = prod * (double)det3<T>(v);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) s[c] = s[c] + v[c];
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ T z_stat3(const Accum3<T> &A, int j, double nlooks, const OmniTabEntry &e)
+{
+    const T det_of_sum = det3<T>(A.s);
+    const double logQ =
+        nlooks * ((e.pklogk + log(A.prod)) - ((double)j * log((double)det_of_sum)));
+    return (T)(e.m2rho * logQ);
+}
+
+template <typename T>
+__device__ __forceinline__ double z_approx3(const Accum3<T> &A, int j, double nlooks,
+                                            const OmniTabEntry &e)
+{
+    const T det_of_sum = det3<T>(A.s);
+    const double logQ = nlooks * ((e.pklogk + approx_ln(A.prod)) -
+                                  ((double)j * approx_ln((double)det_of_sum)));
+    return e.m2rho * logQ;
+}
+
+template <typename T>
+struct C3Args {
+    const T *pl[9];
+    int64_t nx, nrows, sy, sx, st, blocks_per_row;
+    int64_t nx_orig;          // pixels per row of the raster (list entries are y * nx_orig + x)
+    int k, write_tab;
+    double nlooks, alpha;
+    OmniTabEntry e;
+    uint8_t *change;
+    T *z_out, *p_out;
+    uint32_t *flag_count, *flag_idx;
+    uint32_t seg;
+    OmniTabEntry *tab_dev;
+};
+
+// ---- pass A ---------------------------------------------------------------------------------
+template <typename T, bool STATS>
+__global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3Args<T> g,
+                                                                       const OmniTab tab)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kC3Threads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+
+    if (g.write_tab && b == 0)
+        for (int j = tid; j <= k; j += kC3Threads) g.tab_dev[j] = tab.e[j];
+
+    Accum3<T> A;
+    A.reset();
+    {
+        const int64_t xc = in ? x0 : g.nx - 1;
+        const int64_t off0 = row * g.sy + xc * g.sx;
+        for (int t0 = 0; t0 < k; t0 += kC3Chunk) {
+            T v[kC3Chunk][9];
+#pragma unroll
+            for (int tt = 0; tt < kC3Chunk; ++tt)
+                if (t0 + tt < k) {
+                    const int64_t off = off0 + (int64_t)(t0 + tt) * g.st;
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) v[tt][c] = __builtin_nontemporal_load(g.pl[c] + off);
+                }
+#pragma unroll
+            for (int tt = 0; tt < kC3Chunk; ++tt)
+                if (t0 + tt < k) A.step(v[tt]);
+        }
+    }
+
+    bool flag;
+    if (STATS) {
+        const T z = z_stat3<T>(A, k, g.nlooks, g.e);
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair<1>(zd, 9 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        flag = in && ((double)P > g.alpha);
+        if (in) {
+            const int64_t pix = row * g.nx + x0;
+            if (g.z_out) g.z_out[pix] = z;
+            if (g.p_out) g.p_out[pix] = P;
+        }
+    } else {
+        flag = in && (z_approx3<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
+    }
+
+    if (__any(flag)) {
+        const unsigned long long m = __ballot(flag);
+        const unsigned shard = (unsigned)(b % kC3Shards);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kC3CounterStride, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag)
+            g.flag_idx[(size_t)shard * g.seg + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] =
+                (uint32_t)(row * g.nx + x0);
+    }
+
+    // zero-fill this block's slice of the change map (issued last, never waited on)
+    {
+        const int64_t left = g.nx - bpx0;
+        const int npx = left > kC3Threads ? kC3Threads : (int)left;
+        uint8_t *ob = g.change + (row * g.nx + bpx0) * (int64_t)k;
+        const int nb = npx * k;
+        int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (tid < head) ob[tid] = 0;
+        const int nvec = (nb - head) >> 4;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        u4 *vz = reinterpret_cast<u4 *>(ob + head);
+        const u4 zero = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < nvec; i += kC3Threads) __builtin_nontemporal_store(zero, vz + i);
+        const int tail0 = head + (nvec << 4);
+        if (tail0 + tid < nb) ob[tail0 + tid] = 0;
+    }
+}
+
+// ---- pass B ---------------------------------------------------------------------------------
+template <typename T, bool USE_LDS>
+__global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem3[];
+    T *lds = reinterpret_cast<T *>(nd_smem3);
+    const int lane = threadIdx.x;
+    const int k = s.k;
+    const unsigned shard = blockIdx.x % kC3Shards;
+    const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
+    const uint32_t n = s.flag_count[shard * kC3CounterStride];
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+
+    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < n;
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+        const int64_t row = pix / s.nx_orig, col = pix - row * s.nx_orig;
+        const int64_t off = row * s.sy + col * s.sx;
+        if (USE_LDS) {
+            for (int t = 0; t < k; ++t) {
+                const int64_t o = off + (int64_t)t * s.st;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) lds[(t * 9 + c) * 64 + lane] = s.pl[c][o];
+            }
+        }
+        auto load_step = [&](Accum3<T> &A, int t) {
+            T v[9];
+            if (USE_LDS) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = lds[(t * 9 + c) * 64 + lane];
+            } else {
+                const int64_t o = off + (int64_t)t * s.st;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[c] = s.pl[c][o];
+            }
+            A.step(v);
+        };
+
+        // one sweep per segment, as in omnibus_c2_search_kernel (nd/_change.pyx:235-257)
+        Accum3<T> A;
+        A.reset();
+        int l = 0, t = 0, fire_at = -1;
+        bool done = !active;
+        uint8_t *res = s.change + pix * (int64_t)k;
+        while (__any(!done)) {
+            if (!done) {
+                load_step(A, t);
+                const int jj = t - l + 1;
+                const bool last = (t == k - 1);
+                const bool need = (jj >= 2) && (fire_at < 0 || last);
+                bool fires = false;
+                if (need) {
+                    const OmniTabEntry e = s.tab_dev[jj];
+                    const double za = z_approx3<T>(A, jj, s.nlooks, e);
+                    int verdict = 0;
+                    T zp = 0;
+                    if (za >= e.zlo_a) {
+                        verdict = 1;
+                        if (!(za > e.zhi_a && za < INFINITY)) {
+                            zp = z_stat3<T>(A, jj, s.nlooks, e);
+                            const double zd = (double)zp;
+                            verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                        }
+                    }
+                    if (verdict == 2) {
+                        double zd[1] = {(double)zp}, P1[1], P2[1];
+                        chisq_pair<1>(zd, 9 * (jj - 1), e.lgam, P1, P2);
+                        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                        verdict = ((double)P > s.alpha) ? 1 : 0;
+                    }
+                    fires = (verdict == 1);
+                }
+                if (fires && fire_at < 0) fire_at = t;
+                if (!last) {
+                    t = t + 1;
+                } else if (fires && jj >= 2) {
+                    res[fire_at] = 1;
+                    l = fire_at;
+                    if (l >= k - 1) {
+                        done = true;
+                    } else {
+                        A.reset();
+                        t = l;
+                        fire_at = -1;
+                    }
+                } else {
+                    done = true;
+                }
+            }
+        }
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------
+struct C3Workspace {
+    size_t off_count, off_tab, off_idx, total;
+    uint32_t seg;
+};
+
+static C3Workspace c3_layout(int64_t npix, int64_t ny, int64_t k)
+{
+    C3Workspace w;
+    const int64_t nb256 = ceil_div(npix, kC3Threads) + ny;
+    w.seg = (uint32_t)((ceil_div(nb256, kC3Shards) + 1) * kC3Threads);
+    w.off_count = 0;
+    w.off_tab = align256(kC3CounterBytes);
+    w.off_idx = w.off_tab + align256((size_t)(k + 1) * sizeof(OmniTabEntry));
+    w.total = w.off_idx + align256((size_t)w.seg * kC3Shards * sizeof(uint32_t));
+    return w;
+}
+
+template <typename T>
+static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, int64_t k,
+                           int64_t sy, int64_t sx, int64_t st, uint32_t n_looks, double alpha,
+                           uint8_t *change, void *z_out, void *p_out, void *workspace,
+                           size_t workspace_bytes, hipStream_t stream)
+{
+    const int64_t npix = ny * nx;
+    const C3Workspace w = c3_layout(npix, ny, k);
+    if (workspace == nullptr || workspace_bytes < w.total) {
+        set_error("nd_amd_omnibus_c3: workspace of %zu bytes needed, %zu given", w.total,
+                  workspace_bytes);
+        return ND_AMD_EWORKSPACE;
+    }
+    if (((uintptr_t)workspace & 255) != 0) {
+        set_error("nd_amd_omnibus_c3: workspace must be 256-byte aligned");
+        return ND_AMD_EINVAL;
+    }
+    if (k > kTabArgs) {
+        set_error("nd_amd_omnibus_c3: k = %lld exceeds the supported %d dates", (long long)k, kTabArgs);
+        return ND_AMD_EUNSUPPORTED;
+    }
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    const std::vector<OmniTabEntry> htab = get_table<T>((int)k, n_looks, alpha, 3);
+    OmniTab tab;
+    memset(&tab, 0, sizeof(tab));
+    memcpy(tab.e, htab.data(), htab.size() * sizeof(OmniTabEntry));
+
+    C3Args<T> g;
+    for (int c = 0; c < 9; ++c) g.pl[c] = static_cast<const T *>(planes[c]);
+    const bool flat = (sx == 1) && (sy == nx);
+    g.nx = flat ? npix : nx;
+    g.nrows = flat ? 1 : ny;
+    g.nx_orig = nx;
+    g.sy = sy;
+    g.sx = sx;
+    g.st = st;
+    g.blocks_per_row = ceil_div(g.nx, kC3Threads);
+    g.k = (int)k;
+    g.write_tab = 1;
+    g.nlooks = (double)n_looks;
+    g.alpha = alpha;
+    g.e = htab[(size_t)k];
+    g.change = change;
+    g.z_out = static_cast<T *>(z_out);
+    g.p_out = static_cast<T *>(p_out);
+    g.flag_count = reinterpret_cast<uint32_t *>(ws + w.off_count);
+    g.tab_dev = reinterpret_cast<OmniTabEntry *>(ws + w.off_tab);
+    g.flag_idx = reinterpret_cast<uint32_t *>(ws + w.off_idx);
+    g.seg = w.seg;
+    const int64_t nblocks = g.blocks_per_row * g.nrows;
+    if (nblocks > 0x7fffffffLL) {
+        set_error("nd_amd_omnibus_c3: raster too large for one launch");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    ND_HIP_CHECK(hipMemsetAsync(g.flag_count, 0, kC3CounterBytes, stream));
+    const bool stats = z_out != nullptr || p_out != nullptr;
+    {
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+        if (stats)
+            hipLaunchKernelGGL((omnibus_c3_global_kernel<T, true>), dim3((unsigned)nblocks),
+                               dim3(kC3Threads), 0, stream, g, tab);
+        else
+            hipLaunchKernelGGL((omnibus_c3_global_kernel<T, false>), dim3((unsigned)nblocks),
+                               dim3(kC3Threads), 0, stream, g, tab);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+
+    const size_t lds_bytes = (size_t)k * 9 * 64 * sizeof(T);
+    const bool use_lds = lds_bytes <= 64 * 1024;
+    int64_t per_shard = ceil_div(ceil_div(npix, kC3Shards), 64);
+    if (per_shard > 64) per_shard = 64;
+    if (per_shard < 1) per_shard = 1;
+    const int64_t sblocks = per_shard * kC3Shards;
+    {
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
+        if (use_lds)
+            hipLaunchKernelGGL((omnibus_c3_search_kernel<T, true>), dim3((unsigned)sblocks), dim3(64),
+                               lds_bytes, stream, g);
+        else
+            hipLaunchKernelGGL((omnibus_c3_search_kernel<T, false>), dim3((unsigned)sblocks),
+                               dim3(64), 0, stream, g);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+    return ND_AMD_OK;
+}
+
+}  // namespace nd_amd
+
+using namespace nd_amd;
+
+extern "C" size_t nd_amd_omnibus_c3_workspace_bytes(int64_t ny, int64_t nx, int64_t k)
+{
+    if (ny < 0 || nx < 0 || k < 0) return 0;
+    return c3_layout(ny * nx, ny, k).total;
+}
+
+extern "C" int nd_amd_omnibus_c3(const void *const planes[9], int dtype, int64_t ny, int64_t nx,
+                                 int64_t k, int64_t stride_y, int64_t stride_x, int64_t stride_t,
+                                 uint32_t n_looks, double alpha, uint8_t *change, void *z_out,
+                                 void *p_out, void *workspace, size_t workspace_bytes,
+                                 void *hip_stream)
+{
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_omnibus_c3: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (ny < 0 || nx < 0 || k < 0) {
+        set_error("nd_amd_omnibus_c3: negative shape");
+        return ND_AMD_EINVAL;
+    }
+    if (ny == 0 || nx == 0 || k == 0) return ND_AMD_OK;
+    if (!planes || !change) {
+        set_error("nd_amd_omnibus_c3: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    for (int c = 0; c < 9; ++c)
+        if (!planes[c]) {
+            set_error("nd_amd_omnibus_c3: plane %d is null", c);
+            return ND_AMD_EINVAL;
+        }
+    if (n_looks == 0) {
+        set_error("nd_amd_omnibus_c3: n_looks must be >= 1");
+        return ND_AMD_EINVAL;
+    }
+    if (ny * nx >= 0xffffffffLL) {
+        set_error("nd_amd_omnibus_c3: raster exceeds the 32-bit pixel index");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (dtype == ND_AMD_F32)
+        return omnibus_c3_impl<float>(planes, ny, nx, k, stride_y, stride_x, stride_t, n_looks, alpha,
+                                      change, z_out, p_out, workspace, workspace_bytes, stream);
+    return omnibus_c3_impl<double>(planes, ny, nx, k, stride_y, stride_x, stride_t, n_looks, alpha,
+                                   change, z_out, p_out, workspace, workspace_bytes, stream);
+}

@@ -85,6 +85,45 @@ def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x')
     return change
 
 
+def change_detection_c3(planes, alpha, n=1, dims=('time', 'y', 'x'), stats=False):
+    """Full-pol (3 x 3) omnibus change detection -- an extension, the reference is dual-pol only.
+    planes: nine CUDA tensors [C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im] of
+    identical shape/strides/dtype, axes named by `dims`.  Returns uint8 (y, x, time) [, z, P]."""
+    planes = list(planes)
+    if len(planes) != 9:
+        raise ValueError('full-pol covariance needs nine real planes')
+    p0 = planes[0]
+    for i, t in enumerate(planes):
+        _require_cuda(t, 'planes[%d]' % i)
+        if (t.dim() != 3 or t.shape != p0.shape or t.stride() != p0.stride()
+                or t.dtype != p0.dtype or t.device != p0.device):
+            raise ValueError('the nine covariance planes must be 3-D and share shape, strides, '
+                             'dtype and device')
+    dims = tuple(dims)
+    if sorted(dims) != ['time', 'x', 'y']:
+        raise ValueError("dims must be a permutation of ('time', 'y', 'x')")
+    ay, ax, at = dims.index('y'), dims.index('x'), dims.index('time')
+    ny, nx, k = p0.shape[ay], p0.shape[ax], p0.shape[at]
+    dev = p0.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        change = torch.empty((ny, nx, k), dtype=torch.uint8, device=dev)
+        z = torch.empty((ny, nx), dtype=p0.dtype, device=dev) if stats else None
+        P = torch.empty((ny, nx), dtype=p0.dtype, device=dev) if stats else None
+        if ny * nx * k > 0:
+            nbytes = L.nd_amd_omnibus_c3_workspace_bytes(ny, nx, k)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ptrs = (C.c_void_p * 9)(*[t.data_ptr() for t in planes])
+            _lib.check(L.nd_amd_omnibus_c3(
+                ptrs, _DT[p0.dtype], ny, nx, k, p0.stride(ay), p0.stride(ax), p0.stride(at),
+                int(n), float(alpha), _ptr(change), _ptr(z), _ptr(P), _ptr(ws), nbytes,
+                _stream_ptr(dev)))
+            ws.record_stream(torch.cuda.current_stream(dev))
+    if stats:
+        return change, z, P
+    return change
+
+
 # ---------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------

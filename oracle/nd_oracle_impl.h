@@ -147,6 +147,105 @@ int SFX(oracle_omnibus_c2)(const REAL *c11, const REAL *c12r, const REAL *c12i,
     return 0;
 }
 
+/* ---- generic-p restatement (p = 2: dual pol, p = 3: full pol) ------------------------------
+ * The reference hard-codes p = 2 (nd/_change.pyx:51, 99, 135); `_f`, `_rho`, `_omega2` are already
+ * written for any p (:20-39).  These functions apply the same formulas and the same rounding
+ * points to p x p Hermitian covariance matrices given as p*p real planes:
+ *   p = 2: [C11, C12re, C12im, C22]   (must equal the functions above bit for bit)
+ *   p = 3: [C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im]
+ * det(C) for p = 3:  abc - a|z|^2 - b|y|^2 - c|x|^2 + 2 Re(x z conj(y)),  x = C12, y = C13, z = C23,
+ * evaluated left to right in `floating`.  There is no reference implementation for p = 3:
+ * parity for it is UNPINNED. */
+static REAL SFX(orc_det_p)(const REAL *v, int pol)
+{
+    if (pol == 2) return (v[0] * v[3]) - ((v[1] * v[1]) + (v[2] * v[2]));
+    {
+        const REAL a = v[0], b = v[1], c = v[2];
+        const REAL xr = v[3], xi = v[4], yr = v[5], yi = v[6], zr = v[7], zi = v[8];
+        const REAL re = (((xr * zr) - (xi * zi)) * yr) + (((xr * zi) + (xi * zr)) * yi);
+        return (((((a * b) * c) - (a * ((zr * zr) + (zi * zi)))) - (b * ((yr * yr) + (yi * yi))))
+                - (c * ((xr * xr) + (xi * xi)))) + ((REAL)2 * re);
+    }
+}
+
+static REAL SFX(orc_omnibus_p)(const REAL *const *pl, ptrdiff_t off, ptrdiff_t st, size_t k,
+                               unsigned int n, int pol, REAL *z_out)
+{
+    const int nv = pol * pol;
+    REAL p = (REAL)pol, sums[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[9];
+    double prod_of_dets = 1.0, logQ, f, rho_d, omega2;
+    REAL det_of_sum, rho, z, P1, P2, result;
+    size_t i;
+    int c;
+    for (i = 0; i < k; i++) {
+        for (c = 0; c < nv; c++) v[c] = pl[c][off + (ptrdiff_t)i * st];
+        prod_of_dets = prod_of_dets * (double)SFX(orc_det_p)(v, pol);
+        if (pol == 2) {        /* summation order of nd/_change.pyx:66-69 (irrelevant: independent sums) */
+            for (c = 0; c < nv; c++) sums[c] = sums[c] + v[c];
+        } else {
+            for (c = 0; c < nv; c++) sums[c] = sums[c] + v[c];
+        }
+    }
+    det_of_sum = SFX(orc_det_p)(sums, pol);
+    logQ = (double)n * ((((double)(p * (REAL)k)) * log((double)k) + log(prod_of_dets))
+                        - ((double)k * log((double)det_of_sum)));
+    rho_d = orc_rho((double)pol, (double)k, (double)n);
+    rho = (REAL)rho_d;
+    z = (REAL)((-2.0 * (double)rho) * logQ);
+    f = orc_f((double)pol, (double)k, (double)n);
+    omega2 = orc_omega2((double)pol, (double)k, (double)n, rho_d);
+    P1 = (REAL)orc_cdf_chisq_P((double)z, f);
+    P2 = (REAL)orc_cdf_chisq_P((double)z, f + 4.0);
+    result = (REAL)((double)P1 + (omega2 * (double)(REAL)(P2 - P1)));
+    if (z_out) *z_out = z;
+    return result;
+}
+
+/* nd/_change.pyx:224-287 for p x p matrices; planes share one set of element strides */
+int SFX(oracle_omnibus_pol)(const REAL *const *planes, int pol, int64_t ny, int64_t nx, int64_t k,
+                            int64_t sy, int64_t sx, int64_t st, unsigned int n, double alpha,
+                            unsigned char *change, REAL *z_out, REAL *p_out, int nthreads)
+{
+    int64_t iy;
+    if (ny < 0 || nx < 0 || k < 0 || (pol != 2 && pol != 3)) return -1;
+    memset(change, 0, (size_t)ny * (size_t)nx * (size_t)k);
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 2) num_threads(nthreads)
+#endif
+    for (iy = 0; iy < ny; iy++) {
+        int64_t ix;
+        for (ix = 0; ix < nx; ix++) {
+            const ptrdiff_t off = (ptrdiff_t)(iy * sy + ix * sx);
+            unsigned char *result = change + (iy * nx + ix) * k;
+            ptrdiff_t l = 0, j, r = 0;
+            if (k < 1) continue;
+            for (;;) {
+                REAL zz, pg, pm;
+                pg = SFX(orc_omnibus_p)(planes, off + l * (ptrdiff_t)st, (ptrdiff_t)st,
+                                        (size_t)(k - l), n, pol, &zz);
+                if (l == 0) {
+                    if (z_out) z_out[iy * nx + ix] = zz;
+                    if (p_out) p_out[iy * nx + ix] = pg;
+                }
+                if (!((double)pg > alpha)) break;
+                for (j = 2; j < k - l + 1; j++) {
+                    pm = SFX(orc_omnibus_p)(planes, off + l * (ptrdiff_t)st, (ptrdiff_t)st,
+                                            (size_t)j, n, pol, NULL);
+                    r = j - 1;
+                    if ((double)pm > alpha) {
+                        result[l + r] = 1;
+                        break;
+                    }
+                }
+                l = l + r;
+                if (l >= k - 1) break;
+            }
+        }
+    }
+    return 0;
+}
+
 /* Marginal/global P of one series segment, for fixtures and unit pins. */
 REAL SFX(oracle_single_pixel_omnibus)(const REAL *ts4 /* k x 4 C-order */,
                                       int64_t k, unsigned int n, REAL *z_out)

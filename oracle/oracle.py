@@ -64,6 +64,9 @@ def lib():
             fn = getattr(L, 'oracle_omnibus_c2_' + sfx)
             fn.restype = C.c_int
             fn.argtypes = [_vp] * 4 + [_i64] * 6 + [C.c_uint, _dbl, _vp, _vp, _vp, C.c_int]
+            fn = getattr(L, 'oracle_omnibus_pol_' + sfx)
+            fn.restype = C.c_int
+            fn.argtypes = [_vp, C.c_int] + [_i64] * 6 + [C.c_uint, _dbl, _vp, _vp, _vp, C.c_int]
             fn = getattr(L, 'oracle_single_pixel_omnibus_' + sfx)
             fn.restype = C.c_float if sfx == 'f32' else _dbl
             fn.argtypes = [_vp, _i64, C.c_uint, _vp]
@@ -179,6 +182,31 @@ def change_detection_planes(planes, alpha, n=1, njobs=1, stats=False):
         _ptr(change), _ptr(z), _ptr(P), int(njobs))
     if rc != 0:
         raise RuntimeError('oracle_omnibus_c2 failed: %d' % rc)
+    if stats:
+        return change, z, P
+    return change
+
+
+def change_detection_pol(planes, pol, alpha, n=1, njobs=1, stats=False):
+    """Generic-p omnibus (p = 2 or 3) on p*p planes (y, x, time) sharing dtype and strides.
+    p = 3 plane order: C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im.  There is no
+    reference implementation for p = 3 (parity unpinned); p = 2 must equal change_detection."""
+    assert len(planes) == pol * pol
+    p0 = planes[0]
+    sfx = _sfx(p0.dtype)
+    ny, nx, k = p0.shape
+    es = _estr(p0)
+    for p in planes:
+        assert p.shape == p0.shape and p.dtype == p0.dtype and _estr(p) == es
+    ptrs = (C.c_void_p * len(planes))(*[p.ctypes.data for p in planes])
+    change = np.zeros((ny, nx, k), np.uint8)
+    z = np.zeros((ny, nx), p0.dtype)
+    P = np.zeros((ny, nx), p0.dtype)
+    rc = getattr(lib(), 'oracle_omnibus_pol_' + sfx)(
+        C.cast(ptrs, C.c_void_p), int(pol), ny, nx, k, es[0], es[1], es[2], int(n), float(alpha),
+        _ptr(change), _ptr(z), _ptr(P), int(njobs))
+    if rc != 0:
+        raise RuntimeError('oracle_omnibus_pol failed: %d' % rc)
     if stats:
         return change, z, P
     return change

@@ -72,3 +72,29 @@ def lite_test_dataset(dims=None, var=('C11', 'C12__im', 'C12__re', 'C22'), mean=
     for v in var:
         ds[v] = (tuple(dims.keys()), data[v])
     return ds
+
+
+def wishart_c3(rng, shape, looks=9, dtype=np.float32):
+    """n-look complex-Wishart full-pol samples: 9 real planes
+    [C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im] of `shape`."""
+    def cn(sh):
+        return (rng.standard_normal(sh) + 1j * rng.standard_normal(sh)) / np.sqrt(2.0)
+    s1 = cn((looks,) + tuple(shape))
+    s2 = 0.4 * s1 + 0.9 * cn((looks,) + tuple(shape))
+    s3 = 0.2 * s1 - 0.3j * s2 + 0.8 * cn((looks,) + tuple(shape))
+    c = lambda a, b: (a * np.conj(b)).mean(axis=0)
+    c12, c13, c23 = c(s1, s2), c(s1, s3), c(s2, s3)
+    out = [c(s1, s1).real, c(s2, s2).real, c(s3, s3).real, c12.real, c12.imag, c13.real, c13.imag,
+           c23.real, c23.imag]
+    return [np.ascontiguousarray(o.astype(dtype)) for o in out]
+
+
+def omnibus_stack_c3(seed, k, ny, nx, looks=9, dtype=np.float32, change_frac=0.1, factor=4.0):
+    rng = np.random.default_rng(seed)
+    planes = wishart_c3(rng, (k, ny, nx), looks, np.float64)
+    if change_frac > 0:
+        mask = rng.random((ny, nx)) < change_frac
+        t0 = rng.integers(1, max(k, 2), size=(ny, nx))
+        gain = np.where((np.arange(k)[:, None, None] >= t0[None]) & mask[None], factor, 1.0)
+        planes = [p * gain for p in planes]
+    return [np.ascontiguousarray(p.astype(dtype)) for p in planes]

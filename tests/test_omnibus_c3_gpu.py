@@ -1,0 +1,47 @@
+"""Full-pol (C3) omnibus on the GPU against this repository's generic-p oracle.  The reference has
+no p = 3 implementation, so this is self-consistency (HIP vs C restatement vs the float64 numpy
+definition in tests/test_oracle_omnibus.py), not reference parity."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(planes, alpha, n, device, layout='tyx'):
+    import torch
+    from nd_amd import kernels
+    ts = [torch.from_numpy(p).to(device) for p in planes]
+    dims = ('time', 'y', 'x')
+    if layout == 'yxt':
+        ts = [t.permute(1, 2, 0).contiguous() for t in ts]
+        dims = ('y', 'x', 'time')
+    ch, z, P = kernels.change_detection_c3(ts, alpha=alpha, n=n, dims=dims, stats=True)
+    ch2 = kernels.change_detection_c3(ts, alpha=alpha, n=n, dims=dims)
+    torch.cuda.synchronize()
+    assert torch.equal(ch, ch2)
+    return ch.cpu().numpy(), z.cpu().numpy(), P.cpu().numpy()
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('k', [7, 12, 48])
+@pytest.mark.parametrize('alpha', [0.9, 0.99])
+def test_c3_against_generic_oracle(oracle, device, dtype, k, alpha):
+    planes = synth.omnibus_stack_c3(seed=k, k=k, ny=20, nx=70, dtype=dtype, change_frac=0.15)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    want, z0, P0 = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8, stats=True)
+    ch, z, P = _run(planes, alpha, 9, device)
+    assert int((ch != want).sum()) == 0
+    np.testing.assert_allclose(z, z0, rtol=1e-5, equal_nan=True)
+    np.testing.assert_allclose(P, P0, rtol=1e-5, atol=1e-30, equal_nan=True)
+    assert want.sum() > 0
+
+
+def test_c3_layouts_and_tails(oracle, device):
+    planes = synth.omnibus_stack_c3(seed=3, k=6, ny=5, nx=131, dtype=np.float32, change_frac=0.3)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    want = oracle.change_detection_pol(yxt, 3, 0.9, 4, njobs=4)
+    for layout in ('tyx', 'yxt'):
+        ch, _, _ = _run(planes, 0.9, 4, device, layout)
+        np.testing.assert_array_equal(ch, want)

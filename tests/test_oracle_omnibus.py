@@ -130,3 +130,52 @@ def test_threads_and_strides_do_not_matter(oracle):
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(a, c)
     assert a.sum() > 0
+
+
+def test_generic_p_equals_c2_path_for_p2(oracle):
+    """The generic-p restatement with p = 2 reproduces the C2 oracle bit for bit (shared formulas)."""
+    for dt in (np.float32, np.float64):
+        planes = synth.omnibus_stack(seed=4, k=11, ny=14, nx=9, dtype=dt, change_frac=0.3)
+        yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+        a = oracle.change_detection_planes(yxt, 0.9, 9, stats=True)
+        b = oracle.change_detection_pol(yxt, 2, 0.9, 9, stats=True)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        assert a[0].sum() > 0
+
+
+def test_generic_p3_against_numpy_definition(oracle):
+    """p = 3 (no reference implementation: parity unpinned).  The oracle is checked against the
+    textbook statistic in float64: ln Q = n (p k ln k + sum ln det C_i - k ln det sum C_i),
+    z = -2 rho ln Q, P = P1 + omega2 (P2 - P1) with chi-square CDFs from scipy."""
+    from scipy.stats import chi2
+    planes = synth.omnibus_stack_c3(seed=6, k=9, ny=3, nx=4, dtype=np.float64, change_frac=0.5)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    ch, z, P = oracle.change_detection_pol(yxt, 3, 0.9, 9, stats=True)
+    k = 9
+
+    def mats(iy, ix):
+        v = [p[iy, ix] for p in yxt]
+        C = np.zeros((k, 3, 3), complex)
+        C[:, 0, 0], C[:, 1, 1], C[:, 2, 2] = v[0], v[1], v[2]
+        C[:, 0, 1] = v[3] + 1j * v[4]; C[:, 1, 0] = np.conj(C[:, 0, 1])
+        C[:, 0, 2] = v[5] + 1j * v[6]; C[:, 2, 0] = np.conj(C[:, 0, 2])
+        C[:, 1, 2] = v[7] + 1j * v[8]; C[:, 2, 1] = np.conj(C[:, 1, 2])
+        return C
+    for iy in range(3):
+        for ix in range(4):
+            C = mats(iy, ix)
+            lnQ = 9 * (3 * k * np.log(k) + np.log(np.linalg.det(C).real).sum()
+                       - k * np.log(np.linalg.det(C.sum(axis=0)).real))
+            rho = oracle.rho(3, k, 9)
+            w2 = oracle.omega2(3, k, 9, rho)
+            f = oracle.f_dof(3, k, 9)
+            assert f == 72.0
+            zz = -2 * rho * lnQ
+            assert z[iy, ix] == pytest.approx(zz, rel=1e-9)
+            P1, P2 = chi2.cdf(zz, f), chi2.cdf(zz, f + 4)
+            assert P[iy, ix] == pytest.approx(P1 + w2 * (P2 - P1), rel=1e-9, abs=1e-300)
+    # half-integer a = f/2 occurs for even k: chi-square CDF with odd dof
+    for nu in (9, 27, 63, 81):
+        for x in (0.5, 10.0, float(nu), 3.0 * nu):
+            assert oracle.cdf_chisq_P(x, nu) == pytest.approx(chi2.cdf(x, nu), rel=2e-12)
