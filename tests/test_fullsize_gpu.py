@@ -98,3 +98,37 @@ def test_large_k_paths(oracle, device):
         np.testing.assert_array_equal(ch2.cpu().numpy(), want)
         np.testing.assert_allclose(z.cpu().numpy(), z0, rtol=1e-5)
         np.testing.assert_allclose(P.cpu().numpy(), P0, rtol=1e-5, atol=1e-30)
+
+
+def test_nlmeans_config_size_band_matches_oracle(oracle, device):
+    """BASELINE config 3 (non-local means 7x7 patch / 21x21 search, 12 dates x 4096 x 4096, one
+    band): run the full raster, check a band of it (with its halo) against the oracle in both patch
+    modes, and that a constant raster stays constant."""
+    import torch
+    from nd_amd import kernels
+    k, ny, nx = 12, 4096, 4096
+    g = torch.Generator(device=device).manual_seed(11)
+    x = torch.empty((1, k, ny, nx), device=device)
+    for t in range(k):
+        u = torch.rand((4, ny, nx), generator=g, device=device)
+        x[0, t] = -0.25 * torch.log(u).sum(dim=0)              # Gamma(4, 0.25)
+    arr = x.permute(2, 3, 1, 0)                                # (y, x, time, var) view
+    r, f, halo = (10, 10, 0), (3, 3, 0), 13
+    y0, x0, hh, ww, t_sel = 2040, 3000, 8, 96, 5
+    crop = x[:, t_sel:t_sel + 1, y0 - halo:y0 + hh + halo, x0 - halo:x0 + ww + halo]
+    crop_np = np.ascontiguousarray(crop.permute(2, 3, 1, 0).cpu().numpy())
+    for pm in (0, 1):
+        out = torch.empty_like(x)
+        kernels.pixelwise_nlmeans_3d(arr, out.permute(2, 3, 1, 0), r, f, 0.5, 0.5, -1, patch_mode=pm)
+        torch.cuda.synchronize()
+        want = np.empty_like(crop_np)
+        oracle.pixelwise_nlmeans_3d(crop_np, want, r, f, 0.5, 0.5, -1, njobs=8, patch_mode=pm)
+        got = out[0, t_sel, y0:y0 + hh, x0:x0 + ww].cpu().numpy()
+        np.testing.assert_allclose(got, want[halo:halo + hh, halo:halo + ww, 0, 0], rtol=1e-5)
+        if pm == 0:
+            np.testing.assert_array_equal(got, want[halo:halo + hh, halo:halo + ww, 0, 0])
+    c = torch.full((1, 2, 512, 512), 2.5, device=device)
+    o = torch.empty_like(c)
+    kernels.pixelwise_nlmeans_3d(c.permute(2, 3, 1, 0), o.permute(2, 3, 1, 0), r, f, 0.5, 0.5, -1,
+                                 patch_mode=1)
+    assert float((o - 2.5).abs().max()) < 1e-6
