@@ -161,7 +161,6 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     double *tile = reinterpret_cast<double *>(nd_smem_c);
     const int tid = threadIdx.x;
     const int kh = a.kh;
-    const int tw = kTileX + KW - 1;              // staged columns
     const int th = kTileY + kh - 1;              // staged rows
     int64_t b = blockIdx.x;
     const int tx = (int)(b % a.tiles_x);
@@ -176,9 +175,13 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     // issues all of its loads before consuming the first one (coalesced along x). ----
     const double wbox = a.w[0];
     constexpr int TW = kTileX + KW - 1;
+    // LDS image: columns de-interleaved by (c mod 4), element (r, c) at (r*4 + (c&3)) * TWQ + (c>>2).
+    // A thread's 4 adjacent outputs start at column 4*lane', so the lanes of one read instruction
+    // hit consecutive doubles (conflict-free) instead of every fourth one (4-way conflict).
+    constexpr int TWQ = (TW + 3) / 4;
     constexpr int kMaxLoads = ((kTileY + kMaxKH - 1) * TW + 255) / 256;
     const int n_el = th * TW;
-    int *ymap = reinterpret_cast<int *>(tile + n_el);
+    int *ymap = reinterpret_cast<int *>(tile + th * 4 * TWQ);
     int *xmap = ymap + th;
     for (int i = tid; i < th + TW; i += 256) {
         if (i < th)
@@ -201,8 +204,9 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
         for (int i = 0; i < kMaxLoads; ++i) {
             const int e = tid + 256 * i;
             if (e < n_el) {
+                const int r = e / TW, c = e - r * TW;
                 const double v = (double)buf[i];
-                tile[e] = BOX ? wbox * v : v;
+                tile[(r * 4 + (c & 3)) * TWQ + (c >> 2)] = BOX ? wbox * v : v;
             }
         }
     }
@@ -218,9 +222,9 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
 
     for (int r = 0; r < kOY + kh - 1; ++r) {
         double v[kOX + KW - 1];
-        const double *src = tile + (ly + r) * tw + lx;
+        const double *src = tile + (ly + r) * 4 * TWQ + (lx >> 2);      // lx is a multiple of 4
 #pragma unroll
-        for (int c = 0; c < kOX + KW - 1; ++c) v[c] = src[c];
+        for (int c = 0; c < kOX + KW - 1; ++c) v[c] = src[(c & 3) * TWQ + (c >> 2)];
 #pragma unroll
         for (int oy = 0; oy < kOY; ++oy) {
             const int i = r - oy;                       // kernel row feeding output row oy
@@ -347,7 +351,8 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     }
     const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * nb;
     if (nblocks > 0x7fffffffLL || nblocks < 1) return 0;
-    const size_t lds = (size_t)(kTileY + kh - 1) * (size_t)(kTileX + kw - 1) * sizeof(double) +
+    const size_t twq = (size_t)(kTileX + kw - 1 + 3) / 4;
+    const size_t lds = (size_t)(kTileY + kh - 1) * 4 * twq * sizeof(double) +
                        (size_t)((kTileY + kh - 1) + (kTileX + kw - 1)) * sizeof(int);
     if (lds > 64 * 1024) return 0;
     {
