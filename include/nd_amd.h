@@ -128,8 +128,8 @@ int nd_amd_omnibus_c3(const void *const planes[9], int dtype,
  *   out = (T)tmp          -- same order, double accumulation, no FMA.
  *   offsets : host pointer, ntaps x 4 int64
  *   weights : host pointer, ntaps double
- * Up to 128 taps travel to the kernel as a launch argument (asynchronous,
- * graph-capturable).  Larger footprints are copied into `taps_dev`
+ * Up to 128 taps travel to the kernel as a launch argument (fully asynchronous).
+ * Larger footprints are copied into `taps_dev`
  * (>= 24 * ntaps bytes of device memory, may be NULL otherwise); that path
  * synchronises the stream once.
  * ---------------------------------------------------------------------- */

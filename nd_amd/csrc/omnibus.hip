@@ -770,7 +770,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     if (tab_in_args) {
         memcpy(tab.e, htab.data(), htab.size() * sizeof(OmniTabEntry));
     } else {
-        // large k: the table goes through a pageable host copy (synchronises; not capturable)
+        // large k: the table goes through a pageable host copy (synchronises the stream once)
         hipError_t e = hipMemcpyAsync(tab_dev, htab.data(), htab.size() * sizeof(OmniTabEntry),
                                       hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
