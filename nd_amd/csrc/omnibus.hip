@@ -450,9 +450,13 @@ struct OmniSearchArgs {
     uint32_t dump_cap;
 };
 
-template <typename T, bool USE_LDS>
+// MODE 0: series staged in LDS; MODE 1: no LDS, each date read straight from the dump (or the
+// planes) with the next date's load issued one iteration ahead -- 4 waves per SIMD instead of the
+// 1.5 the 24.5 KB LDS image allows.
+template <typename T, int MODE>
 __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchArgs<T> s)
 {
+    constexpr bool USE_LDS = (MODE == 0);
     extern __shared__ __align__(16) unsigned char nd_smem[];
     T *lds = reinterpret_cast<T *>(nd_smem);
     const int lane = threadIdx.x;
@@ -527,13 +531,34 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                 }
             }
         }
+        // MODE 1: date t of this lane's series; `nxt` holds date `nxt_t` fetched one iteration ago
+        const bool from_dump = idx < s.dump_cap;
+        const T *dsrc = s.dump + ((int64_t)shard * s.dump_cap + (from_dump ? idx : 0)) * (int64_t)(4 * k);
+        Pack<T, 4> nxt;
+        int nxt_t = -1;
+        auto fetch = [&](int t) -> Pack<T, 4> {
+            Pack<T, 4> q;
+            if (from_dump) {
+                q = *reinterpret_cast<const Pack<T, 4> *>(dsrc + 4 * t);
+            } else {
+                const int64_t o = off + (int64_t)t * s.st;
+                q.v[0] = s.c11[o];
+                q.v[1] = s.c12r[o];
+                q.v[2] = s.c12i[o];
+                q.v[3] = s.c22[o];
+            }
+            return q;
+        };
         auto load_step = [&](Accum<T> &A, int t) {
             if (USE_LDS) {
                 A.step(lds[(t * 4 + 0) * 64 + lane], lds[(t * 4 + 1) * 64 + lane],
                        lds[(t * 4 + 2) * 64 + lane], lds[(t * 4 + 3) * 64 + lane]);
             } else {
-                const int64_t o = off + (int64_t)t * s.st;
-                A.step(s.c11[o], s.c12r[o], s.c12i[o], s.c22[o]);
+                const Pack<T, 4> cur = (nxt_t == t) ? nxt : fetch(t);
+                const int tn = t + 1 < k ? t + 1 : t;
+                nxt = fetch(tn);                       // in flight while this date is evaluated
+                nxt_t = tn;
+                A.step(cur.v[0], cur.v[1], cur.v[2], cur.v[3]);
             }
         };
 
@@ -866,12 +891,17 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     const int64_t sblocks = per_shard * kShards;
     {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
-        if (use_lds)
-            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, true>), dim3((unsigned)sblocks),
-                               dim3(64), lds_bytes, stream, s);
+        static const int mode_env = [] {
+            const char *e = getenv("ND_AMD_SEARCH_MODE");
+            return e ? atoi(e) : -1;
+        }();
+        const int mode = mode_env >= 0 ? mode_env : (use_lds ? 0 : 1);
+        if (mode == 0 && use_lds)
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0>), dim3((unsigned)sblocks), dim3(64),
+                               lds_bytes, stream, s);
         else
-            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, false>), dim3((unsigned)sblocks),
-                               dim3(64), 0, stream, s);
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 1>), dim3((unsigned)sblocks), dim3(64),
+                               0, stream, s);
     }
     ND_HIP_CHECK(hipGetLastError());
     return ND_AMD_OK;
