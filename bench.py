@@ -165,13 +165,15 @@ def main():
             'value': value, 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 planes; f32 sums, f64 determinant product / logs / chi-square',
+            'dtype': 'f32',
             'data': 'synthetic',
             'config': {
                 'workload': 'OmnibusTest dual-pol C2, synthetic %dt x %d x %d float32 per GPU '
                             '(BASELINE.json configs[1]), n=%d looks, alpha=%g, %.3g of pixels '
                             'with a x4 step; inputs resident in HBM'
                             % (k, ny, nx, args.looks, args.alpha, args.change_frac),
+                'arithmetic': 'float32 planes and running sums; float64 product of determinants, '
+                              'logs and chi-square pair (the reference\'s rounding points)',
                 'flagged_pixel_fraction': flagged,
                 'sharding': 'y-tiles, one per rank, no collective',
             },
