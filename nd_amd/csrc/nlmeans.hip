@@ -186,6 +186,8 @@ struct NlmTiledArgs {
     int64_t si0, si2, si3;     // input strides (axis 1 stride is 1)
     int64_t so0, so2, so3;
     int r0, r1, f0, f1;
+    int rz;                    // window radius along axis 2 (0: axis 2 is a plain slice axis)
+    int64_t Gz, offz;          // global extent / tile offset of axis 2
     int nvars;
     int tiles_x, tiles_y;
     float dsq_norm;
@@ -274,10 +276,11 @@ __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs 
 {
     extern __shared__ __align__(16) unsigned char nd_smem_n[];
     const int tid = threadIdx.x;
-    const int r0 = a.r0, r1 = a.r1;
+    const int r0 = a.r0, r1 = a.r1, rz = a.rz;
     const int cols = kWinTX + 2 * r1, rows = kWinTY + 2 * r0;
-    float *lds = reinterpret_cast<float *>(nd_smem_n);
-    int *ymap = reinterpret_cast<int *>(lds + rows * cols);
+    const int psz = rows * cols, nz = 2 * rz + 1;
+    float *lds = reinterpret_cast<float *>(nd_smem_n);          // [nz][rows][cols]
+    int *ymap = reinterpret_cast<int *>(lds + nz * psz);
     int *xmap = ymap + rows;
 
     int64_t b = blockIdx.x;
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs 
     const int64_t y0 = a.clo0 + (int64_t)ty * kWinTY, x0 = a.clo1 + (int64_t)tx * kWinTX;
 
     const int lx = (tid % 32) * 4, ly = (tid / 32) * 4;          // 4 x 4 pixels per thread
-    const double nq = (double)((2 * r0 + 1) * (2 * r1 + 1) - 1);
+    const double nq = (double)(nz * (2 * r0 + 1) * (2 * r1 + 1) - 1);
     bool fail;
     const double wself = nlm_self_weight(nq, nq, nq > 0 ? 1.0 : 0.0, a.n_eff, a.neff_policy,
                                          a.status, &fail);
@@ -296,30 +299,41 @@ __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs 
 
     for (int v = 0; v < a.nvars; ++v) {
         __syncthreads();
-        nlm_stage(a, lds, ymap, xmap, rows, cols, a.off0 + y0 - r0, a.off1 + x0 - r1, i2, v, tid);
+        // the window planes along axis 2 (one plane when rz = 0), whole-sample reflection at the
+        // global ends of that axis
+        for (int dz = 0; dz < nz; ++dz) {
+            int64_t zz = nlm_reflect_i(a.offz + i2 + dz - rz, a.Gz) - a.offz;
+            zz = zz < 0 ? 0 : (zz >= a.N2 ? a.N2 - 1 : zz);
+            nlm_stage(a, lds + dz * psz, ymap, xmap, rows, cols, a.off0 + y0 - r0, a.off1 + x0 - r1,
+                      zz, v, tid);
+        }
 #pragma unroll
         for (int py = 0; py < 4; ++py) {
             const int yy = ly + py;
             float ws[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int dy = 0; dy < 2 * r0 + 1; ++dy) {
-                const float *row = lds + (yy + dy) * cols + lx;
-                // window columns 0 .. 2 r1 for pixel 0, shifted by i for pixel i
-                float w[2 * R1MAX + 4];
+            // the reference's visiting order: axis-2 offset outermost when it is a window axis
+            // (it is then the FIRST filter dimension, see nlm_try_tiled), rows, columns innermost
+            for (int dz = 0; dz < nz; ++dz) {
+                for (int dy = 0; dy < 2 * r0 + 1; ++dy) {
+                    const float *row = lds + dz * psz + (yy + dy) * cols + lx;
+                    // window columns 0 .. 2 r1 for pixel 0, shifted by i for pixel i
+                    float w[2 * R1MAX + 4];
 #pragma unroll
-                for (int c = 0; c < 2 * R1MAX + 4; ++c)
-                    if (c < 2 * r1 + 4) w[c] = row[c];
-                const bool centre_row = (dy == r0);
+                    for (int c = 0; c < 2 * R1MAX + 4; ++c)
+                        if (c < 2 * r1 + 4) w[c] = row[c];
+                    const bool centre_row = (dy == r0) && (dz == rz);
 #pragma unroll
-                for (int dx = 0; dx < 2 * R1MAX + 1; ++dx) {
-                    if (dx < 2 * r1 + 1 && !(centre_row && dx == r1)) {
+                    for (int dx = 0; dx < 2 * R1MAX + 1; ++dx) {
+                        if (dx < 2 * r1 + 1 && !(centre_row && dx == r1)) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) ws[i] = ws[i] + w[dx + i];
+                            for (int i = 0; i < 4; ++i) ws[i] = ws[i] + w[dx + i];
+                        }
                     }
                 }
             }
             const int64_t y = y0 + yy;
             if (y < a.chi0 && !fail) {
-                const float *crow = lds + (yy + r0) * cols + lx + r1;
+                const float *crow = lds + rz * psz + (yy + r0) * cols + lx + r1;
                 float *o = a.out + i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -551,61 +565,78 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
 {
     static const bool disabled = getenv("ND_AMD_NO_TILED") != nullptr;
     if (disabled || dtype != ND_AMD_F32) return 0;
-    if (r[2] != 0 || f[2] != 0) return 0;
-    if (si[1] != 1 || so[1] != 1) return 0;
-    if (r[0] == 0 && r[1] == 0) return 0;
     if (nvars < 1) return 0;
-    for (int d = 0; d < 2; ++d)
+    // Canonical axes of the tiled kernels: rows, contiguous columns, and a third axis that is
+    // either a plain slice axis or (window kernel only) a window axis visited OUTERMOST.
+    //   layout A: user axes (rows, cols, slices) -- e.g. (y, x, time): cols contiguous, r[2] = f[2] = 0
+    //   layout B: user axes (z, rows, cols)      -- e.g. (time, y, x): cols contiguous, z = first
+    //             filter dimension, so the reference visits it outermost (nd/_filters.pyx:363-370)
+    int A0, A1, A2;
+    if (si[1] == 1 && so[1] == 1 && r[2] == 0 && f[2] == 0) {
+        A0 = 0; A1 = 1; A2 = 2;
+    } else if (si[2] == 1 && so[2] == 1) {
+        A0 = 1; A1 = 2; A2 = 0;
+    } else {
+        return 0;
+    }
+    const uint32_t rz = r[A2], fz = f[A2];
+    if (r[A0] == 0 && r[A1] == 0 && rz == 0) return 0;
+    for (int d = 0; d < 3; ++d)
         if (G[d] > 0x3fffffff || N[d] > 0x3fffffff) return 0;
     NlmTiledArgs a;
     a.arr = static_cast<const float *>(arr);
     a.out = static_cast<float *>(out);
-    a.N0 = N[0]; a.N1 = N[1]; a.N2 = N[2];
-    a.G0 = G[0]; a.G1 = G[1];
-    a.off0 = toff[0]; a.off1 = toff[1];
-    a.clo0 = clo[0]; a.chi0 = chi[0]; a.clo1 = clo[1]; a.chi1 = chi[1]; a.clo2 = clo[2]; a.chi2 = chi[2];
-    a.si0 = si[0]; a.si2 = si[2]; a.si3 = si[3];
-    a.so0 = so[0]; a.so2 = so[2]; a.so3 = so[3];
-    a.r0 = (int)r[0]; a.r1 = (int)r[1]; a.f0 = (int)f[0]; a.f1 = (int)f[1];
+    a.N0 = N[A0]; a.N1 = N[A1]; a.N2 = N[A2];
+    a.G0 = G[A0]; a.G1 = G[A1]; a.Gz = G[A2];
+    a.off0 = toff[A0]; a.off1 = toff[A1]; a.offz = toff[A2];
+    a.clo0 = clo[A0]; a.chi0 = chi[A0]; a.clo1 = clo[A1]; a.chi1 = chi[A1];
+    a.clo2 = clo[A2]; a.chi2 = chi[A2];
+    a.si0 = si[A0]; a.si2 = si[A2]; a.si3 = si[3];
+    a.so0 = so[A0]; a.so2 = so[A2]; a.so3 = so[3];
+    a.r0 = (int)r[A0]; a.r1 = (int)r[A1]; a.f0 = (int)f[A0]; a.f1 = (int)f[A1];
+    a.rz = (int)rz;
     a.nvars = (int)nvars;
-    a.dsq_norm = (float)((((uint32_t)nvars * (2u * f[0] + 1u)) * (2u * f[1] + 1u)) * 1u);
+    a.dsq_norm = (float)((((uint32_t)nvars * (2u * f[0] + 1u)) * (2u * f[1] + 1u)) * (2u * f[2] + 1u));
     a.two_sigma2 = 2.0 * (sigma * sigma);
     a.h2 = h * h;
     a.n_eff = n_eff;
     a.neff_policy = neff_policy;
     a.status = status_dev;
-    const int64_t ey = chi[0] - clo[0], ex = chi[1] - clo[1], nsl = chi[2] - clo[2];
+    const int64_t ey = a.chi0 - a.clo0, ex = a.chi1 - a.clo1, nsl = a.chi2 - a.clo2;
     if (ey < 1 || ex < 1 || nsl < 1) return 0;
 
-    const bool uniform = (patch_mode == 0) && (f[0] > 0 || f[1] > 0);
+    const bool uniform = (patch_mode == 0) && (f[0] > 0 || f[1] > 0 || f[2] > 0);
     if (uniform) {
         // weight exp(-max(0 - 2 sigma^2, 0) / h^2) must be exactly 1
         if (!(sigma == sigma) || !(h == h) || h == 0.0 || !(sigma * sigma < INFINITY)) return 0;
-        if (r[1] > 16) return 0;
+        if (a.r1 > 16) return 0;
         a.tiles_x = (int)ceil_div(ex, kWinTX);
         a.tiles_y = (int)ceil_div(ey, kWinTY);
         const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nsl;
-        const size_t rows = kWinTY + 2 * r[0], cols = kWinTX + 2 * r[1];
-        const size_t lds = rows * cols * sizeof(float) + (rows + cols) * sizeof(int);
+        const size_t rows = kWinTY + 2 * a.r0, cols = kWinTX + 2 * a.r1;
+        const size_t lds = (size_t)(2 * rz + 1) * rows * cols * sizeof(float) +
+                           (rows + cols) * sizeof(int);
         if (lds > 64 * 1024 || nb > 0x7fffffffLL) return 0;
         KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
-        if (r[1] <= 4)
+        if (a.r1 <= 4)
             hipLaunchKernelGGL((nlmeans_window_kernel<4>), dim3((unsigned)nb), dim3(256), lds, stream, a);
-        else if (r[1] <= 10)
+        else if (a.r1 <= 10)
             hipLaunchKernelGGL((nlmeans_window_kernel<10>), dim3((unsigned)nb), dim3(256), lds, stream, a);
         else
             hipLaunchKernelGGL((nlmeans_window_kernel<16>), dim3((unsigned)nb), dim3(256), lds, stream, a);
         return 1;
     }
-    // true patch distances (patch_mode 1, or f = 0 in either mode: the loops run once)
-    const uint32_t F0 = (patch_mode == 1) ? f[0] : 0u, F1 = (patch_mode == 1) ? f[1] : 0u;
-    if (patch_mode == 0 && (f[0] != 0 || f[1] != 0)) return 0;
+    // true patch distances (patch_mode 1, or f = 0 in either mode: the loops run once); the third
+    // axis must be a plain slice axis here
+    if (rz != 0 || fz != 0) return 0;
+    const uint32_t F0 = (patch_mode == 1) ? f[A0] : 0u, F1 = (patch_mode == 1) ? f[A1] : 0u;
+    if (patch_mode == 0 && (f[A0] != 0 || f[A1] != 0)) return 0;
     if (F0 != F1 || F0 > 3 || nvars > 4) return 0;
     const int tyw = (nvars == 1) ? 16 : 8;
     a.tiles_x = (int)ceil_div(ex, 64);
     a.tiles_y = (int)ceil_div(ey, 4 * tyw);
-    const size_t cols = 64 + 2 * (r[1] + F0);
-    const size_t rows = 4 * tyw + 2 * (r[0] + F0);
+    const size_t cols = 64 + 2 * (a.r1 + F0);
+    const size_t rows = 4 * tyw + 2 * (a.r0 + F0);
     const size_t lds = (size_t)nvars * rows * cols * sizeof(float) + (rows + cols) * sizeof(int);
     if (lds > 64 * 1024) return 0;
     if ((int64_t)a.tiles_x * a.tiles_y * nsl > 0x7fffffffLL) return 0;

@@ -174,3 +174,64 @@ def test_tiny_weights_follow_the_reference(oracle, device):
         oracle.pixelwise_nlmeans_3d(a, want, (3, 3, 0), (1, 1, 0), s, h, -1, njobs=8, patch_mode=1)
         got = _gpu_nlm(a, (3, 3, 0), (1, 1, 0), s, h, -1, device, patch_mode=1, permute=(3, 2, 0, 1))
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-30)
+
+
+@pytest.mark.parametrize('case', [
+    ((5, 40, 70, 4), (1, 3, 3), (1, 1, 1), 0.5, 0.5, 50.0),      # the tutorial's filter
+    ((5, 40, 70, 4), (1, 3, 3), (1, 1, 1), 0.5, 0.5, -1),
+    ((3, 33, 130, 1), (2, 2, 4), (1, 0, 1), 0.5, 0.5, -1),
+    ((6, 20, 20, 2), (0, 3, 2), (0, 1, 1), 0.5, 0.5, -1),         # time is a plain slice axis
+    ((4, 35, 66, 2), (1, 0, 2), (1, 0, 1), 0.4, 0.6, 20.0),
+])
+def test_time_first_layout_window_kernel(oracle, device, case):
+    """(time, y, x, var) views of planar stacks, 3-D search window: the reference-compatible mode
+    (unit weights) runs in the tiled window kernel with the time offset visited outermost, as in
+    nd/_filters.pyx:363-370; results must equal the reference's float32 sums bit for bit."""
+    import torch
+    from nd_amd import kernels
+    shape, r, f, s, h, ne = case
+    rng = np.random.default_rng(47)
+    a = rng.gamma(4.0, 0.25, shape).astype(np.float32)                 # (t, y, x, var)
+    want = np.empty_like(a)
+    oracle.pixelwise_nlmeans_3d(a, want, r, f, s, h, ne, neff_policy=0, njobs=8, patch_mode=0)
+    planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)   # (var, t, y, x)
+    out = torch.empty_like(planar)
+    kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, s, h, ne,
+                                 patch_mode=0, neff_policy=0)
+    torch.cuda.synchronize()
+    got = out.permute(1, 2, 3, 0).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_time_first_layout_patch_kernel_and_tiles(oracle, device):
+    """(time, y, x, var) views with r_time = 0: true patch distances through the sliding-sum kernel,
+    and row blocks with halos along y (user axis 1) reproduce the unsharded result."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(48)
+    a = rng.gamma(4.0, 0.25, (3, 70, 66, 2)).astype(np.float32)
+    r, f = (0, 3, 2), (0, 1, 1)
+    want = np.empty_like(a)
+    oracle.pixelwise_nlmeans_3d(a, want, r, f, 0.4, 0.5, -1, njobs=8, patch_mode=1)
+    planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)
+    out = torch.empty_like(planar)
+    kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, 0.4, 0.5, -1,
+                                 patch_mode=1)
+    np.testing.assert_allclose(out.permute(1, 2, 3, 0).cpu().numpy(), want, rtol=RTOL)
+    for pm, rr, ff in ((1, r, f), (0, (1, 3, 2), (1, 1, 1))):
+        ref = torch.empty_like(planar)
+        kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), ref.permute(1, 2, 3, 0), rr, ff, 0.4, 0.5,
+                                     -1, patch_mode=pm)
+        halo = rr[1] + ff[1]
+        acc = torch.zeros_like(planar)
+        for lo, hi in [(0, 25), (25, 48), (48, 70)]:
+            tlo, thi = max(lo - halo, 0), min(hi + halo, 70)
+            tile = planar[:, :, tlo:thi].contiguous()
+            tout = torch.empty_like(tile)
+            kernels.pixelwise_nlmeans_3d(tile.permute(1, 2, 3, 0), tout.permute(1, 2, 3, 0), rr, ff, 0.4,
+                                         0.5, -1, patch_mode=pm, global_shape=(3, 70, 66),
+                                         tile_offset=(0, tlo, 0),
+                                         core=((0, 3), (lo - tlo, hi - tlo), (0, 66)))
+            acc[:, :, lo:hi] = tout[:, :, lo - tlo:hi - tlo]
+        torch.cuda.synchronize()
+        assert torch.equal(acc, ref)
