@@ -184,10 +184,15 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     int *ymap = reinterpret_cast<int *>(tile + th * 4 * TWQ);
     int *xmap = ymap + th;
     for (int i = tid; i < th + TW; i += 256) {
-        if (i < th)
-            ymap[i] = (int)extend_index(y_base + a.oy0 + i, a.ny, a.mode);
-        else
-            xmap[i - th] = (int)extend_index(x_base + a.ox0 + (i - th), a.nx, a.mode);
+        // (scipy's reflect table yields -1 for offsets that are exact multiples of 2*len beyond
+        // -2*len; clamp so that such a degenerate window can never index before the plane)
+        if (i < th) {
+            const int64_t m = extend_index(y_base + a.oy0 + i, a.ny, a.mode);
+            ymap[i] = m < 0 ? 0 : (int)m;
+        } else {
+            const int64_t m = extend_index(x_base + a.ox0 + (i - th), a.nx, a.mode);
+            xmap[i - th] = m < 0 ? 0 : (int)m;
+        }
     }
     __syncthreads();
     {
