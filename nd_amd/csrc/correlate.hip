@@ -319,6 +319,12 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
                                         kw != 11))
         return 0;
     if (dims[2] < 1 || dims[3] < 1 || dims[2] > 0x7fffffffLL || dims[3] > 0x7fffffffLL) return 0;
+    // windows reaching farther than twice the plane from it hit the non-periodic corner of
+    // scipy's offset table: leave those to the generic kernel, which restates the table as is
+    {
+        const int64_t ry = (-ymin > ymax ? -ymin : ymax), rx = (-xmin > xmax ? -xmin : xmax);
+        if (ry >= 2 * dims[2] || rx >= 2 * dims[3]) return 0;
+    }
     // batch = dims[0] x dims[1] must be addressable with one stride
     int64_t nb = dims[0] * dims[1], sbi, sbo;
     if (dims[0] == 1) {
