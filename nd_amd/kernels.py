@@ -41,13 +41,16 @@ def _ptr(t):
 # OmnibusTest C2
 # ---------------------------------------------------------------------------
 def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x'),
-                     stats=False):
+                     stats=False, workspace='recommended'):
     """Omnibus change detection on four covariance planes.
 
     c11, c12re, c12im, c22 : CUDA tensors of identical shape/strides/dtype whose
         three axes are named by `dims` (any order of 'y', 'x', 'time'); the
         reference's (y, x, time, 4) view (nd/change.py:66-67) is these four
         tensors side by side.
+    workspace : 'recommended' (room for the series of 1/8 of the pixels, so the change-point
+        search never re-reads the planes) or 'minimal' (candidate list only: less memory, listed
+        pixels are gathered from the planes).
     Returns uint8 tensor (y, x, time) [, z (y, x), P (y, x)].
     """
     planes = (c11, c12re, c12im, c22)
@@ -72,7 +75,13 @@ def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x')
         z = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
         P = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
         if ny * nx * k > 0:
-            nbytes = L.nd_amd_omnibus_c2_workspace_bytes(_DT[c11.dtype], ny, nx, k, None)
+            min_bytes = C.c_size_t(0)
+            nbytes = L.nd_amd_omnibus_c2_workspace_bytes(_DT[c11.dtype], ny, nx, k,
+                                                         C.byref(min_bytes))
+            if workspace == 'minimal':
+                nbytes = min_bytes.value
+            elif workspace != 'recommended':
+                raise ValueError("workspace must be 'recommended' or 'minimal'")
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _lib.check(L.nd_amd_omnibus_c2(
                 _ptr(c11), _ptr(c12re), _ptr(c12im), _ptr(c22), _DT[c11.dtype],

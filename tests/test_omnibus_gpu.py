@@ -115,3 +115,20 @@ def test_degenerate_values(oracle, device):
     got = _run_gpu(planes, 0.5, 9, device)
     want = _run_oracle(oracle, planes, 0.5, 9)
     _compare(got, want)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_minimal_workspace_gathers_from_planes(oracle, device, dtype):
+    """Without room for the series dump every listed pixel is gathered from the planes by the
+    search kernel; also n = 1 / small alpha, where the decision bounds are disabled (omega2 > 1)
+    and every pixel is listed."""
+    import torch
+    from nd_amd import kernels
+    planes = synth.omnibus_stack(seed=17, k=9, ny=30, nx=90, looks=2, dtype=dtype, change_frac=0.3)
+    ts = [torch.from_numpy(p).to(device) for p in planes]
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    for alpha, n in [(0.9, 9), (0.01, 1), (0.5, 1)]:
+        want = oracle.change_detection_planes(yxt, alpha, n, njobs=8)
+        for ws in ('minimal', 'recommended'):
+            got = kernels.change_detection(*ts, alpha=alpha, n=n, workspace=ws)
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
