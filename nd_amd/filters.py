@@ -368,14 +368,30 @@ class NLMeansFilter(Filter):
         with torch.cuda.device(dev):
             t = _device.to_device(arr, dev)
             t4 = t[(None,) * (4 - t.dim())]
-            if _device.is_tensor(output):
+            # The tiled kernels want planar memory (variable outermost) with the last windowed
+            # axis contiguous; datasets arrive with the variable axis fastest.  Re-lay the data out
+            # on the device (one transpose pass each way) when that is the case.
+            if r[2] == 0 and f[2] == 0:
+                fwd, back = (3, 2, 0, 1), (2, 3, 1, 0)       # memory (var, axis2, axis0, axis1)
+                fast = t4.stride(1) == 1
+            else:
+                fwd, back = (3, 0, 1, 2), (1, 2, 3, 0)       # memory (var, axis0, axis1, axis2)
+                fast = t4.stride(2) == 1
+            relayout = (not fast) and t4.dtype == torch.float32 and t4.numel() >= (1 << 14)
+            src = t4.permute(*fwd).contiguous().permute(*back) if relayout else t4
+            if _device.is_tensor(output) and not relayout:
                 out4 = output[(None,) * (4 - output.dim())]
+            elif relayout:
+                out4 = torch.empty_like(src.permute(*fwd)).permute(*back)
             else:
                 out4 = torch.empty_like(t4)
             kernels.pixelwise_nlmeans_3d(
-                t4, out4, r, f, self.sigma, self.h, self.n_eff,
+                src, out4, r, f, self.sigma, self.h, self.n_eff,
                 patch_mode=0 if self.patch_distances == 'reference' else 1)
-            if not _device.is_tensor(output):
+            if _device.is_tensor(output):
+                if out4.data_ptr() != output.data_ptr():
+                    output.copy_(out4.reshape(output.shape))
+            else:
                 _device.write_back(out4.reshape(t.shape), output)
 
 

@@ -321,3 +321,32 @@ def test_complex_torch_tensors_stay_on_device(oracle, device):
     assert ch.values.is_cuda
     yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
     np.testing.assert_array_equal(ch.values.cpu().numpy(), oracle.change_detection_planes(yxt, 0.9, 9).astype(bool))
+
+
+def test_nlmeans_dataset_paths_use_fast_layout(oracle, device):
+    """Datasets with the reference's (y, x, time) variables, large enough for the re-layout path:
+    dims ('y','x') and the tutorial's dims ('time','y','x') against the oracle on the stacked array."""
+    from nd_amd import xr_lite
+    from nd_amd.filters import NLMeansFilter
+    rng = np.random.default_rng(3)
+    names = ['C11', 'C12__im', 'C12__re', 'C22']
+    ds = xr_lite.Dataset()
+    data = {n: rng.gamma(4.0, 0.25, (40, 48, 6)).astype(np.float32) for n in names}
+    for n in names:
+        ds[n] = (('y', 'x', 'time'), data[n])
+    stacked = np.stack([data[n] for n in names], axis=-1)                  # (y, x, t, var)
+    # dims ('y', 'x'): reference-compatible and true-patch modes
+    for pd, pm in (('reference', 0), ('signed', 1)):
+        out = NLMeansFilter(dims=('y', 'x'), r=3, f=1, sigma=0.5, h=0.5, patch_distances=pd).apply(ds)
+        want = np.empty_like(stacked)
+        oracle.pixelwise_nlmeans_3d(stacked, want, (3, 3, 0), (1, 1, 0), 0.5, 0.5, -1, njobs=8, patch_mode=pm)
+        for i, n in enumerate(names):
+            np.testing.assert_allclose(out[n].values, want[..., i], rtol=1e-5)
+    # tutorial: dims ('time', 'y', 'x'), r = (1, 3, 3), n_eff
+    out = NLMeansFilter(dims=('time', 'y', 'x'), r=(1, 3, 3), f=1, sigma=0.5, h=0.5, n_eff=20).apply(ds)
+    st = np.ascontiguousarray(stacked.transpose(2, 0, 1, 3))               # (t, y, x, var)
+    want = np.empty_like(st)
+    oracle.pixelwise_nlmeans_3d(st, want, (1, 3, 3), (1, 1, 1), 0.5, 0.5, 20.0, njobs=8, patch_mode=0)
+    for i, n in enumerate(names):
+        assert out[n].dims == ('y', 'x', 'time')
+        np.testing.assert_array_equal(out[n].values, want[..., i].transpose(1, 2, 0))
