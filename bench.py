@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--looks', type=int, default=9)
     ap.add_argument('--alpha', type=float, default=0.99)
     ap.add_argument('--change-frac', type=float, default=0.01)
-    ap.add_argument('--cpu-rows', type=int, default=2048,
+    ap.add_argument('--cpu-rows', type=int, default=4096,
                     help='rows of the stack the CPU baseline is timed on (0 = skip)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch of the dominant kernel from a separate '
