@@ -350,3 +350,14 @@ def test_nlmeans_dataset_paths_use_fast_layout(oracle, device):
     for i, n in enumerate(names):
         assert out[n].dims == ('y', 'x', 'time')
         np.testing.assert_array_equal(out[n].values, want[..., i].transpose(1, 2, 0))
+
+
+def test_host_streamed_omnibus_equals_untiled(oracle, device):
+    """nd_amd.streaming: row tiles uploaded / computed / downloaded on overlapping streams give
+    the untiled change map (ragged last tile, float32 and float64)."""
+    from nd_amd import streaming
+    for dtype in (np.float32, np.float64):
+        planes = synth.omnibus_stack(seed=23, k=10, ny=150, nx=130, dtype=dtype, change_frac=0.2)
+        got = streaming.omnibus_streamed(planes, alpha=0.9, n=9, rows_per_tile=64)
+        yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+        np.testing.assert_array_equal(got, oracle.change_detection_planes(yxt, 0.9, 9, njobs=8))
