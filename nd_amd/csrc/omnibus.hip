@@ -140,6 +140,10 @@ struct OmniGlobalArgs {
 };
 
 constexpr int kGlobalThreads = 256;
+#ifndef ND_RETAIN_THREADS
+#define ND_RETAIN_THREADS 256
+#endif
+constexpr int kRetainThreads = ND_RETAIN_THREADS;   // block size of the register-retaining pass A
 constexpr int kShards = 128;
 constexpr int kCounterStride = 32;   // uint32 words between shard counters (128 B)
 #ifndef ND_TIME_CHUNK
@@ -308,7 +312,7 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 // EXACT: k == KMAX and stride_x == 1, so the per-date guards fold away, the loads issue as one
 // straight run and address a uniform base plus a 32-bit lane offset
 template <typename T, int KMAX, bool EXACT, bool STATS>
-__global__ void __launch_bounds__(kGlobalThreads)
+__global__ void __launch_bounds__(kRetainThreads)
 omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 {
     const int tid = threadIdx.x;
@@ -316,7 +320,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     const int64_t b = blockIdx.x;
     const int64_t row = b / g.blocks_per_row;
     const int64_t bx = b - row * g.blocks_per_row;
-    const int64_t bpx0 = bx * (int64_t)kGlobalThreads;
+    const int64_t bpx0 = bx * (int64_t)kRetainThreads;
     const int64_t x0 = bpx0 + tid;
     const int k = g.k;
     const bool in = x0 < g.nx;
@@ -359,7 +363,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     }
 
     if (g.write_tab && b == 0) {
-        for (int j = tid; j <= k; j += kGlobalThreads) g.tab_dev[j] = tab.e[j];
+        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
     }
 
     // ---- fold in time order ----
@@ -418,7 +422,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     // these stores (vmcnt retires in order). ----
     {
         const int64_t left = g.nx - bpx0;
-        const int npx = left > kGlobalThreads ? kGlobalThreads : (int)left;
+        const int npx = left > kRetainThreads ? kRetainThreads : (int)left;
         uint8_t *ob = g.change + (row * g.nx + bpx0) * (int64_t)k;
         const int nb = npx * k;                              // <= 256 * k bytes
         int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
@@ -426,7 +430,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
         if (tid < head) ob[tid] = 0;
         const int nvec = (nb - head) >> 4;
         uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
-        for (int i = tid; i < nvec; i += kGlobalThreads) store_zero16_nt(vz + i);
+        for (int i = tid; i < nvec; i += kRetainThreads) store_zero16_nt(vz + i);
         const int tail0 = head + (nvec << 4);
         if (tail0 + tid < nb) ob[tail0 + tid] = 0;
     }
@@ -687,7 +691,7 @@ constexpr size_t kCounterBytes = (size_t)kShards * kCounterStride * sizeof(uint3
 static uint32_t omni_seg(int64_t npix, int64_t ny)
 {
     static_assert(kShards == 128, "bound below assumes 128 shards");
-    const int64_t nb256 = ceil_div(npix, kGlobalThreads) + ny;
+    const int64_t nb256 = ceil_div(npix, 256) + ny;
     return (uint32_t)(2 * nb256 + (2 * ny + 256) * 4 + 256);
 }
 
@@ -721,7 +725,7 @@ template <typename T, int KMAX>
 static void launch_retain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_t nblocks,
                             bool stats, hipStream_t stream)
 {
-    const dim3 grid((unsigned)nblocks), block(kGlobalThreads);
+    const dim3 grid((unsigned)nblocks), block(kRetainThreads);
 #ifndef ND_RETAIN_EXACT
 #define ND_RETAIN_EXACT 1
 #endif
@@ -844,7 +848,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     g.nx = flat ? npix : nx;
     g.nrows = flat ? 1 : ny;
     const int ppt = retain ? 1 : (aligned ? VPPT : 1);
-    g.blocks_per_row = ceil_div(g.nx, (int64_t)kGlobalThreads * ppt);
+    g.blocks_per_row = ceil_div(g.nx, retain ? (int64_t)kRetainThreads : (int64_t)kGlobalThreads * ppt);
     const int64_t nblocks = g.blocks_per_row * g.nrows;
     if (nblocks > 0x7fffffffLL) {
         set_error("nd_amd_omnibus_c2: raster too large for one launch (%lld blocks)",

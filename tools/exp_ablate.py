@@ -46,16 +46,10 @@ def build_variant(name, patches, extra=()):
     subprocess.check_call([HIPCC] + FLAGS + list(extra) + ['-shared', '-o', so] + srcs)
     return so
 
-LISTC = """    if (__any(flag)) {
-        const unsigned long long m = __ballot(flag);
-        const unsigned shard = (unsigned)(b % kShards);"""
 VARIANTS = {
-    'base': [],
-    'nozero': [("        for (int i = tid; i < nvec; i += kGlobalThreads) store_zero16_nt(vz + i);", "        if (nvec < 0) store_zero16_nt(vz);")],
-    'nolist': [(LISTC, """    if (__any(flag) && g.k > 1000) {
-        const unsigned long long m = __ballot(flag);
-        const unsigned shard = (unsigned)(b % kShards);""")],
-    'nodump': [("            if (slot < g.dump_cap) {\n                T *d = g.dump + ((int64_t)shard", "            if (slot < g.dump_cap && g.k > 1000) {\n                T *d = g.dump + ((int64_t)shard")],
+    't256': [],
+    't128': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 128")],
+    't64': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 64")],
 }
 
 if __name__ == '__main__':
