@@ -15,7 +15,8 @@ from .algorithm import Algorithm, wrap_algorithm
 from .filters import BoxcarFilter
 from .io import disassemble_complex
 
-__all__ = ['ChangeDetection', 'OmnibusTest', 'omnibus', 'omnibus_statistics']
+__all__ = ['ChangeDetection', 'OmnibusTest', 'omnibus', 'omnibus_statistics', 'change_count',
+           'first_change']
 
 _VARS = ['C11', 'C12__re', 'C12__im', 'C22']      # column order of nd/change.py:66
 
@@ -122,3 +123,30 @@ def omnibus_statistics(ds, ml=None, n=1, alpha=0.01, device=None):
     z = -2 rho ln Q and the probability P of the global test over the whole series
     (nd/_change.pyx:46-77, 133-151).  Returns (change, z, P)."""
     return _omnibus_change_detection(ds, alpha=alpha, ml=ml, n=n, device=device, stats=True)
+
+
+def change_count(change):
+    """Number of detected changes per pixel, `change.sum('time')` of the tutorial
+    (examples/tutorial_s1.ipynb cell 20); keeps the container type and device of `change`."""
+    ns = _adapter.namespace(change)
+    ax = change.dims.index('time')
+    vals = change.values
+    data = vals.sum(dim=ax) if _device.is_tensor(vals) else vals.sum(axis=ax)
+    return ns.DataArray(data, dims=[d for d in change.dims if d != 'time'], attrs=change.attrs,
+                        name='change_count')
+
+
+def first_change(change):
+    """Index of the first detected change per pixel along 'time', -1 where there is none."""
+    ns = _adapter.namespace(change)
+    ax = change.dims.index('time')
+    vals = change.values
+    if _device.is_tensor(vals):
+        any_ = vals.any(dim=ax)
+        idx = vals.to(torch.uint8).argmax(dim=ax)
+        data = torch.where(any_, idx, torch.full_like(idx, -1))
+    else:
+        any_ = vals.any(axis=ax)
+        data = np.where(any_, vals.argmax(axis=ax), -1)
+    return ns.DataArray(data, dims=[d for d in change.dims if d != 'time'], attrs=change.attrs,
+                        name='first_change')

@@ -205,3 +205,15 @@ def test_filter_host_attributes():
     assert GaussianFilter(sigma=1.5)._buffer('x') == 6
     with pytest.raises(ValueError):
         NLMeansFilter(patch_distances='other')
+
+
+def test_change_summaries():
+    from nd_amd import xr_lite
+    from nd_amd.change import change_count, first_change
+    ch = np.zeros((2, 3, 5), bool)
+    ch[0, 0, 2] = ch[0, 0, 4] = ch[1, 2, 1] = True
+    da = xr_lite.DataArray(ch, ('y', 'x', 'time'), name='change')
+    np.testing.assert_array_equal(change_count(da).values, ch.sum(axis=2))
+    fc = first_change(da).values
+    assert fc[0, 0] == 2 and fc[1, 2] == 1 and fc[0, 1] == -1
+    assert change_count(da).dims == ('y', 'x')
