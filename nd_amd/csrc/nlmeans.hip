@@ -349,6 +349,234 @@ __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs 
     }
 }
 
+// ---- patch_mode 0, f > 0, rolling form -----------------------------------------------------
+// One block owns a 128 x 32 tile of ONE variable and walks the third axis.  The planes the window
+// needs along that axis live in an LDS ring of 2 rz + 1 slots (one slot when the axis is a plain
+// slice axis), so every plane is staged once per tile instead of once per output slice, and the
+// global loads of the next plane are in flight (held in registers) while the current slice is
+// computed.  A thread owns 4 x 4 pixels and reads each staged row ONCE for all four of its output
+// rows; two vertically adjacent outputs receive the same input element at the same step of their
+// (reference-ordered) running sums, so they share one packed float32 addition.
+typedef float nlm_f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kRollRowsPerWave = 13;          // (32 + 2 * 10) rows over 4 waves
+constexpr int kRollR0Max = 10;
+
+__device__ __forceinline__ float nlm_div_rounded(float s, double total, double inv_total)
+{
+    // (float)((double)s / total) without the division: s * (1/total) is within 3 ulp of the
+    // correctly rounded quotient, so both round to the same float unless the product sits within a
+    // few ulp of a float rounding boundary or leaves the normal float range -- then divide.
+    const double sd = (double)s;
+    double q = sd * inv_total;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(q);
+    const unsigned lo = (unsigned)bits & 0x1fffffffu;
+    const unsigned e = (unsigned)(bits >> 52) & 0x7ffu;
+    const bool risky = (lo - 0x0ffffff8u) <= 16u || e < 1023u - 125u || e > 1023u + 126u;
+    if (risky) q = sd / total;
+    return (float)q;
+}
+
+template <int R1>
+__global__ void __launch_bounds__(256) nlmeans_window_roll_kernel(const NlmTiledArgs a)
+{
+    constexpr int NW = ((2 * R1 + 4) + 3) / 4 * 4;     // floats a thread reads from one staged row
+    constexpr int COLSP = kWinTX - 4 + NW;             // row pitch (multiple of 4, >= COLS)
+    extern __shared__ __align__(16) unsigned char nd_smem_r[];
+    float *lds = reinterpret_cast<float *>(nd_smem_r); // [nzr][rows][COLSP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = a.r0, rz = a.rz;
+    const int rows = kWinTY + 2 * r0, psz = rows * COLSP, nzr = 2 * rz + 1;
+
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int ty = (int)(b % a.tiles_y);
+    const int v = (int)(b / a.tiles_y);
+    const int64_t y0 = a.clo0 + (int64_t)ty * kWinTY, x0 = a.clo1 + (int64_t)tx * kWinTX;
+    const int lx = (tid % 32) * 4, ly = (tid / 32) * 4;
+
+    const double nq = (double)(nzr * (2 * r0 + 1) * (2 * R1 + 1) - 1);
+    bool fail;
+    const double wself = nlm_self_weight(nq, nq, nq > 0 ? 1.0 : 0.0, a.n_eff, a.neff_policy,
+                                         a.status, &fail);
+    const double total = nq + wself;
+    const double inv_total = 1.0 / total;
+
+    // source column of each staged column this lane handles (whole-sample reflection in global
+    // coordinates; the clamps only keep never-used corner positions inside the allocation)
+    int xoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int m = nlm_reflect_i(a.off1 + x0 - R1 + lane + 64 * j, a.G1) - (int)a.off1;
+        xoff[j] = m < 0 ? 0 : (m >= (int)a.N1 ? (int)a.N1 - 1 : m);
+    }
+    const float *base = a.arr + (int64_t)v * a.si3;
+    const int64_t gy0 = a.off0 + y0 - r0;
+
+    float pre[kRollRowsPerWave][3];
+    auto load_plane = [&](int64_t p) {
+        const float *bp = base + p * a.si2;
+#pragma unroll
+        for (int u = 0; u < kRollRowsPerWave; ++u) {
+            const int rr = wave + 4 * u;
+            if (rr < rows) {
+                int m = nlm_reflect_i(gy0 + rr, a.G0) - (int)a.off0;
+                m = m < 0 ? 0 : (m >= (int)a.N0 ? (int)a.N0 - 1 : m);
+                const float *rp = bp + (int64_t)m * a.si0;
+                pre[u][0] = rp[xoff[0]];
+                pre[u][1] = rp[xoff[1]];
+                if (lane < 2 * R1) pre[u][2] = rp[xoff[2]];
+            }
+        }
+    };
+    auto store_plane = [&](int slot) {
+        float *sp = lds + slot * psz;
+#pragma unroll
+        for (int u = 0; u < kRollRowsPerWave; ++u) {
+            const int rr = wave + 4 * u;
+            if (rr < rows) {
+                float *rp = sp + rr * COLSP + lane;
+                rp[0] = pre[u][0];
+                rp[64] = pre[u][1];
+                if (lane < 2 * R1) rp[128] = pre[u][2];
+            }
+        }
+    };
+    // local plane that stands for logical slice q of the window
+    auto zmap = [&](int64_t q) {
+        int64_t zz = (int64_t)nlm_reflect_i(a.offz + q, a.Gz) - a.offz;
+        return zz < 0 ? (int64_t)0 : (zz >= a.N2 ? a.N2 - 1 : zz);
+    };
+
+    {
+        const int64_t lo = a.clo2 - rz < 0 ? 0 : a.clo2 - rz;
+        const int64_t hi = a.clo2 + rz > a.N2 - 1 ? a.N2 - 1 : a.clo2 + rz;
+        for (int64_t p = lo; p <= hi; ++p) {
+            load_plane(p);
+            store_plane((int)(p % nzr));
+        }
+    }
+    __syncthreads();
+
+    const bool vec_ok = ((((uintptr_t)a.out) & 15) == 0) && ((a.so0 | a.so2 | a.so3 | x0) & 3) == 0;
+
+    for (int64_t i2 = a.clo2; i2 < a.chi2; ++i2) {
+        const int64_t nxt = i2 + rz + 1;
+        const bool has_next = (nxt <= a.N2 - 1) && (i2 + 1 < a.chi2);
+        if (has_next) load_plane(nxt);
+
+        nlm_f32x2 acc[2][4];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[pr][i] = (nlm_f32x2){0.f, 0.f};
+
+        // the reference's visiting order: third-axis offset outermost when it is a window axis,
+        // then rows, columns innermost; the centre is skipped here and added last
+        for (int dz = 0; dz < nzr; ++dz) {
+            const float *P = lds + (int)(zmap(i2 + dz - rz) % nzr) * psz + ly * COLSP + lx;
+            const bool cplane = (dz == rz);
+#pragma unroll 1
+            for (int ry = 0; ry < 4 + 2 * r0; ++ry) {
+                float w[NW];
+                const float4 *rp = reinterpret_cast<const float4 *>(P + ry * COLSP);
+#pragma unroll
+                for (int c = 0; c < NW / 4; ++c) {
+                    const float4 t = rp[c];
+                    w[4 * c + 0] = t.x;
+                    w[4 * c + 1] = t.y;
+                    w[4 * c + 2] = t.z;
+                    w[4 * c + 3] = t.w;
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    // window row index of this input row for the pair's upper / lower output row
+                    const int du = ry - 2 * pr, dl = du - 1;
+                    const bool vu = du >= 0 && du <= 2 * r0, vl = dl >= 0 && dl <= 2 * r0;
+                    const bool cu = cplane && du == r0, cl = cplane && dl == r0;
+                    if (vu && vl && !cu && !cl) {
+#pragma unroll
+                        for (int dx = 0; dx < 2 * R1 + 1; ++dx)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[pr][i] = acc[pr][i] + (nlm_f32x2){w[dx + i], w[dx + i]};
+                    } else {
+                        if (vu) {
+#pragma unroll
+                            for (int dx = 0; dx < 2 * R1 + 1; ++dx)
+                                if (!(cu && dx == R1)) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) acc[pr][i].x = acc[pr][i].x + w[dx + i];
+                                }
+                        }
+                        if (vl) {
+#pragma unroll
+                            for (int dx = 0; dx < 2 * R1 + 1; ++dx)
+                                if (!(cl && dx == R1)) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) acc[pr][i].y = acc[pr][i].y + w[dx + i];
+                                }
+                        }
+                    }
+                }
+            }
+        }
+
+        if (!fail) {
+            const float *C = lds + (int)(i2 % nzr) * psz + (ly + r0) * COLSP + lx + R1;
+#pragma unroll
+            for (int py = 0; py < 4; ++py) {
+                const int64_t y = y0 + ly + py;
+                if (y < a.chi0) {
+                    float res[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float ws = (py & 1) ? acc[py >> 1][i].y : acc[py >> 1][i].x;
+                        // self term last (nd/_filters.pyx:417-420), weights are exactly 1 / wself
+                        const float sv = (float)((double)ws + (wself * (double)C[py * COLSP + i]));
+                        res[i] = nlm_div_rounded(sv, total, inv_total);
+                    }
+                    float *o = a.out + i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x0 + lx;
+                    if (vec_ok && x0 + lx + 3 < a.chi1) {
+                        *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (x0 + lx + i < a.chi1) o[i] = res[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();                       // every wave is done with the oldest plane
+        if (has_next) store_plane((int)(nxt % nzr));
+        __syncthreads();
+    }
+}
+
+template <int R1>
+static void launch_roll(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
+{
+    hipLaunchKernelGGL((nlmeans_window_roll_kernel<R1>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+}
+
+static bool launch_roll_r1(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
+{
+    switch (a.r1) {
+    case 0: launch_roll<0>(a, nb, lds, stream); return true;
+    case 1: launch_roll<1>(a, nb, lds, stream); return true;
+    case 2: launch_roll<2>(a, nb, lds, stream); return true;
+    case 3: launch_roll<3>(a, nb, lds, stream); return true;
+    case 4: launch_roll<4>(a, nb, lds, stream); return true;
+    case 5: launch_roll<5>(a, nb, lds, stream); return true;
+    case 6: launch_roll<6>(a, nb, lds, stream); return true;
+    case 7: launch_roll<7>(a, nb, lds, stream); return true;
+    case 8: launch_roll<8>(a, nb, lds, stream); return true;
+    case 9: launch_roll<9>(a, nb, lds, stream); return true;
+    case 10: launch_roll<10>(a, nb, lds, stream); return true;
+    default: return false;
+    }
+}
+
 // ---- patch_mode 1: sliding patch-row sums ---------------------------------------------------
 template <int F, int V, int TYW, bool NEFF>
 __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a)
@@ -612,6 +840,16 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
         if (a.r1 > 16) return 0;
         a.tiles_x = (int)ceil_div(ex, kWinTX);
         a.tiles_y = (int)ceil_div(ey, kWinTY);
+        static const bool no_roll = getenv("ND_AMD_NLM_NOROLL") != nullptr;
+        if (!no_roll && a.r0 <= kRollR0Max && a.r1 <= 10) {
+            const size_t nw = ((2 * (size_t)a.r1 + 4) + 3) / 4 * 4;
+            const size_t lds_r = (size_t)(2 * rz + 1) * (kWinTY + 2 * a.r0) * (kWinTX - 4 + nw) * sizeof(float);
+            const int64_t nbr = (int64_t)a.tiles_x * a.tiles_y * nvars;
+            if (lds_r <= 64 * 1024 && nbr <= 0x7fffffffLL) {
+                KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
+                if (launch_roll_r1(a, nbr, lds_r, stream)) return 1;
+            }
+        }
         const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nsl;
         const size_t rows = kWinTY + 2 * a.r0, cols = kWinTX + 2 * a.r1;
         const size_t lds = (size_t)(2 * rz + 1) * rows * cols * sizeof(float) +

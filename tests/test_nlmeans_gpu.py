@@ -235,3 +235,58 @@ def test_time_first_layout_patch_kernel_and_tiles(oracle, device):
             acc[:, :, lo:hi] = tout[:, :, lo - tlo:hi - tlo]
         torch.cuda.synchronize()
         assert torch.equal(acc, ref)
+
+
+def test_window_kernel_magnitudes_and_rounding(oracle, device):
+    """Unit-weight window kernel over data spanning the float32 range (zeros, negatives, values near
+    the subnormal and overflow ends): the normalisation (float)((double)sum / total) must round like
+    the reference's division for every element, with integer and fractional totals."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(52)
+    shape = (4, 96, 260, 2)
+    a = rng.gamma(4.0, 0.25, shape)
+    scale = 10.0 ** rng.integers(-36, 34, (1, 96 // 8, 260 // 10, 1)).astype(np.float64)
+    a = a * np.repeat(np.repeat(scale, 8, axis=1), 10, axis=2)
+    a[:, 10:20, 30:80] = 0.0
+    a[:, 40:60, 100:150] *= -1.0
+    a = a.astype(np.float32)
+    planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)
+    for r, f, ne in (((1, 3, 3), (1, 1, 1), 50.0), ((1, 3, 3), (1, 1, 1), -1), ((0, 10, 10), (0, 3, 3), -1),
+                     ((1, 2, 5), (1, 1, 1), 7.5)):
+        want = np.empty_like(a)
+        with np.errstate(all='ignore'):
+            oracle.pixelwise_nlmeans_3d(a, want, r, f, 0.5, 0.5, ne, neff_policy=0, njobs=8, patch_mode=0)
+        out = torch.empty_like(planar)
+        kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, 0.5, 0.5, ne,
+                                     patch_mode=0, neff_policy=0)
+        torch.cuda.synchronize()
+        got = out.permute(1, 2, 3, 0).cpu().numpy()
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_window_kernel_partial_core_on_every_axis(device):
+    """Written range restricted along the window's outermost axis too (a tile of a longer series)."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(53)
+    full = torch.from_numpy(rng.gamma(4.0, 0.25, (2, 9, 50, 140)).astype(np.float32)).to(device)  # (var,t,y,x)
+    r, f = (2, 3, 3), (1, 1, 1)
+    ref = torch.empty_like(full)
+    kernels.pixelwise_nlmeans_3d(full.permute(1, 2, 3, 0), ref.permute(1, 2, 3, 0), r, f, 0.5, 0.5, -1,
+                                 patch_mode=0)
+    acc = torch.zeros_like(full)
+    for lo, hi in [(0, 4), (4, 9)]:
+        tlo, thi = max(lo - r[0], 0), min(hi + r[0], 9)
+        tile = full[:, tlo:thi].contiguous()
+        tout = torch.full_like(tile, -7.0)
+        kernels.pixelwise_nlmeans_3d(tile.permute(1, 2, 3, 0), tout.permute(1, 2, 3, 0), r, f, 0.5, 0.5, -1,
+                                     patch_mode=0, global_shape=(9, 50, 140), tile_offset=(tlo, 0, 0),
+                                     core=((lo - tlo, hi - tlo), (3, 47), (5, 133)))
+        acc[:, lo:hi, 3:47, 5:133] = tout[:, lo - tlo:hi - tlo, 3:47, 5:133]
+        # nothing outside the core is written
+        probe = tout.clone()
+        probe[:, lo - tlo:hi - tlo, 3:47, 5:133] = -7.0
+        assert bool((probe == -7.0).all())
+    torch.cuda.synchronize()
+    assert torch.equal(acc[:, :, 3:47, 5:133], ref[:, :, 3:47, 5:133])
