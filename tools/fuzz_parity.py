@@ -1,0 +1,233 @@
+"""Randomised parity campaign: the HIP path (through the C ABI) against the CPU oracle on random
+shapes, strides, parameters and corner values.  Not part of the pytest suite (run time is open
+ended); every failure it ever found became a fixed case in tests/.
+
+    python tools/fuzz_parity.py --seconds 120 --seed 1 [--what omnibus,nlmeans,correlate,gaussian,c3]
+
+Prints one line per failure (with the parameters needed to replay it) and a summary; exit code 1
+if anything differed."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from nd_amd import kernels
+from oracle import oracle as O
+
+DEV = torch.device('cuda:0')
+
+
+def wishart(rng, k, ny, nx, looks, dtype, pol=2):
+    s = (rng.normal(size=(pol, looks, k, ny, nx)) + 1j * rng.normal(size=(pol, looks, k, ny, nx))) / np.sqrt(2)
+    out = {}
+    for i in range(pol):
+        out['C%d%d' % (i + 1, i + 1)] = (np.abs(s[i]) ** 2).mean(axis=0)
+        for j in range(i + 1, pol):
+            c = (s[i] * np.conj(s[j])).mean(axis=0)
+            out['C%d%dre' % (i + 1, j + 1)] = c.real
+            out['C%d%dim' % (i + 1, j + 1)] = c.imag
+    return {n: v.astype(dtype) for n, v in out.items()}
+
+
+def case_omnibus(rng):
+    k = int(rng.choice([2, 3, 5, 8, 9, 12, 16, 17, 24, 25, 31, 32, 33, 40, 48, 49, 60]))
+    ny, nx = int(rng.integers(1, 40)), int(rng.integers(1, 300))
+    looks = int(rng.choice([1, 2, 4, 9, 20]))
+    dtype = rng.choice([np.float32, np.float64])
+    alpha = float(rng.choice([0.01, 0.5, 0.9, 0.99, 0.999, 0.9999, 1e-4]))
+    n = int(rng.choice([looks, 1, 3]))
+    w = wishart(rng, k, ny, nx, looks, dtype)
+    planes = [w['C11'], w['C12re'], w['C12im'], w['C22']]
+    # step changes, zeros, NaNs, infinities, negative determinants
+    if rng.random() < 0.7:
+        m = rng.random((ny, nx)) < 0.3
+        t0 = rng.integers(1, k, (ny, nx)) if k > 1 else np.zeros((ny, nx), int)
+        g = np.where((np.arange(k)[:, None, None] >= t0[None]) & m[None], rng.choice([0.1, 4.0, 30.0]), 1.0)
+        planes = [(p * g).astype(dtype) for p in planes]
+    if rng.random() < 0.3:
+        bad = rng.random((k, ny, nx)) < 0.01
+        val = rng.choice([0.0, np.nan, np.inf, -1.0])
+        planes[int(rng.integers(0, 4))][bad] = val
+    layout = rng.choice(['tyx', 'yxt', 'pad'])
+    desc = dict(k=k, ny=ny, nx=nx, looks=looks, dtype=np.dtype(dtype).name, alpha=alpha, n=n, layout=str(layout))
+    with np.errstate(all='ignore'):
+        want, zw, pw = O.change_detection_planes([np.moveaxis(p, 0, -1) for p in planes], alpha, n, njobs=8, stats=True)
+    if layout == 'tyx':
+        dev = [torch.from_numpy(p).to(DEV) for p in planes]
+        dims = ('time', 'y', 'x')
+    elif layout == 'yxt':
+        dev = [torch.from_numpy(np.ascontiguousarray(np.moveaxis(p, 0, -1))).to(DEV) for p in planes]
+        dims = ('y', 'x', 'time')
+    else:
+        big = torch.zeros((4, k, ny + 2, nx + 5), dtype=torch.from_numpy(planes[0]).dtype, device=DEV)
+        for v in range(4):
+            big[v, :, 1:ny + 1, 3:nx + 3] = torch.from_numpy(planes[v]).to(DEV)
+        dev = [big[v, :, 1:ny + 1, 3:nx + 3] for v in range(4)]
+        dims = ('time', 'y', 'x')
+    stats = bool(rng.random() < 0.5)
+    ws = str(rng.choice(['recommended', 'minimal']))
+    desc.update(stats=stats, workspace=ws)
+    res = kernels.change_detection(*dev, alpha=alpha, n=n, dims=dims, stats=stats, workspace=ws)
+    got = (res[0] if stats else res).cpu().numpy()
+    ok = np.array_equal(got, want)
+    if ok and stats:
+        z, P = res[1].cpu().numpy(), res[2].cpu().numpy()
+        with np.errstate(all='ignore'):
+            ok = (np.allclose(z, zw, rtol=1e-5, atol=0, equal_nan=True) and
+                  np.allclose(P, pw, rtol=1e-5, atol=1e-7, equal_nan=True))
+    return ok, desc
+
+
+def case_c3(rng):
+    k = int(rng.choice([2, 4, 7, 12, 24, 33]))
+    ny, nx = int(rng.integers(1, 20)), int(rng.integers(1, 200))
+    looks = int(rng.choice([3, 9, 16]))
+    dtype = rng.choice([np.float32, np.float64])
+    alpha = float(rng.choice([0.5, 0.9, 0.99, 0.9999]))
+    w = wishart(rng, k, ny, nx, looks, dtype, pol=3)
+    names = ['C11', 'C22', 'C33', 'C12re', 'C12im', 'C13re', 'C13im', 'C23re', 'C23im']
+    planes = [w[n] for n in names]
+    if rng.random() < 0.7:
+        m = rng.random((ny, nx)) < 0.3
+        t0 = rng.integers(1, k, (ny, nx))
+        g = np.where((np.arange(k)[:, None, None] >= t0[None]) & m[None], 5.0, 1.0)
+        planes = [(p * g).astype(dtype) for p in planes]
+    desc = dict(k=k, ny=ny, nx=nx, looks=looks, dtype=np.dtype(dtype).name, alpha=alpha)
+    with np.errstate(all='ignore'):
+        want = O.change_detection_pol([np.moveaxis(p, 0, -1) for p in planes], 3, alpha, looks, njobs=8)
+    dev = [torch.from_numpy(p).to(DEV) for p in planes]
+    got = kernels.change_detection_c3(dev, alpha=alpha, n=looks).cpu().numpy()
+    return np.array_equal(got, want), desc
+
+
+def case_nlmeans(rng):
+    layout = str(rng.choice(['A', 'B', 'C']))
+    nv = int(rng.choice([1, 1, 2, 4, 5]))
+    pm = int(rng.choice([0, 1]))
+    dtype = np.float32 if rng.random() < 0.8 else np.float64
+    if layout == 'A':            # (y, x, time, var) view of planar memory, 2-D window
+        shape = (int(rng.integers(12, 80)), int(rng.integers(12, 200)), int(rng.integers(1, 4)), nv)
+        r = (int(rng.integers(0, 6)), int(rng.integers(0, 6)), 0)
+        f = (int(rng.integers(0, 3)),) * 2 + (0,) if rng.random() < 0.7 else (int(rng.integers(0, 3)), int(rng.integers(0, 3)), 0)
+        perm = (3, 2, 0, 1)
+    elif layout == 'B':          # (time, y, x, var) view of planar memory, 3-D window
+        shape = (int(rng.integers(3, 8)), int(rng.integers(12, 60)), int(rng.integers(12, 200)), nv)
+        r = (int(rng.integers(0, 3)), int(rng.integers(0, 5)), int(rng.integers(0, 5)))
+        f = tuple(int(v) for v in rng.integers(0, 2, 3))
+        perm = (3, 0, 1, 2)
+    else:                        # C-contiguous (a, b, c, var): generic kernel
+        shape = (int(rng.integers(3, 12)), int(rng.integers(5, 30)), int(rng.integers(5, 40)), nv)
+        r = tuple(int(v) for v in rng.integers(0, 3, 3))
+        f = tuple(int(v) for v in rng.integers(0, 2, 3))
+        perm = None
+    for d in range(3):           # keep a single reflection inside the array
+        reach = r[d] + f[d]
+        if reach > shape[d] - 1:
+            r = tuple(0 if i == d else r[i] for i in range(3)); f = tuple(0 if i == d else f[i] for i in range(3))
+    sigma, h = float(rng.choice([0.3, 0.5, 1.0, 2.0])), float(rng.choice([0.3, 0.5, 1.0, 2.0]))
+    ne = float(rng.choice([-1, -1, 3.0, 10.0, 50.0]))
+    nq = (2 * r[0] + 1) * (2 * r[1] + 1) * (2 * r[2] + 1) - 1
+    if ne == nq + 1:
+        # ill-posed corner of find_weight (nd/_filters.pyx:296-315): with n_eff - 1 equal to the
+        # number of neighbours, equal weights put the discriminant at exactly 0 +- rounding noise,
+        # and whether the reference returns a number or NaN depends on the last ulp of libm's exp
+        ne = float(nq + 2)
+    a = rng.gamma(4.0, 0.25, shape).astype(dtype)
+    if rng.random() < 0.3:
+        a -= a.mean().astype(dtype)
+    desc = dict(layout=layout, shape=shape, r=r, f=f, sigma=sigma, h=h, n_eff=ne, patch_mode=pm, dtype=np.dtype(dtype).name)
+    want = np.empty_like(a)
+    with np.errstate(all='ignore'):
+        O.pixelwise_nlmeans_3d(a, want, r, f, sigma, h, ne, neff_policy=0, njobs=8, patch_mode=pm)
+    t = torch.from_numpy(a).to(DEV)
+    if perm is not None:
+        inv = [perm.index(i) for i in range(4)]
+        t = t.permute(*perm).contiguous().permute(*inv)
+    out = torch.empty_like(t)
+    kernels.pixelwise_nlmeans_3d(t, out, r, f, sigma, h, ne, patch_mode=pm, neff_policy=0)
+    got = out.cpu().numpy()
+    uniform = pm == 0 and max(f) > 0
+    if uniform or dtype == np.float64 and False:
+        ok = np.array_equal(got, want, equal_nan=True)
+    else:
+        scale = float(np.abs(a).max())
+        ok = np.allclose(got, want, rtol=1e-5, atol=2e-6 * scale, equal_nan=True)
+    return ok, desc
+
+
+def case_correlate(rng):
+    nd = int(rng.choice([2, 3]))
+    dtype = np.float32 if rng.random() < 0.7 else np.float64
+    shape = tuple(int(v) for v in (rng.integers(1, 6, nd - 2).tolist() + [rng.integers(1, 70), rng.integers(1, 300)]))
+    ksh = tuple(int(v) for v in ([1] * (nd - 2) if rng.random() < 0.7 else rng.integers(1, 4, nd - 2).tolist()) +
+                rng.integers(1, 8, 2).tolist())
+    kind = str(rng.choice(['box', 'rand', 'sparse']))
+    if kind == 'box':
+        kern = np.ones(ksh) / np.prod(ksh)
+    else:
+        kern = rng.normal(size=ksh)
+        if kind == 'sparse':
+            kern[rng.random(ksh) < 0.4] = 0.0
+            if not kern.any():
+                kern.flat[0] = 1.0
+    mode = str(rng.choice(['reflect', 'constant', 'nearest', 'mirror', 'wrap']))
+    cval = float(rng.choice([0.0, 1.5]))
+    origin = 0
+    a = rng.normal(size=shape).astype(dtype)
+    desc = dict(shape=shape, kernel=ksh, kind=kind, mode=mode, cval=cval, dtype=np.dtype(dtype).name)
+    want = O.convolve(a, kern, mode=mode, cval=cval, origin=origin)
+    t = torch.from_numpy(a).to(DEV)
+    if rng.random() < 0.3 and nd == 3:          # (y, x, time)-style memory: window axes are not the fastest
+        t = t.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+        desc['strided'] = True
+    got = kernels.convolve(t, kern, mode=mode, cval=cval, origin=origin).cpu().numpy()
+    return np.array_equal(got, want, equal_nan=True), desc
+
+
+def case_gaussian(rng):
+    import scipy.ndimage as snf
+    nd = int(rng.choice([2, 3]))
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    shape = tuple(int(v) for v in rng.integers(1, 60, nd))
+    sigma = tuple(float(v) for v in rng.choice([0.0, 0.5, 1.0, 2.5, 7.0], nd))
+    mode = str(rng.choice(['reflect', 'constant', 'nearest', 'mirror', 'wrap']))
+    a = rng.normal(size=shape).astype(dtype)
+    desc = dict(shape=shape, sigma=sigma, mode=mode, dtype=np.dtype(dtype).name)
+    want = snf.gaussian_filter(a, sigma=sigma, mode=mode)
+    got = kernels.gaussian_filter(torch.from_numpy(a).to(DEV), sigma, mode=mode).cpu().numpy()
+    return np.array_equal(got, want, equal_nan=True), desc
+
+
+CASES = {'omnibus': case_omnibus, 'c3': case_c3, 'nlmeans': case_nlmeans, 'correlate': case_correlate,
+         'gaussian': case_gaussian}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seconds', type=float, default=60.0)
+    ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--what', default=','.join(CASES))
+    a = ap.parse_args()
+    names = a.what.split(',')
+    O.build()
+    count = {n: 0 for n in names}
+    fails = 0
+    t_end = time.time() + a.seconds
+    i = 0
+    while time.time() < t_end:
+        name = names[i % len(names)]
+        rng = np.random.default_rng([a.seed, i])
+        try:
+            ok, desc = CASES[name](rng)
+        except Exception as e:                       # an error is a failure too
+            ok, desc = False, {'exception': repr(e)}
+        count[name] += 1
+        if not ok:
+            fails += 1
+            print('FAIL %s seed=(%d,%d) %s' % (name, a.seed, i, desc), flush=True)
+        i += 1
+    print('cases', count, 'failures', fails)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == '__main__':
+    main()
