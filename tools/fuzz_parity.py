@@ -1,6 +1,6 @@
 """Randomised parity campaign: the HIP path (through the C ABI) against the CPU oracle on random
 shapes, strides, parameters and corner values.  Not part of the pytest suite (run time is open
-ended); every failure it ever found became a fixed case in tests/.
+ended); what it finds is either fixed with a regression case in tests/ or recorded in DESIGN.md 9.
 
     python tools/fuzz_parity.py --seconds 120 --seed 1 [--what omnibus,nlmeans,correlate,gaussian,c3]
 
