@@ -42,24 +42,24 @@ def iscomplexobj(a):
 
 
 def get_vars_for_dims(ds, dims, invert=False):
-    return [v for v in ds.data_vars
-            if set(ds[v].dims).issuperset(set(dims)) != invert]
+    """Names of the variables that carry every dimension in `dims` (or, inverted, the others)."""
+    wanted = set(dims)
+    return [name for name in ds.data_vars if wanted.issubset(ds[name].dims) is not invert]
 
 
 def expand_variables(da, dim='variable'):
+    """Undo `Dataset.to_array()`: one variable per label of `dim`; the array's attributes move to
+    the dataset."""
     if namespace(da) is xr_lite:
         return xr_lite.expand_variables(da, dim)
-    _vars = []
-    attrs = da.attrs
-    da.attrs = {}
-    for v in da[dim]:
-        _var = da.sel(**{dim: v})
-        _var.name = str(_var[dim].values)
-        del _var[dim]
-        _vars.append(_var)
-    result = xr.merge(_vars)
-    result.attrs = attrs
-    return result
+    pieces = {}
+    for label in da[dim].values:
+        piece = da.sel(**{dim: label}).drop_vars(dim)
+        piece.attrs = {}
+        pieces[str(label)] = piece
+    out = xr.Dataset(pieces)
+    out.attrs = dict(da.attrs)
+    return out
 
 
 def is_complex(ds):
@@ -88,14 +88,16 @@ def xr_split(ds, dim, chunks, buffer=0):
 
 
 def xr_merge(ds_list, dim, buffer=0):
+    """Concatenate chunks produced by xr_split, dropping the `buffer` samples each chunk shares
+    with its neighbours (the outer ends of the first and last chunk were never extended)."""
     ns = namespace(ds_list[0])
-    if buffer > 0 and len(ds_list) > 1:
-        idx_first = slice(None, -int(buffer))
-        idx_middle = slice(int(buffer), -int(buffer))
-        idx_end = slice(int(buffer), None)
-        parts = [ds_list[0].isel(**{dim: idx_first})] + \
-                [ds.isel(**{dim: idx_middle}) for ds in ds_list[1:-1]] + \
-                [ds_list[-1].isel(**{dim: idx_end})]
-    else:
-        parts = ds_list
-    return ns.concat(parts, dim=dim)
+    halo = int(buffer)
+    last = len(ds_list) - 1
+    if halo > 0 and last > 0:
+        trimmed = []
+        for i, part in enumerate(ds_list):
+            start = halo if i > 0 else None
+            stop = -halo if i < last else None
+            trimmed.append(part.isel(**{dim: slice(start, stop)}))
+        ds_list = trimmed
+    return ns.concat(ds_list, dim=dim)

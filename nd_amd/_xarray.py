@@ -12,30 +12,34 @@ except Exception:            # pragma: no cover - xarray absent here
     xr = None
 
 
+# accessor method -> (module, function form of the algorithm)
+_METHODS = {
+    'change_omnibus': ('change', 'omnibus'),
+    'nlmeans': ('filters', 'nlmeans'),
+    'boxcar': ('filters', 'boxcar'),
+    'convolve': ('filters', 'convolution'),
+    'gaussian': ('filters', 'gaussian'),
+}
+
+
+def _forward(target):
+    def method(accessor, *args, **kwargs):
+        return target(accessor._obj, *args, **kwargs)
+    method.__name__ = target.__name__
+    method.__doc__ = target.__doc__
+    return method
+
+
 def register():
+    """Attach the `nd_amd` accessor to xarray Datasets and DataArrays; False without xarray."""
     if xr is None:
         return False
     from . import change, filters
-
-    class _Accessor:
-        def __init__(self, obj):
-            self._obj = obj
-
-        def change_omnibus(self, *args, **kwargs):
-            return change.omnibus(self._obj, *args, **kwargs)
-
-        def nlmeans(self, *args, **kwargs):
-            return filters.nlmeans(self._obj, *args, **kwargs)
-
-        def boxcar(self, *args, **kwargs):
-            return filters.boxcar(self._obj, *args, **kwargs)
-
-        def convolve(self, *args, **kwargs):
-            return filters.convolution(self._obj, *args, **kwargs)
-
-        def gaussian(self, *args, **kwargs):
-            return filters.gaussian(self._obj, *args, **kwargs)
-
-    xr.register_dataset_accessor('nd_amd')(_Accessor)
-    xr.register_dataarray_accessor('nd_amd')(_Accessor)
+    modules = {'change': change, 'filters': filters}
+    namespace = {'__init__': lambda accessor, obj: setattr(accessor, '_obj', obj)}
+    for name, (module, function) in _METHODS.items():
+        namespace[name] = _forward(getattr(modules[module], function))
+    accessor = type('NdAmdAccessor', (), namespace)
+    xr.register_dataset_accessor('nd_amd')(accessor)
+    xr.register_dataarray_accessor('nd_amd')(accessor)
     return True

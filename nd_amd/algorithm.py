@@ -62,32 +62,32 @@ def parallel(fn, dim=None, chunks=None, buffer=0):
 
 
 def parallelize(func):
-    def wrapper(self, ds, *args, njobs=1, **kwargs):
-        method = partial(func, self)
-        if njobs == -1:
-            njobs = mp.cpu_count()
-        if njobs == 1:
-            return method(ds, *args, **kwargs)
-        dim = self._parallel_dimension(ds)
-        buffer = self._buffer(dim)
-        # never more chunks than the dimension can carry with its halo
-        n = ds.sizes[dim]
-        chunks = max(1, min(int(njobs), n // max(1, 2 * int(buffer) + 1)))
-        if chunks == 1:
-            return method(ds, *args, **kwargs)
-        return parallel(method, dim=dim, chunks=chunks, buffer=buffer)(ds, *args, **kwargs)
+    """Give `func(self, ds, ...)` the keyword-only argument `njobs` (nd/algorithm.py:38-105):
+    1 = call `func` on the whole dataset, -1 = one chunk per CPU core, n = n chunks along
+    `self._parallel_dimension(ds)`, each extended by `self._buffer(dim)` and trimmed on merge."""
 
-    sig_func = inspect.signature(func)
-    sig_wrapper = inspect.signature(wrapper)
-    parameters = tuple(sig_func.parameters.values()) + (sig_wrapper.parameters['njobs'],)
-    wrapper.__signature__ = sig_func.replace(parameters=_sorted_parameters(parameters))
-    doc = func.__doc__ or ''
-    wrapper.__doc__ = doc.rstrip() + (
+    def run(self, ds, *args, njobs=1, **kwargs):
+        call = partial(func, self)
+        chunks = mp.cpu_count() if njobs == -1 else int(njobs)
+        if chunks > 1:
+            dim = self._parallel_dimension(ds)
+            halo = int(self._buffer(dim))
+            # never more chunks than the dimension can carry with its halo
+            chunks = max(1, min(chunks, ds.sizes[dim] // (2 * halo + 1)))
+            if chunks > 1:
+                return parallel(call, dim=dim, chunks=chunks, buffer=halo)(ds, *args, **kwargs)
+        return call(ds, *args, **kwargs)
+
+    own = inspect.signature(func)
+    njobs_param = inspect.signature(run).parameters['njobs']
+    run.__signature__ = own.replace(
+        parameters=_sorted_parameters(tuple(own.parameters.values()) + (njobs_param,)))
+    run.__doc__ = (func.__doc__ or '').rstrip() + (
         '\n        njobs : int, optional\n'
         '            Number of chunks to process separately (halo-buffered, merged afterwards).\n'
         '            -1 uses the number of available cores; 1 disables chunking (default).\n')
-    wrapper.__name__ = getattr(func, '__name__', 'apply')
-    return wrapper
+    run.__name__ = getattr(func, '__name__', 'apply')
+    return run
 
 
 def extract_arguments(fn, args, kwargs):
@@ -108,24 +108,24 @@ def extract_arguments(fn, args, kwargs):
 
 
 def wrap_algorithm(algo, name=None):
+    """Function form of an Algorithm class (nd/algorithm.py:108-198): `f(ds, <init arguments>)` builds
+    `algo(<init arguments>)` and returns its `.apply(ds)`; arguments of `apply` itself (such as
+    `njobs`) are recognised by name."""
     if not (inspect.isclass(algo) and issubclass(algo, Algorithm)):
         raise ValueError('Class must be an instance of `nd.Algorithm`.')
 
-    def _wrapper(*args, **kwargs):
-        apply_kwargs = dict(extract_arguments(algo.apply, args, kwargs))
-        init_args = apply_kwargs.pop('args', ())
-        init_kwargs = apply_kwargs.pop('kwargs', {})
-        return algo(*init_args, **init_kwargs).apply(**apply_kwargs)
+    def function(*args, **kwargs):
+        for_apply = dict(extract_arguments(algo.apply, args, kwargs))
+        instance = algo(*for_apply.pop('args', ()), **for_apply.pop('kwargs', {}))
+        return instance.apply(**for_apply)
 
-    _wrapper.__module__ = algo.__module__
+    function.__module__ = algo.__module__
     if name is not None:
-        _wrapper.__name__ = name
-        _wrapper.__qualname__ = name
-    sig_init = inspect.signature(algo.__init__)
-    sig_apply = inspect.signature(algo.apply)
-    parameters = tuple(sig_apply.parameters.values())[1:] + \
-        tuple(sig_init.parameters.values())[1:]
-    _wrapper.__signature__ = sig_init.replace(parameters=_sorted_parameters(parameters))
-    link = ':class:`{}.{}`'.format(algo.__module__, algo.__name__)
-    _wrapper.__doc__ = 'Wrapper for {}.\n\n{}'.format(link, algo.__doc__ or '')
-    return _wrapper
+        function.__name__ = function.__qualname__ = name
+    init_sig = inspect.signature(algo.__init__)
+    merged = [p for sig in (inspect.signature(algo.apply), init_sig)
+              for p in list(sig.parameters.values())[1:]]                 # drop `self`
+    function.__signature__ = init_sig.replace(parameters=_sorted_parameters(merged))
+    function.__doc__ = 'Wrapper for :class:`{}.{}`.\n\n{}'.format(algo.__module__, algo.__name__,
+                                                                  algo.__doc__ or '')
+    return function

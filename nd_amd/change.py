@@ -22,6 +22,7 @@ _VARS = ['C11', 'C12__re', 'C12__im', 'C22']      # column order of nd/change.py
 
 
 class ChangeDetection(Algorithm):
+    """Base of the change detectors (nd/change.py:21-29): only carries `njobs`."""
 
     njobs = 1
 
@@ -59,9 +60,8 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
     ns = _adapter.namespace(ds)
     ds.persist() if hasattr(ds, 'persist') else None
     ds_m = disassemble_complex(ds)
-    if ml is not None:
-        ds_m = BoxcarFilter(w=ml).apply(ds_m)
-        n = ml ** 2
+    if ml is not None:          # spatial multilooking first; the looks multiply accordingly
+        ds_m, n = BoxcarFilter(w=ml).apply(ds_m), ml * ml
     host = not any(_device.is_tensor(ds_m[v].values) for v in _VARS if v in ds_m.data_vars)
     dev = _device.device_of(*[ds_m[v].values for v in _VARS if v in ds_m.data_vars], device=device)
     with torch.cuda.device(dev):
@@ -82,33 +82,25 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
 
 
 class OmnibusTest(ChangeDetection):
-    """
-    OmnibusTest
+    """Conradsen et al.'s omnibus test for change in a time series of complex-Wishart covariance
+    matrices, followed by the sequential search for the dates of change -- the detector of
+    nd/change.py:81-116, computed on the GPU.
 
-    The change detection algorithm by Conradsen et al. (2015), on MI355X.
+    ml      optional boxcar window: the covariance terms are first averaged over ml x ml pixels and
+            the number of looks becomes ml**2 (nd/change.py:61-63)
+    n       number of looks of the data when `ml` is not given (default 1)
+    alpha   threshold on the test's probability: a change is declared where P > alpha
+            (nd/_change.pyx:239-249; default 0.01, the reference's tests use 0.9)
+    device  optional torch device for host inputs (default: the current ROCm device)
+    njobs   accepted and stored like in the reference; one GPU launch covers the whole raster
 
-    Parameters
-    ----------
-    ml : int, optional
-        Multilooking window size. By default, no multilooking is performed and
-        the dataset is assumed to already be multilooked.
-    n : int, optional
-        The number of looks in `ds`. If `ml` is specified this parameter is
-        ignored (default: 1).
-    alpha : float (0. ... 1.), optional
-        The significance level (default: 0.01).
-    kwargs : dict, optional
-        Extra keyword arguments to be applied to ``ChangeDetection.__init__``
-        (``njobs`` is accepted for compatibility: the whole raster is one GPU launch).
-    """
+    `apply(ds)` returns the boolean DataArray 'change' with dimensions ('y', 'x', 'time')."""
 
     def __init__(self, ml=None, n=1, alpha=0.01, *args, **kwargs):
         _lib.lib()          # ImportError when libnd_amd.so is missing, like nd/change.py:106-108
-        self.ml = ml
-        self.n = n
-        self.alpha = alpha
         self.device = kwargs.pop('device', None)
-        super().__init__(*args, **kwargs)
+        ChangeDetection.__init__(self, *args, **kwargs)
+        self.ml, self.n, self.alpha = ml, n, alpha
 
     def apply(self, ds):
         return _omnibus_change_detection(ds, alpha=self.alpha, ml=self.ml, n=self.n,

@@ -27,35 +27,44 @@ __all__ = ['Filter', 'ConvolutionFilter', 'convolution', 'BoxcarFilter', 'boxcar
 
 
 def _expand_kernel(kernel, kernel_dims, new_dims):
-    """Reshape a kernel spanning `kernel_dims` to cover the superset `new_dims`
-    (nd/filters.py:36-75)."""
-    if not set(new_dims).issuperset(set(kernel_dims)):
+    """View `kernel` (one axis per entry of `kernel_dims`) as an array with one axis per entry of
+    `new_dims`, length 1 on the axes it does not span.  Same contract and error messages as
+    nd/filters.py:36-75 (its test: nd/tests/test_filters_common.py)."""
+    missing = [d for d in kernel_dims if d not in new_dims]
+    if missing:
         raise ValueError('`new_dims` must be a superset of `kernel_dims`.')
-    if kernel.ndim != len(kernel_dims):
+    if len(kernel_dims) != kernel.ndim:
         raise ValueError('The length of `kernel_dims` must match the dimension of `kernel`.')
-    new_kernel_shape = np.ones(len(new_dims), dtype=int)
-    new_kernel_shape[[new_dims.index(_) for _ in kernel_dims]] = kernel.shape
-    return kernel.reshape(new_kernel_shape)
+    extent = dict(zip(kernel_dims, kernel.shape))
+    return kernel.reshape([extent.get(d, 1) for d in new_dims])
 
 
 def _largest_dim(ds, dims):
-    return sorted(dims, key=lambda d: ds.sizes[d], reverse=True)[0]
+    return max(dims, key=lambda d: ds.sizes[d])
+
+
+def _split_dimension(filt, ds):
+    """Dimension to cut when a filter is applied in chunks: the longest one the filter does not
+    touch (no halo needed), else the longest one overall."""
+    free = [d for d in ds.dims if d not in filt.dims]
+    return _largest_dim(ds, free or list(ds.dims))
 
 
 class Filter(Algorithm):
-    """
-    The base class for a generic filter.
+    """Common dataset handling of all filters (the marshalling of nd/filters.py:82-198).
 
-    Parameters
-    ----------
-    dims : tuple of str
-        The dimensions along which the filter is applied.
+    A subclass sets `dims` (names of the dimensions it filters along) and implements
+    `_filter(arr, axes, output)`, which filters the plain array `arr` along the integer `axes`
+    and stores the result in `output` (same shape and dtype, never aliased with `arr`).
+
+    Class attributes
+      per_variable      True: `_filter` sees one variable at a time.  False: it sees all variables
+                        that carry `dims`, stacked along a trailing 'variable' axis, with the filter
+                        dimensions leading.
+      supports_complex  False: complex variables are presented as `<name>__re` / `<name>__im`.
     """
 
-    # applied independently per variable (True) or on all variables stacked along a trailing
-    # 'variable' axis (False)
     per_variable = True
-    # False: complex variables are split into two reals before filtering
     supports_complex = False
     dims = ()
 
@@ -65,70 +74,61 @@ class Filter(Algorithm):
 
     @parallelize
     def apply(self, ds, inplace=False):
-        """
-        Apply the filter to the input dataset.
-
-        Parameters
-        ----------
-        ds : xarray.Dataset
-            The input dataset
-        inplace : bool, optional
-            If True, overwrite the input data inplace (default: False).
-
-        Returns
-        -------
-        xarray.Dataset
-            The filtered dataset
-        """
+        """Filter a Dataset or DataArray and return the filtered copy; variables that lack one of
+        `self.dims` pass through untouched.  `inplace=True` is rejected like in the reference
+        (nd/filters.py:121-123)."""
         if inplace:
             raise NotImplementedError('Inplace filtering is not currently implemented.')
-        ns = _adapter.namespace(ds)
-        orig_dims = tuple(ds.dims)
-        ordered_dims = self.dims + tuple(d for d in orig_dims if d not in self.dims)
-
-        convert_complex = _adapter.is_complex(ds) and not self.supports_complex
-        if convert_complex:
+        split_complex = (not self.supports_complex) and _adapter.is_complex(ds)
+        if split_complex:
             disassemble_complex(ds, inplace=True)
-
-        if isinstance(ds, ns.DataArray):
-            result = ds.copy(deep=True)
-            vdims = result.dims
-            axes = tuple([vdims.index(d) for d in self.dims])
-            self._filter(ds.values, axes, output=result.values)
+        if isinstance(ds, _adapter.namespace(ds).DataArray):
+            result = self._apply_array(ds)
+        elif self.per_variable:
+            result = self._apply_each(ds)
         else:
-            variables = _adapter.get_vars_for_dims(ds, self.dims)
-            other_variables = _adapter.get_vars_for_dims(ds, self.dims, invert=True)
-            if self.per_variable:
-                result = ds.copy(deep=True)
-                for v in variables:
-                    vdims = result[v].dims
-                    axes = tuple([vdims.index(d) for d in self.dims])
-                    self._filter(ds[v].values, axes, output=result[v].values)
-            else:
-                ordered_dims = ordered_dims + ('variable',)
-                da_ordered = ds[variables].to_array().transpose(*ordered_dims)
-                da_filtered = da_ordered.copy(deep=True)
-                axes = tuple([da_ordered.dims.index(d) for d in self.dims])
-                self._filter(da_ordered.values, axes, output=da_filtered.values)
-                result = _adapter.expand_variables(da_filtered)
-                for v in list(result.data_vars):
-                    result[v] = result[v].transpose(*ds[v].dims)
-                for v in other_variables:
-                    result[v] = ds[v]
-
-        if convert_complex:
+            result = self._apply_stacked(ds)
+        if split_complex:
+            # the caller's dataset gets its complex variables back; the result keeps the split
+            # form, as it does in the reference (nd/filters.py:186-188)
             assemble_complex(ds, inplace=True)
         return result
 
+    def _axes_in(self, dims):
+        return tuple(dims.index(d) for d in self.dims)
+
+    def _apply_array(self, da):
+        out = da.copy(deep=True)
+        self._filter(da.values, self._axes_in(out.dims), output=out.values)
+        return out
+
+    def _apply_each(self, ds):
+        out = ds.copy(deep=True)
+        for name in _adapter.get_vars_for_dims(ds, self.dims):
+            self._filter(ds[name].values, self._axes_in(out[name].dims), output=out[name].values)
+        return out
+
+    def _apply_stacked(self, ds):
+        names = _adapter.get_vars_for_dims(ds, self.dims)
+        passthrough = _adapter.get_vars_for_dims(ds, self.dims, invert=True)
+        order = self.dims + tuple(d for d in ds.dims if d not in self.dims) + ('variable',)
+        stacked = ds[names].to_array().transpose(*order)
+        filtered = stacked.copy(deep=True)
+        self._filter(stacked.values, self._axes_in(stacked.dims), output=filtered.values)
+        out = _adapter.expand_variables(filtered)
+        for name in list(out.data_vars):
+            out[name] = out[name].transpose(*ds[name].dims)      # original axis order
+        for name in passthrough:
+            out[name] = ds[name]
+        return out
+
     @abstractmethod
     def _filter(self, arr, axes, output=None):
-        """Filter `arr` along `axes`, writing into `output` in place."""
+        """Filter `arr` along `axes` into `output`."""
         return
 
 
-# ------------------
-# CONVOLUTION FILTER
-# ------------------
+# ---- convolution -----------------------------------------------------------------------------
 
 def _convolve_into(arr, nd_kernel, output, device=None, **kwargs):
     """scipy.ndimage.convolve(arr, nd_kernel, output=output, **kwargs) on the GPU (real dtype)."""
@@ -163,130 +163,98 @@ def _convolve_into(arr, nd_kernel, output, device=None, **kwargs):
 
 
 class ConvolutionFilter(Filter):
-    """
-    Kernel-convolution of an xarray.Dataset.
+    """Convolution with an arbitrary kernel, per variable (nd/filters.py:205-267).
 
-    Parameters
-    ----------
-    dims : tuple, optional
-        The dataset dimensions corresponding to the kernel axes
-        (default: ('y', 'x')). The length of the tuple must match the
-        number of dimensions of the kernel.
-    kernel : ndarray
-        The convolution kernel.
-    kwargs : dict, optional
-        Extra keyword arguments with the meaning they have for
-        ``scipy.ndimage.convolve`` (``mode``, ``cval``, ``origin``).
-    """
+    dims    names of the dataset dimensions the kernel axes refer to, in kernel-axis order
+            (default ('y', 'x')); `len(dims)` must equal `kernel.ndim`
+    kernel  array of weights; `None` means the identity (a single 1)
+    kwargs  passed on with scipy.ndimage.convolve's meaning: `mode` (default 'reflect'), `cval`,
+            `origin`
+
+    Complex variables are filtered as two real arrays.  Results are those of
+    scipy.ndimage.convolve, bit for bit (tests/test_correlate_gpu.py)."""
 
     per_variable = True
     supports_complex = True
     kwargs = {}
 
     def __init__(self, dims=('y', 'x'), kernel=None, **kwargs):
-        if kernel is None:
-            kernel = np.ones([1] * len(dims))
         self.dims = tuple(dims)
-        self.kernel = np.asarray(kernel)
+        self.kernel = np.ones((1,) * len(self.dims)) if kernel is None else np.asarray(kernel)
         self.kwargs = kwargs
 
     def _parallel_dimension(self, ds):
-        """Prefer the largest dimension that is not part of the filter."""
-        extra_dims = [d for d in ds.dims if d not in self.dims]
-        return _largest_dim(ds, extra_dims if len(extra_dims) > 0 else list(ds.dims))
+        return _split_dimension(self, ds)
 
     def _buffer(self, dim):
-        if dim not in self.dims:
-            return 0
-        return self.kernel.shape[self.dims.index(dim)] // 2
+        """Rows of context a chunk needs on each side along `dim`: half the kernel extent."""
+        return self.kernel.shape[self.dims.index(dim)] // 2 if dim in self.dims else 0
 
     def _filter(self, arr, axes, output):
-        new_kernel_shape = np.ones(arr.ndim, dtype=int)
-        new_kernel_shape[list(axes)] = self.kernel.shape
-        nd_kernel = self.kernel.reshape(new_kernel_shape)
-        if _adapter.iscomplexobj(arr):
-            # real and imaginary parts separately (nd/filters.py:261-265)
-            if _device.is_tensor(arr):
-                ro, io = torch.view_as_real(output).unbind(-1)
-                ri, ii = torch.view_as_real(arr).unbind(-1)
-                _convolve_into(ri, nd_kernel, ro, **self.kwargs)
-                _convolve_into(ii, nd_kernel, io, **self.kwargs)
-            else:
-                _convolve_into(np.real(arr), nd_kernel, np.real(output), **self.kwargs)
-                _convolve_into(np.imag(arr), nd_kernel, np.imag(output), **self.kwargs)
-        else:
+        shape = [1] * arr.ndim
+        for axis, n in zip(axes, self.kernel.shape):
+            shape[axis] = n
+        nd_kernel = self.kernel.reshape(shape)
+        if not _adapter.iscomplexobj(arr):
             _convolve_into(arr, nd_kernel, output, **self.kwargs)
+        elif _device.is_tensor(arr):
+            # interleaved complex memory seen as two strided real views
+            for part_in, part_out in zip(torch.view_as_real(arr).unbind(-1),
+                                         torch.view_as_real(output).unbind(-1)):
+                _convolve_into(part_in, nd_kernel, part_out, **self.kwargs)
+        else:
+            _convolve_into(arr.real, nd_kernel, output.real, **self.kwargs)
+            _convolve_into(arr.imag, nd_kernel, output.imag, **self.kwargs)
 
 
 convolution = wrap_algorithm(ConvolutionFilter, 'convolution')
 
 
 class BoxcarFilter(ConvolutionFilter):
-    """
-    A boxcar filter.
-
-    Parameters
-    ----------
-    dims : tuple of str, optional
-        The dimensions along which to apply the filter (default: ('y', 'x')).
-    w : int
-        The width of the boxcar window. Should be an odd integer in order to
-        ensure symmetry.
-    kwargs : dict, optional
-        Extra keyword arguments with the meaning they have for ``scipy.ndimage.convolve``.
-    """
+    """Moving average over a `w`-wide window along each of `dims` (nd/filters.py:277-298): a
+    ConvolutionFilter whose kernel is constant, `1 / w**len(dims)` in float64.  Use an odd `w` for
+    a centred window; `kwargs` as for ConvolutionFilter."""
 
     def __init__(self, dims=('y', 'x'), w=3, **kwargs):
-        N = len(dims)
-        self.dims = tuple(dims)
-        self.kernel = np.ones((w,) * N, dtype=np.float64) / w**N
-        self.kwargs = kwargs
+        ndim = len(dims)
+        ConvolutionFilter.__init__(self, dims, np.ones((w,) * ndim, dtype=np.float64) / w**ndim,
+                                   **kwargs)
 
 
 boxcar = wrap_algorithm(BoxcarFilter, 'boxcar')
 
 
-# ---------------
-# GAUSSIAN FILTER
-# ---------------
+# ---- Gaussian --------------------------------------------------------------------------------
 
 class GaussianFilter(Filter):
-    """
-    A Gaussian filter (scipy.ndimage.gaussian_filter semantics).
+    """Gaussian smoothing with scipy.ndimage.gaussian_filter's semantics (nd/filters.py:308-378).
 
-    Parameters
-    ----------
-    dims : tuple of str, optional
-        The dimensions along which to apply the Gaussian filtering (default: ('y', 'x')).
-    sigma : float or sequence of float
-        The standard deviation for the Gaussian kernel, per dimension if a sequence.
-    """
+    dims    dimensions to smooth along (default ('y', 'x'))
+    sigma   standard deviation in samples: one number for all of `dims`, or one per dimension
+    kwargs  `mode`, `cval`, `truncate` as in scipy"""
 
     def __init__(self, dims=('y', 'x'), sigma=1, **kwargs):
-        if isinstance(sigma, (int, float)):
-            sigma = [sigma] * len(dims)
         self.dims = tuple(dims)
-        self.sigma = sigma
+        self.sigma = [sigma] * len(self.dims) if np.isscalar(sigma) else sigma
         self.kwargs = kwargs
 
     def _parallel_dimension(self, ds):
-        extra_dims = [d for d in ds.dims if d not in self.dims]
-        return _largest_dim(ds, extra_dims if len(extra_dims) > 0 else list(ds.dims))
+        return _split_dimension(self, ds)
 
     def _buffer(self, dim):
+        """scipy truncates the kernel at 4 sigma: radius int(4 sigma + 0.5)."""
         if dim not in self.dims:
             return 0
-        sigma = self.sigma[self.dims.index(dim)]
-        return int(4.0 * sigma + 0.5)
+        return int(4.0 * self.sigma[self.dims.index(dim)] + 0.5)
 
     def _filter(self, arr, axes, output):
         unknown = set(self.kwargs) - {'mode', 'cval', 'truncate'}
         if unknown:
             raise TypeError('unsupported scipy.ndimage.gaussian_filter arguments: %s'
                             % sorted(unknown))
-        ndsigma = [0] * arr.ndim
-        for ax, s in zip(axes, self.sigma):
-            ndsigma[ax] = s
+        per_axis = [0] * arr.ndim                     # sigma 0 = axis left alone
+        for axis, value in zip(axes, self.sigma):
+            per_axis[axis] = value
         dev = _device.device_of(arr, output)
         with torch.cuda.device(dev):
             t = _device.to_device(arr, dev)
@@ -295,7 +263,7 @@ class GaussianFilter(Filter):
             out_t = output if _device.is_tensor(output) else torch.empty_like(t)
             if out_t.data_ptr() == t.data_ptr():
                 t = t.clone()
-            kernels.gaussian_filter(t, ndsigma, out=out_t, **self.kwargs)
+            kernels.gaussian_filter(t, per_axis, out=out_t, **self.kwargs)
             if out_t is not output:
                 _device.write_back(out_t, output)
 
@@ -303,67 +271,56 @@ class GaussianFilter(Filter):
 gaussian = wrap_algorithm(GaussianFilter, 'gaussian')
 
 
-# ----------------------
-# NON-LOCAL MEANS FILTER
-# ----------------------
+# ---- non-local means -------------------------------------------------------------------------
 
 class NLMeansFilter(Filter):
-    """
-    Non-Local Means (Buades2011).
+    """Non-local means over up to three dimensions, weights shared by all variables
+    (nd/filters.py:388-466; kernel: nd/_filters.pyx:320-420).
 
-    Parameters
-    ----------
-    dims : tuple of str
-        The dataset dimensions along which to filter.
-    r : {int, sequence}
-        The radius
-    sigma : float
-        The standard deviation of the noise present in the data.
-    h : float
-    f : int
-    n_eff : float, optional
-        The desired effective sample size (default: -1 = none).
-    patch_distances : {'reference', 'signed'}, optional
-        'reference' (default) reproduces the compiled reference bit for bit: on 64-bit platforms
-        its patch loops `range(-f, f+1)` over an unsigned `f` never execute when f > 0, so all
-        neighbours in the search window get weight 1 (nd/_filters.c:3539-3553).  'signed'
-        evaluates the patch distances the source text describes.
-    """
+    dims     dimensions that span the search window and the patches
+    r        search radius: one number, or one per entry of `dims` (0 = do not search along it)
+    sigma    noise standard deviation: patch distances below 2 sigma^2 count as zero
+    h        decay of the weights with patch distance
+    f        patch radius, applied along every dimension whose r is non-zero
+    n_eff    target effective sample size; the weight of the centre pixel is solved for it
+             (-1: the centre pixel gets the largest neighbour weight)
+    patch_distances
+             'reference' (default) is what the compiled reference computes on 64-bit platforms:
+             its patch loops run over range(-f, f+1) with an UNSIGNED f, which is empty for f > 0,
+             so every pixel of the search window gets weight 1 (nd/_filters.c:3539-3553).
+             'signed' evaluates the patch distances the source text describes."""
 
     per_variable = False
 
     def __init__(self, dims=('y', 'x'), r=1, sigma=1, h=1, f=1, n_eff=-1,
                  patch_distances='reference'):
-        if isinstance(r, (int, float)):
-            r = [r] * len(dims)
-        self.dims = tuple(dims)
-        self.r = np.array(r, dtype=np.uint32)
-        self.f = np.array([f if _ > 0 else 0 for _ in self.r], dtype=np.uint32)
-        self.sigma = sigma
-        self.h = h
-        self.n_eff = n_eff
         if patch_distances not in ('reference', 'signed'):
             raise ValueError("patch_distances must be 'reference' or 'signed'")
+        self.dims = tuple(dims)
+        radii = [r] * len(self.dims) if np.isscalar(r) else list(r)
+        self.r = np.asarray(radii).astype(np.uint32)
+        self.f = np.where(self.r > 0, f, 0).astype(np.uint32)
+        self.sigma, self.h, self.n_eff = sigma, h, n_eff
         self.patch_distances = patch_distances
 
     def _parallel_dimension(self, ds):
-        extra_dims = [d for d in ds.dims if d not in self.dims]
-        return _largest_dim(ds, extra_dims if len(extra_dims) > 0 else list(ds.dims))
+        return _split_dimension(self, ds)
 
     def _buffer(self, dim):
+        """A chunk needs search radius + patch radius rows of context."""
         if dim not in self.dims:
             return 0
-        axis = self.dims.index(dim)
-        return int(self.r[axis] + self.f[axis])
+        i = self.dims.index(dim)
+        return int(self.r[i]) + int(self.f[i])
 
     def _filter(self, arr, axes, output):
-        # Pad r and f to three dimensions; like the reference, the filter dimensions are taken
-        # to be the leading axes and the last axis the variable axis (`axes` is not consulted,
-        # nd/filters.py:447-463).
-        pad_before = np.zeros(4 - arr.ndim, dtype=self.r.dtype)
-        pad_after = np.zeros(arr.ndim - len(self.r) - 1, dtype=self.r.dtype)
-        r = np.concatenate([pad_before, self.r, pad_after])
-        f = np.concatenate([pad_before, self.f, pad_after])
+        # The kernel works on (d0, d1, d2, variable).  Like the reference (nd/filters.py:447-463,
+        # which never looks at `axes`) the filter dimensions are taken to be the leading axes and
+        # the variable axis the last one; missing axes are added in front with radius 0, unused
+        # trailing ones get radius 0 too.
+        lead, trail = 4 - arr.ndim, arr.ndim - 1 - len(self.r)
+        r = np.array([0] * lead + list(self.r) + [0] * trail, dtype=np.uint32)
+        f = np.array([0] * lead + list(self.f) + [0] * trail, dtype=np.uint32)
         dev = _device.device_of(arr, output)
         with torch.cuda.device(dev):
             t = _device.to_device(arr, dev)
