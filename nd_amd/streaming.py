@@ -8,8 +8,12 @@ map over tiles, merge) for the one algorithm that needs no halo.  The omnibus te
 the tiles are independent and the result is bit-identical to the untiled one.  Throughput is bounded
 by the host link (PCIe Gen5 x16, 63 GB/s spec -> 164 Mpx/s at 384 B per pixel), three orders of
 magnitude below the device-resident rate that bench.py reports.
+
+`nlmeans_omnibus_streamed` is the same pipeline for a windowed stage in front of the test: tiles
+carry `buffer` halo rows exactly like `tiling.tile(..., buffer=...)` (nd/tiling.py:18-120).
 """
 import os
+import warnings
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -40,13 +44,12 @@ def _parallel_copy(pairs):
     list(_pool().map(lambda ds: ds[0].copy_(ds[1]), pairs))
 
 
-def omnibus_streamed(planes, alpha, n=1, rows_per_tile=1024, device=None, out=None):
-    """planes: four host arrays (numpy or CPU tensors) of shape (time, y, x), float32 or float64,
-    [C11, C12re, C12im, C22].  Returns a uint8 numpy array (y, x, time) (written into `out` if
-    given).  Two staging slots; per tile: H2D on the copy stream, kernels on the compute stream,
-    D2H of the change map on the copy stream."""
-    planes = [torch.from_numpy(np.ascontiguousarray(p)) if isinstance(p, np.ndarray) else p
-              for p in planes]
+def _check_planes(planes):
+    with warnings.catch_warnings():
+        # read-only inputs (numpy.memmap opened with mode 'r') are only ever read here
+        warnings.filterwarnings('ignore', message='The given NumPy array is not writable')
+        planes = [torch.from_numpy(np.ascontiguousarray(p)) if isinstance(p, np.ndarray) else p
+                  for p in planes]
     if len(planes) != 4:
         raise ValueError('four covariance planes expected')
     p0 = planes[0]
@@ -55,9 +58,23 @@ def omnibus_streamed(planes, alpha, n=1, rows_per_tile=1024, device=None, out=No
             raise ValueError('planes must be four host arrays (time, y, x) of one dtype and shape')
     if p0.dtype not in (torch.float32, torch.float64):
         raise TypeError('float32 or float64 expected')
+    return planes
+
+
+def _stream_rows(planes, rows_per_tile, halo, process, device=None, out=None):
+    """Row-tile pipeline shared by the streamed entry points.  For every tile of `rows_per_tile`
+    rows the rows [r0 - halo, r1 + halo) (clipped to the raster) of the four planes are uploaded
+    into a device stack (4, time, rows, x); `process(stack, e0, r0, r1)` -- e0 = first uploaded row
+    -- must return the uint8 change map (r1 - r0, x, time) of the tile's own rows as a device
+    tensor.  Two staging slots; per tile: H2D on the copy stream, `process` on the compute stream,
+    D2H of the change map on the copy stream."""
+    planes = _check_planes(planes)
+    p0 = planes[0]
     k, ny, nx = p0.shape
     dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
     rows = max(1, min(int(rows_per_tile), ny))
+    halo = int(halo)
+    ext_rows = min(ny, rows + 2 * halo)
     if out is None:
         out = np.empty((ny, nx, k), np.uint8)
     out_t = torch.from_numpy(out)
@@ -66,8 +83,8 @@ def omnibus_streamed(planes, alpha, n=1, rows_per_tile=1024, device=None, out=No
         slots = []
         for _ in range(2):
             slots.append({
-                'host_in': _pinned_like((4, k, rows, nx), p0.dtype),
-                'dev_in': synth.empty_stack(4, k, rows, nx, dev, p0.dtype),
+                'host_in': _pinned_like((4, k, ext_rows, nx), p0.dtype),
+                'dev_in': synth.empty_stack(4, k, ext_rows, nx, dev, p0.dtype),
                 'host_out': _pinned_like((rows, nx, k), torch.uint8),
                 'uploaded': torch.cuda.Event(), 'computed': torch.cuda.Event(),
                 'downloaded': torch.cuda.Event(), 'result': None, 'span': None,
@@ -88,19 +105,18 @@ def omnibus_streamed(planes, alpha, n=1, rows_per_tile=1024, device=None, out=No
         for i, (r0, r1) in enumerate(tiles):
             s = slots[i % 2]
             drain(s)                                    # slot free again (its D2H finished)
-            nr = r1 - r0
+            e0, e1 = max(r0 - halo, 0), min(r1 + halo, ny)
+            ne, nr = e1 - e0, r1 - r0
             # pageable -> pinned, one job per (variable, block of dates)
             tb = max(1, k // 4)
-            _parallel_copy([(s['host_in'][v, t0:t0 + tb, :nr], planes[v][t0:t0 + tb, r0:r1])
+            _parallel_copy([(s['host_in'][v, t0:t0 + tb, :ne], planes[v][t0:t0 + tb, e0:e1])
                             for v in range(4) for t0 in range(0, k, tb)])
             with torch.cuda.stream(copy_s):
-                s['dev_in'][:, :, :nr].copy_(s['host_in'][:, :, :nr], non_blocking=True)
+                s['dev_in'][:, :, :ne].copy_(s['host_in'][:, :, :ne], non_blocking=True)
                 s['uploaded'].record(copy_s)
             with torch.cuda.stream(comp_s):
                 comp_s.wait_event(s['uploaded'])
-                d = s['dev_in']
-                s['result'] = kernels.change_detection(d[0][:, :nr], d[1][:, :nr], d[2][:, :nr],
-                                                       d[3][:, :nr], alpha=alpha, n=n)
+                s['result'] = process(s['dev_in'][:, :, :ne], e0, r0, r1)
                 s['computed'].record(comp_s)
             with torch.cuda.stream(copy_s):
                 copy_s.wait_event(s['computed'])
@@ -111,3 +127,46 @@ def omnibus_streamed(planes, alpha, n=1, rows_per_tile=1024, device=None, out=No
         for s in slots:
             drain(s)
     return out
+
+
+def omnibus_streamed(planes, alpha, n=1, rows_per_tile=1024, device=None, out=None):
+    """planes: four host arrays (numpy, numpy.memmap or CPU tensors) of shape (time, y, x), float32
+    or float64, [C11, C12re, C12im, C22].  Returns a uint8 numpy array (y, x, time) (written into
+    `out` if given).  The omnibus test is per pixel: tiles need no halo and the result equals the
+    untiled one bit for bit."""
+    def process(stack, e0, r0, r1):
+        return kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha, n=n)
+    return _stream_rows(planes, rows_per_tile, 0, process, device, out)
+
+
+def nlmeans_omnibus_streamed(planes, r, f, sigma, h, alpha, n=1, n_eff=-1, patch_mode=0,
+                             rows_per_tile=1024, device=None, out=None):
+    """The tutorial pipeline (non-local means over (time, y, x) with joint weights over the four
+    covariance terms, then the omnibus test) over a host-resident stack: the reference's
+    `tiling.map_over_tiles` with `buffer = r_y + f_y` (nd/tiling.py:243-330), tiles cut along y.
+    Every tile is uploaded with its halo rows, filtered with the reflection applied at the edges
+    of the WHOLE raster (global_shape / tile_offset of the C ABI), and tested on its own rows, so
+    the change map equals the one computed on the whole raster at once.
+    r, f: (time, y, x) radii as in NLMeansFilter(dims=('time', 'y', 'x'))."""
+    rt, ry, rx = (int(v) for v in r)
+    ft, fy, fx = (int(v) for v in f)
+    ny = planes[0].shape[1]
+
+    def process(stack, e0, r0, r1):
+        nvar, k, ne, nx = stack.shape
+        filtered = torch.empty_like(stack)
+        lo, hi = r0 - e0, r1 - e0
+        if rt == 0 and ft == 0:
+            kernels.pixelwise_nlmeans_3d(
+                stack.permute(2, 3, 1, 0), filtered.permute(2, 3, 1, 0), (ry, rx, 0), (fy, fx, 0),
+                sigma, h, n_eff, patch_mode=patch_mode, global_shape=(ny, nx, k),
+                tile_offset=(e0, 0, 0), core=((lo, hi), (0, nx), (0, k)))
+        else:
+            kernels.pixelwise_nlmeans_3d(
+                stack.permute(1, 2, 3, 0), filtered.permute(1, 2, 3, 0), (rt, ry, rx), (ft, fy, fx),
+                sigma, h, n_eff, patch_mode=patch_mode, global_shape=(k, ny, nx),
+                tile_offset=(0, e0, 0), core=((0, k), (lo, hi), (0, nx)))
+        own = filtered[:, :, lo:hi]
+        return kernels.change_detection(own[0], own[1], own[2], own[3], alpha=alpha, n=n)
+
+    return _stream_rows(planes, rows_per_tile, ry + fy, process, device, out)

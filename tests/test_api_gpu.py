@@ -361,3 +361,29 @@ def test_host_streamed_omnibus_equals_untiled(oracle, device):
         got = streaming.omnibus_streamed(planes, alpha=0.9, n=9, rows_per_tile=64)
         yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
         np.testing.assert_array_equal(got, oracle.change_detection_planes(yxt, 0.9, 9, njobs=8))
+
+
+def test_host_streamed_pipeline_equals_whole_raster(oracle, device, tmp_path):
+    """nlmeans -> omnibus over a host stack cut into row tiles with halo (the map_over_tiles
+    analogue): equal to filtering and testing the whole raster at once, here checked against the
+    CPU oracle; inputs come from numpy.memmap files like a raster too large for memory would."""
+    from nd_amd import streaming
+    planes = synth.omnibus_stack(seed=29, k=6, ny=90, nx=140, dtype=np.float32, change_frac=0.2)
+    mm = []
+    for i, p in enumerate(planes):
+        path = tmp_path / ('plane%d.npy' % i)
+        np.save(path, p)
+        mm.append(np.load(path, mmap_mode='r'))
+    for r, f, pm, ne in (((1, 3, 3), (1, 1, 1), 0, 20.0), ((0, 3, 2), (0, 1, 1), 1, -1)):
+        got = streaming.nlmeans_omnibus_streamed(mm, r, f, 0.5, 0.5, alpha=0.9, n=9, n_eff=ne,
+                                                 patch_mode=pm, rows_per_tile=32)
+        st = np.ascontiguousarray(np.stack(planes, axis=-1))                 # (t, y, x, var)
+        filt = np.empty_like(st)
+        oracle.pixelwise_nlmeans_3d(st, filt, r, f, 0.5, 0.5, ne, njobs=8, patch_mode=pm)
+        if pm == 0:
+            yxt = [np.ascontiguousarray(np.moveaxis(filt[..., v], 0, -1)) for v in range(4)]
+            np.testing.assert_array_equal(got, oracle.change_detection_planes(yxt, 0.9, 9, njobs=8))
+        # whichever mode: the tiled result equals the device's own whole-raster result
+        whole = streaming.nlmeans_omnibus_streamed(mm, r, f, 0.5, 0.5, alpha=0.9, n=9, n_eff=ne,
+                                                   patch_mode=pm, rows_per_tile=90)
+        np.testing.assert_array_equal(got, whole)
