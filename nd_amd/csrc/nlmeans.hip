@@ -21,6 +21,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace nd_amd {
@@ -376,7 +378,9 @@ __device__ __forceinline__ float nlm_div_rounded(float s, double total, double i
     return (float)q;
 }
 
-template <int R1>
+// R0T >= 0: the row radius is the compile-time constant R0T (the row loop unrolls and every
+// validity test folds away); R0T = -1: taken from the arguments.
+template <int R1, int R0T>
 __global__ void __launch_bounds__(256) nlmeans_window_roll_kernel(const NlmTiledArgs a)
 {
     constexpr int NW = ((2 * R1 + 4) + 3) / 4 * 4;     // floats a thread reads from one staged row
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(256) nlmeans_window_roll_kernel(const NlmTiled
     extern __shared__ __align__(16) unsigned char nd_smem_r[];
     float *lds = reinterpret_cast<float *>(nd_smem_r); // [nzr][rows][COLSP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = a.r0, rz = a.rz;
+    const int r0 = R0T >= 0 ? R0T : a.r0, rz = a.rz;
     const int rows = kWinTY + 2 * r0, psz = rows * COLSP, nzr = 2 * rz + 1;
 
     int64_t b = blockIdx.x;
@@ -471,54 +475,71 @@ __global__ void __launch_bounds__(256) nlmeans_window_roll_kernel(const NlmTiled
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[pr][i] = (nlm_f32x2){0.f, 0.f};
 
+        // One staged row feeds every output row whose window holds it.  The two outputs of a pair
+        // (rows 2 pr and 2 pr + 1 of the thread's patch) see input row ry as their window rows
+        // du = ry - 2 pr and dl = du - 1; where both are inside the window the additions are
+        // packed.  The window centre must not enter the sum: its lane adds +0.0 instead, which
+        // leaves a running sum that started at +0.0 unchanged bit for bit.
+        auto row_step = [&](const float *P, int ry, bool cplane, auto full) {
+            constexpr bool FULL = decltype(full)::value;     // both outputs of both pairs hold this row
+            float w[NW];
+            const float4 *rp = reinterpret_cast<const float4 *>(P + ry * COLSP);
+#pragma unroll
+            for (int c = 0; c < NW / 4; ++c) {
+                const float4 t = rp[c];
+                w[4 * c + 0] = t.x;
+                w[4 * c + 1] = t.y;
+                w[4 * c + 2] = t.z;
+                w[4 * c + 3] = t.w;
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int du = ry - 2 * pr, dl = du - 1;
+                const bool vu = FULL || (du >= 0 && du <= 2 * r0), vl = FULL || (dl >= 0 && dl <= 2 * r0);
+                const bool cu = cplane && du == r0, cl = cplane && dl == r0;
+                if (vu && vl) {
+#pragma unroll
+                    for (int dx = 0; dx < 2 * R1 + 1; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float x = w[dx + i];
+                            const nlm_f32x2 t = {(dx == R1 && cu) ? 0.f : x, (dx == R1 && cl) ? 0.f : x};
+                            acc[pr][i] = acc[pr][i] + t;
+                        }
+                } else if (vu) {
+#pragma unroll
+                    for (int dx = 0; dx < 2 * R1 + 1; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[pr][i].x = acc[pr][i].x + ((dx == R1 && cu) ? 0.f : w[dx + i]);
+                } else if (vl) {
+#pragma unroll
+                    for (int dx = 0; dx < 2 * R1 + 1; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[pr][i].y = acc[pr][i].y + ((dx == R1 && cl) ? 0.f : w[dx + i]);
+                }
+            }
+        };
         // the reference's visiting order: third-axis offset outermost when it is a window axis,
-        // then rows, columns innermost; the centre is skipped here and added last
+        // then rows, columns innermost; the centre is added last
         for (int dz = 0; dz < nzr; ++dz) {
             const float *P = lds + (int)(zmap(i2 + dz - rz) % nzr) * psz + ly * COLSP + lx;
             const bool cplane = (dz == rz);
+            if (R0T >= 0) {
+#pragma unroll
+                for (int ry = 0; ry < 4 + 2 * (R0T >= 0 ? R0T : 0); ++ry)
+                    row_step(P, ry, cplane, std::false_type{});
+            } else {
+                // rows 3 .. 2 r0 lie inside the window of all four output rows: no validity tests
+                const int nrow = 4 + 2 * r0;
+#pragma unroll
+                for (int ry = 0; ry < 3; ++ry) row_step(P, ry, cplane, std::false_type{});
+#pragma unroll 2
+                for (int ry = 3; ry <= 2 * r0; ++ry) row_step(P, ry, cplane, std::true_type{});
 #pragma unroll 1
-            for (int ry = 0; ry < 4 + 2 * r0; ++ry) {
-                float w[NW];
-                const float4 *rp = reinterpret_cast<const float4 *>(P + ry * COLSP);
-#pragma unroll
-                for (int c = 0; c < NW / 4; ++c) {
-                    const float4 t = rp[c];
-                    w[4 * c + 0] = t.x;
-                    w[4 * c + 1] = t.y;
-                    w[4 * c + 2] = t.z;
-                    w[4 * c + 3] = t.w;
-                }
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    // window row index of this input row for the pair's upper / lower output row
-                    const int du = ry - 2 * pr, dl = du - 1;
-                    const bool vu = du >= 0 && du <= 2 * r0, vl = dl >= 0 && dl <= 2 * r0;
-                    const bool cu = cplane && du == r0, cl = cplane && dl == r0;
-                    if (vu && vl && !cu && !cl) {
-#pragma unroll
-                        for (int dx = 0; dx < 2 * R1 + 1; ++dx)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                acc[pr][i] = acc[pr][i] + (nlm_f32x2){w[dx + i], w[dx + i]};
-                    } else {
-                        if (vu) {
-#pragma unroll
-                            for (int dx = 0; dx < 2 * R1 + 1; ++dx)
-                                if (!(cu && dx == R1)) {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) acc[pr][i].x = acc[pr][i].x + w[dx + i];
-                                }
-                        }
-                        if (vl) {
-#pragma unroll
-                            for (int dx = 0; dx < 2 * R1 + 1; ++dx)
-                                if (!(cl && dx == R1)) {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) acc[pr][i].y = acc[pr][i].y + w[dx + i];
-                                }
-                        }
-                    }
-                }
+                for (int ry = (2 * r0 + 1 > 3 ? 2 * r0 + 1 : 3); ry < nrow; ++ry)
+                    row_step(P, ry, cplane, std::false_type{});
             }
         }
 
@@ -556,7 +577,13 @@ __global__ void __launch_bounds__(256) nlmeans_window_roll_kernel(const NlmTiled
 template <int R1>
 static void launch_roll(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
 {
-    hipLaunchKernelGGL((nlmeans_window_roll_kernel<R1>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+    // square windows up to 11 x 11 get the fully unrolled row loop
+    if (R1 >= 1 && R1 <= 5 && a.r0 == R1)
+        hipLaunchKernelGGL((nlmeans_window_roll_kernel<R1, (R1 >= 1 && R1 <= 5) ? R1 : -1>),
+                           dim3((unsigned)nb), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((nlmeans_window_roll_kernel<R1, -1>), dim3((unsigned)nb), dim3(256), lds,
+                           stream, a);
 }
 
 static bool launch_roll_r1(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
