@@ -71,13 +71,19 @@ __device__ __forceinline__ T z_stat(const Accum<T> &A, int j, double nlooks, con
 // Screen statistic: z from approx_ln.  |z_approx - z| <= |m2rho| n (k+1) 1e-7; the host widens
 // zlo_a / zhi_a by ten times that, so z_approx < zlo_a implies z < zlo (omni tables).
 template <typename T>
+__device__ __forceinline__ double z_approx(const Accum<T> &A, int j, double nlooks, double m2rho,
+                                           double pklogk)
+{
+    const T det_of_sum = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
+    const double logQ = nlooks * ((pklogk + approx_ln(A.prod)) -
+                                  ((double)j * approx_ln((double)det_of_sum)));
+    return m2rho * logQ;
+}
+template <typename T>
 __device__ __forceinline__ double z_approx(const Accum<T> &A, int j, double nlooks,
                                            const OmniTabEntry &e)
 {
-    const T det_of_sum = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
-    const double logQ = nlooks * ((e.pklogk + approx_ln(A.prod)) -
-                                  ((double)j * approx_ln((double)det_of_sum)));
-    return e.m2rho * logQ;
+    return z_approx<T>(A, j, nlooks, e.m2rho, e.pklogk);
 }
 
 // The input planes are read exactly once and the change map is written once: both bypass the
@@ -465,14 +471,28 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     T *lds = reinterpret_cast<T *>(nd_smem);
     const int lane = threadIdx.x;
     const int k = s.k;
-    // per-j constants: LDS copy behind the series region (USE_LDS), else read from global
-    const OmniTabEntry *tabp = s.tab;
+    // Per-j constants of the screen (m2rho, pklogk, zlo_a, zhi_a): every lane looks up its own j
+    // in every iteration, so they sit in LDS as four separate arrays of doubles -- consecutive j in
+    // consecutive banks (as 64-byte records all j of one parity would share a bank).
+    const OmniTabEntry *tabp = s.tab;          // full records, read only on the rare exact path
+    const int kp = k + 1;
+    double *scr = reinterpret_cast<double *>(nd_smem + (size_t)k * 4 * 64 * sizeof(T));
     if (USE_LDS) {
-        OmniTabEntry *tl = reinterpret_cast<OmniTabEntry *>(nd_smem + (size_t)k * 4 * 64 * sizeof(T));
-        for (int j = lane; j <= k; j += 64) tl[j] = s.tab[j];
+        for (int j = lane; j <= k; j += 64) {
+            const OmniTabEntry e = s.tab[j];
+            scr[j] = e.m2rho;
+            scr[kp + j] = e.pklogk;
+            scr[2 * kp + j] = e.zlo_a;
+            scr[3 * kp + j] = e.zhi_a;
+        }
         __syncthreads();
-        tabp = tl;
     }
+    // MODE 1 (series too long for LDS): the same four constants straight from the records
+    auto screen = [&](int f, int j) -> double {
+        if (USE_LDS) return scr[f * kp + j];
+        const OmniTabEntry &e = s.tab[j];
+        return f == 0 ? e.m2rho : (f == 1 ? e.pklogk : (f == 2 ? e.zlo_a : e.zhi_a));
+    };
     // blocks shard, shard + kShards, ... work through the list of one shard
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards;
@@ -589,29 +609,33 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                 // a marginal test while none has fired yet (j >= 2); at the last date the same
                 // evaluation is the global test, needed even if a marginal fired earlier
                 const bool need = (jj >= 2) && (fire_at < 0 || last);
-                bool fires = false;
+                // Screen: z from the hardware log2 against the widened bounds.  fires = above the
+                // band for certain; inband = the screen cannot tell.  (NaN compares false twice.)
+                bool fires = false, inband = false;
                 if (need) {
-                    const OmniTabEntry e = tabp[jj];
-                    const double za = z_approx<T>(A, jj, s.nlooks, e);
-                    // 0 = cannot fire (z < zlo, or NaN), 1 = fires for certain (zhi < z < inf),
-                    // 2 = inside the band: needs the chi-square pair
-                    int verdict = 0;
-                    T zp = 0;
-                    if (za >= e.zlo_a) {
-                        verdict = 1;
-                        if (!(za > e.zhi_a && za < INFINITY)) {
-                            zp = z_stat<T>(A, jj, s.nlooks, e);
-                            const double zd = (double)zp;
-                            verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                    const double za = z_approx<T>(A, jj, s.nlooks, screen(0, jj), screen(1, jj));
+                    fires = (za > screen(3, jj)) && (za < INFINITY);
+                    inband = (za >= screen(2, jj)) && !fires;
+                }
+                // The exact evaluation (two double logs, possibly the chi-square pair) sits behind
+                // a wave-uniform branch so that the compiler cannot fold it into the loop body: it
+                // is needed for ~1e-5 of the tests, the loop body runs for all of them.
+                if (__any(inband)) {
+                    if (inband) {
+                        const OmniTabEntry e = tabp[jj];
+                        const T zp = z_stat<T>(A, jj, s.nlooks, e);
+                        const double zd = (double)zp;
+                        // 0 = cannot fire (z < zlo, or NaN), 1 = fires for certain
+                        // (zhi < z < inf), 2 = inside the exact band: needs the chi-square pair
+                        int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                        if (verdict == 2) {
+                            double zv[1] = {zd}, P1[1], P2[1];
+                            chisq_pair<1>(zv, 4 * (jj - 1), e.lgam, P1, P2);
+                            const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                            verdict = ((double)P > s.alpha) ? 1 : 0;
                         }
+                        fires = (verdict == 1);
                     }
-                    if (verdict == 2) {
-                        double zd[1] = {(double)zp}, P1[1], P2[1];
-                        chisq_pair<1>(zd, 4 * (jj - 1), e.lgam, P1, P2);
-                        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
-                        verdict = ((double)P > s.alpha) ? 1 : 0;
-                    }
-                    fires = (verdict == 1);
                 }
                 if (!last) {
                     if (fires && fire_at < 0) fire_at = t;
@@ -886,7 +910,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     s.tab = tab_dev;
     s.dump = g.dump;
     s.dump_cap = g.dump_cap;
-    const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T) + (size_t)(k + 1) * sizeof(OmniTabEntry);
+    const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);      // screen constants
+    const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T) + scr_bytes;
     const bool use_lds = lds_bytes <= 64 * 1024;
     // kShards x (blocks per shard); a shard's blocks stride through its list
     int64_t per_shard = ceil_div(ceil_div(npix, kShards), 64);

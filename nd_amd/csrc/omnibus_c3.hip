@@ -224,27 +224,29 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
                 const int jj = t - l + 1;
                 const bool last = (t == k - 1);
                 const bool need = (jj >= 2) && (fire_at < 0 || last);
-                bool fires = false;
+                // screen on the hardware-log2 statistic; the exact evaluation sits behind a
+                // wave-uniform branch so that it is not folded into the loop body (omnibus.hip)
+                bool fires = false, inband = false;
                 if (need) {
-                    const OmniTabEntry e = s.tab_dev[jj];
+                    const OmniTabEntry &e = s.tab_dev[jj];
                     const double za = z_approx3<T>(A, jj, s.nlooks, e);
-                    int verdict = 0;
-                    T zp = 0;
-                    if (za >= e.zlo_a) {
-                        verdict = 1;
-                        if (!(za > e.zhi_a && za < INFINITY)) {
-                            zp = z_stat3<T>(A, jj, s.nlooks, e);
-                            const double zd = (double)zp;
-                            verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                    fires = (za > e.zhi_a) && (za < INFINITY);
+                    inband = (za >= e.zlo_a) && !fires;
+                }
+                if (__any(inband)) {
+                    if (inband) {
+                        const OmniTabEntry e = s.tab_dev[jj];
+                        const T zp = z_stat3<T>(A, jj, s.nlooks, e);
+                        const double zd = (double)zp;
+                        int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                        if (verdict == 2) {
+                            double zv[1] = {zd}, P1[1], P2[1];
+                            chisq_pair<1>(zv, 9 * (jj - 1), e.lgam, P1, P2);
+                            const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                            verdict = ((double)P > s.alpha) ? 1 : 0;
                         }
+                        fires = (verdict == 1);
                     }
-                    if (verdict == 2) {
-                        double zd[1] = {(double)zp}, P1[1], P2[1];
-                        chisq_pair<1>(zd, 9 * (jj - 1), e.lgam, P1, P2);
-                        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
-                        verdict = ((double)P > s.alpha) ? 1 : 0;
-                    }
-                    fires = (verdict == 1);
                 }
                 if (fires && fire_at < 0) fire_at = t;
                 if (!last) {

@@ -47,9 +47,11 @@ def build_variant(name, patches, extra=()):
     return so
 
 VARIANTS = {
-    't256': [],
-    't128': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 128")],
-    't64': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 64")],
+    'base': [],
+    'b_onesweep': [("                        if (l >= k - 1) {\n                            done = true;                   // :256",
+                    "                        if (true) {\n                            done = true;                   // :256")],
+    'b_tabuniform': [("const OmniTabEntry &e = tabp[jj];", "const OmniTabEntry &e = tabp[k];")],
+    'b_nofirst': [("const bool need = (jj >= 2) && (fire_at < 0 || last);", "const bool need = (jj >= 2) && last;")],
 }
 
 if __name__ == '__main__':
