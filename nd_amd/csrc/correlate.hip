@@ -151,10 +151,16 @@ struct TiledArgs {
     int kh, oy0, ox0;           // window: input row = y + oy0 + i, input col = x + ox0 + j
     int mode;
     int tiles_x, tiles_y;
+    int64_t nbatch;             // planes
+    int ppb;                    // planes one block walks through
     double w[kMaxKH * kMaxKH];  // dense KH x KW weights, row-major (0 = tap absent)
 };
 
-template <typename T, int KW, bool BOX>
+// The block keeps its tile position and walks `ppb` consecutive planes of the batch: the border
+// maps and every thread's source offsets are computed once, and the loads of plane b+1 are in
+// flight (held in registers) while plane b is computed and stored.  KHB bounds the kernel height
+// the instantiation can stage (register array sizes).
+template <typename T, int KW, bool BOX, int KHB>
 __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T> a)
 {
     extern __shared__ __align__(16) unsigned char nd_smem_c[];
@@ -166,20 +172,19 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     const int tx = (int)(b % a.tiles_x);
     b /= a.tiles_x;
     const int ty = (int)(b % a.tiles_y);
-    const int64_t batch = b / a.tiles_y;
+    const int64_t b0 = (b / a.tiles_y) * a.ppb;
+    const int64_t b1 = b0 + a.ppb < a.nbatch ? b0 + a.ppb : a.nbatch;
     const int64_t x_base = (int64_t)tx * kTileX, y_base = (int64_t)ty * kTileY;
-    const T *plane = a.in + batch * a.sin_b;
 
-    // ---- stage the window.  The border rule is separable: one source row per staged row and one
-    // source column per staged column, computed once into small LDS tables; then every thread
-    // issues all of its loads before consuming the first one (coalesced along x). ----
+    // ---- once per block: the border rule is separable -- one source row per staged row and one
+    // source column per staged column go through small LDS tables into per-thread offsets ----
     const double wbox = a.w[0];
     constexpr int TW = kTileX + KW - 1;
     // LDS image: columns de-interleaved by (c mod 4), element (r, c) at (r*4 + (c&3)) * TWQ + (c>>2).
     // A thread's 4 adjacent outputs start at column 4*lane', so the lanes of one read instruction
     // hit consecutive doubles (conflict-free) instead of every fourth one (4-way conflict).
     constexpr int TWQ = (TW + 3) / 4;
-    constexpr int kMaxLoads = ((kTileY + kMaxKH - 1) * TW + 255) / 256;
+    constexpr int kMaxLoads = ((kTileY + KHB - 1) * TW + 255) / 256;
     const int n_el = th * TW;
     int *ymap = reinterpret_cast<int *>(tile + th * 4 * TWQ);
     int *xmap = ymap + th;
@@ -195,81 +200,104 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
         }
     }
     __syncthreads();
-    {
-        T buf[kMaxLoads];
+    int soff[kMaxLoads];           // source offset inside a plane (the host checks it fits 31 bits)
+    int doff[kMaxLoads];           // destination index in the LDS image
 #pragma unroll
-        for (int i = 0; i < kMaxLoads; ++i) {
-            const int e = tid + 256 * i;
-            if (e < n_el) {
-                const int r = e / TW, c = e - r * TW;
-                buf[i] = plane[(int64_t)ymap[r] * a.sin_y + xmap[c]];
-            }
+    for (int i = 0; i < kMaxLoads; ++i) {
+        const int e = tid + 256 * i;
+        soff[i] = 0;
+        doff[i] = 0;
+        if (e < n_el) {
+            const int r = e / TW, c = e - r * TW;
+            soff[i] = ymap[r] * (int)a.sin_y + xmap[c];
+            doff[i] = (r * 4 + (c & 3)) * TWQ + (c >> 2);
         }
+    }
+
+    T buf[kMaxLoads];
+    auto load_plane = [&](int64_t bb) {
+        const T *plane = a.in + bb * a.sin_b;
 #pragma unroll
-        for (int i = 0; i < kMaxLoads; ++i) {
-            const int e = tid + 256 * i;
-            if (e < n_el) {
-                const int r = e / TW, c = e - r * TW;
+        for (int i = 0; i < kMaxLoads; ++i)
+            if (tid + 256 * i < n_el) buf[i] = plane[soff[i]];
+    };
+    auto store_plane = [&]() {
+#pragma unroll
+        for (int i = 0; i < kMaxLoads; ++i)
+            if (tid + 256 * i < n_el) {
                 const double v = (double)buf[i];
-                tile[(r * 4 + (c & 3)) * TWQ + (c >> 2)] = BOX ? wbox * v : v;
+                tile[doff[i]] = BOX ? wbox * v : v;
             }
-        }
+    };
+    if (b0 < b1) {
+        load_plane(b0);
+        store_plane();
     }
     __syncthreads();
 
-    // ---- 4 x 4 outputs per thread ----
     const int lx = (tid % 32) * kOX, ly = (tid / 32) * kOY;
-    double acc[kOY][kOX];
-#pragma unroll
-    for (int oy = 0; oy < kOY; ++oy)
-#pragma unroll
-        for (int ox = 0; ox < kOX; ++ox) acc[oy][ox] = 0.0;
+    for (int64_t bb = b0; bb < b1; ++bb) {
+        const bool has_next = bb + 1 < b1;
+        if (has_next) load_plane(bb + 1);
 
-    for (int r = 0; r < kOY + kh - 1; ++r) {
-        double v[kOX + KW - 1];
-        const double *src = tile + (ly + r) * 4 * TWQ + (lx >> 2);      // lx is a multiple of 4
+        // ---- 4 x 4 outputs per thread ----
+        double acc[kOY][kOX];
 #pragma unroll
-        for (int c = 0; c < kOX + KW - 1; ++c) v[c] = src[(c & 3) * TWQ + (c >> 2)];
+        for (int oy = 0; oy < kOY; ++oy)
 #pragma unroll
-        for (int oy = 0; oy < kOY; ++oy) {
-            const int i = r - oy;                       // kernel row feeding output row oy
-            if (i >= 0 && i < kh) {
+            for (int ox = 0; ox < kOX; ++ox) acc[oy][ox] = 0.0;
+
+        for (int r = 0; r < kOY + kh - 1; ++r) {
+            double v[kOX + KW - 1];
+            const double *src = tile + (ly + r) * 4 * TWQ + (lx >> 2);      // lx is a multiple of 4
 #pragma unroll
-                for (int j = 0; j < KW; ++j) {
-                    const double w = a.w[i * KW + j];
-                    if (BOX || w != 0.0) {
+            for (int c = 0; c < kOX + KW - 1; ++c) v[c] = src[(c & 3) * TWQ + (c >> 2)];
 #pragma unroll
-                        for (int ox = 0; ox < kOX; ++ox) {
-                            if (BOX)
-                                acc[oy][ox] = acc[oy][ox] + v[ox + j];
-                            else
-                                acc[oy][ox] = acc[oy][ox] + w * v[ox + j];
+            for (int oy = 0; oy < kOY; ++oy) {
+                const int i = r - oy;                       // kernel row feeding output row oy
+                if (i >= 0 && i < kh) {
+#pragma unroll
+                    for (int j = 0; j < KW; ++j) {
+                        const double w = a.w[i * KW + j];
+                        if (BOX || w != 0.0) {
+#pragma unroll
+                            for (int ox = 0; ox < kOX; ++ox) {
+                                if (BOX)
+                                    acc[oy][ox] = acc[oy][ox] + v[ox + j];
+                                else
+                                    acc[oy][ox] = acc[oy][ox] + w * v[ox + j];
+                            }
                         }
                     }
                 }
             }
         }
-    }
 
-    T *oplane = a.out + batch * a.sout_b;
+        T *oplane = a.out + bb * a.sout_b;
 #pragma unroll
-    for (int oy = 0; oy < kOY; ++oy) {
-        const int64_t y = y_base + ly + oy;
-        if (y < a.ny) {
-            T *orow = oplane + y * a.sout_y;
-            const int64_t x = x_base + lx;
-            if (x + kOX <= a.nx && ((uintptr_t)(orow + x) % (sizeof(T) * kOX)) == 0) {
-                struct alignas(sizeof(T) * kOX) Out4 {
-                    T v[kOX];
-                } o;
+        for (int oy = 0; oy < kOY; ++oy) {
+            const int64_t y = y_base + ly + oy;
+            if (y < a.ny) {
+                T *orow = oplane + y * a.sout_y;
+                const int64_t x = x_base + lx;
+                if (x + kOX <= a.nx && ((uintptr_t)(orow + x) % (sizeof(T) * kOX)) == 0) {
+                    struct alignas(sizeof(T) * kOX) Out4 {
+                        T v[kOX];
+                    } o;
 #pragma unroll
-                for (int ox = 0; ox < kOX; ++ox) o.v[ox] = (T)acc[oy][ox];
-                *reinterpret_cast<Out4 *>(orow + x) = o;
-            } else {
+                    for (int ox = 0; ox < kOX; ++ox) o.v[ox] = (T)acc[oy][ox];
+                    *reinterpret_cast<Out4 *>(orow + x) = o;
+                } else {
 #pragma unroll
-                for (int ox = 0; ox < kOX; ++ox)
-                    if (x + ox < a.nx) orow[x + ox] = (T)acc[oy][ox];
+                    for (int ox = 0; ox < kOX; ++ox)
+                        if (x + ox < a.nx) orow[x + ox] = (T)acc[oy][ox];
+                }
             }
+        }
+        if (has_next) {
+            __syncthreads();               // every thread is done reading this plane's image
+            store_plane();
+            __syncthreads();
         }
     }
 }
@@ -278,12 +306,18 @@ template <typename T, int KW>
 static void launch_tiled(const TiledArgs<T> &a, bool box, int64_t nblocks, size_t lds,
                          hipStream_t stream)
 {
-    if (box)
-        hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, true>), dim3((unsigned)nblocks), dim3(256),
-                           lds, stream, a);
-    else
-        hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false>), dim3((unsigned)nblocks),
-                           dim3(256), lds, stream, a);
+    const dim3 grid((unsigned)nblocks), block(256);
+    if (a.kh <= 5) {
+        if (box)
+            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, true, 5>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false, 5>), grid, block, lds, stream, a);
+    } else {
+        if (box)
+            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, true, kMaxKH>), grid, block, lds, stream, a);
+        else
+            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false, kMaxKH>), grid, block, lds, stream, a);
+    }
 }
 
 // Try the tiled form; returns 1 if it was launched, 0 if the request does not fit it.
@@ -360,7 +394,18 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
         a.w[(offsets[4 * t + 2] - ymin) * kw + (offsets[4 * t + 3] - xmin)] = weights[t];
         if (weights[t] != weights[0]) box = false;
     }
-    const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * nb;
+    // source offsets inside one plane are kept as 32-bit integers
+    if ((dims[2] - 1) * (si[2] < 0 ? -si[2] : si[2]) + dims[3] > 0x7fffffffLL || si[2] < 0) return 0;
+    // each block walks `ppb` planes; keep at least ~2048 blocks in flight for small rasters
+    a.nbatch = nb;
+    {
+        const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y;
+        int64_t groups = ceil_div(2048, tiles);
+        if (groups > nb) groups = nb;
+        if (groups < 1) groups = 1;
+        a.ppb = (int)ceil_div(nb, groups);
+    }
+    const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * ceil_div(nb, (int64_t)a.ppb);
     if (nblocks > 0x7fffffffLL || nblocks < 1) return 0;
     const size_t twq = (size_t)(kTileX + kw - 1 + 3) / 4;
     const size_t lds = (size_t)(kTileY + kh - 1) * 4 * twq * sizeof(double) +
