@@ -184,8 +184,6 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     // A thread's 4 adjacent outputs start at column 4*lane', so the lanes of one read instruction
     // hit consecutive doubles (conflict-free) instead of every fourth one (4-way conflict).
     constexpr int TWQ = (TW + 3) / 4;
-    constexpr int kMaxLoads = ((kTileY + KHB - 1) * TW + 255) / 256;
-    const int n_el = th * TW;
     int *ymap = reinterpret_cast<int *>(tile + th * 4 * TWQ);
     int *xmap = ymap + th;
     for (int i = tid; i < th + TW; i += 256) {
@@ -200,33 +198,58 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
         }
     }
     __syncthreads();
-    int soff[kMaxLoads];           // source offset inside a plane (the host checks it fits 31 bits)
-    int doff[kMaxLoads];           // destination index in the LDS image
+    // Staging map.  Main part: thread (row parity p = tid / 128, column c = tid % 128) takes rows
+    // p, p + 2, ... of column c: the row offsets are wave-uniform (scalar registers), the column
+    // offset is one register, and the LDS destinations differ by compile-time constants.  The
+    // KW - 1 columns to the right of the 128th are spread over the threads element by element.
+    constexpr int NR = (kTileY + KHB - 1 + 1) / 2;
+    constexpr int NE = ((kTileY + KHB - 1) * (KW - 1) + 255) / 256;
+    const int wrow = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int c0 = tid & 127;
+    const int xo = xmap[c0];
+    const int dlane = (c0 & 3) * TWQ + (c0 >> 2);
+    int rowoff[NR];                // source offset of the row inside a plane (fits 31 bits, host)
 #pragma unroll
-    for (int i = 0; i < kMaxLoads; ++i) {
-        const int e = tid + 256 * i;
-        soff[i] = 0;
-        doff[i] = 0;
-        if (e < n_el) {
-            const int r = e / TW, c = e - r * TW;
-            soff[i] = ymap[r] * (int)a.sin_y + xmap[c];
-            doff[i] = (r * 4 + (c & 3)) * TWQ + (c >> 2);
+    for (int i = 0; i < NR; ++i) {
+        const int r = wrow + 2 * i;
+        rowoff[i] = __builtin_amdgcn_readfirstlane(r < th ? ymap[r] * (int)a.sin_y : 0);
+    }
+    int soff2[NE > 0 ? NE : 1], doff2[NE > 0 ? NE : 1];
+    const int n_edge = th * (KW - 1);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + 256 * j;
+        soff2[j] = 0;
+        doff2[j] = 0;
+        if (e < n_edge) {
+            const int r = e / (KW > 1 ? KW - 1 : 1), c = kTileX + (e - r * (KW - 1));
+            soff2[j] = ymap[r] * (int)a.sin_y + xmap[c];
+            doff2[j] = (r * 4 + (c & 3)) * TWQ + (c >> 2);
         }
     }
 
-    T buf[kMaxLoads];
+    T buf[NR], buf2[NE > 0 ? NE : 1];
     auto load_plane = [&](int64_t bb) {
         const T *plane = a.in + bb * a.sin_b;
 #pragma unroll
-        for (int i = 0; i < kMaxLoads; ++i)
-            if (tid + 256 * i < n_el) buf[i] = plane[soff[i]];
+        for (int i = 0; i < NR; ++i)
+            if (wrow + 2 * i < th) buf[i] = (plane + rowoff[i])[xo];
+#pragma unroll
+        for (int j = 0; j < NE; ++j)
+            if (tid + 256 * j < n_edge) buf2[j] = plane[soff2[j]];
     };
     auto store_plane = [&]() {
 #pragma unroll
-        for (int i = 0; i < kMaxLoads; ++i)
-            if (tid + 256 * i < n_el) {
+        for (int i = 0; i < NR; ++i)
+            if (wrow + 2 * i < th) {
                 const double v = (double)buf[i];
-                tile[doff[i]] = BOX ? wbox * v : v;
+                tile[(wrow + 2 * i) * 4 * TWQ + dlane] = BOX ? wbox * v : v;
+            }
+#pragma unroll
+        for (int j = 0; j < NE; ++j)
+            if (tid + 256 * j < n_edge) {
+                const double v = (double)buf2[j];
+                tile[doff2[j]] = BOX ? wbox * v : v;
             }
     };
     if (b0 < b1) {
