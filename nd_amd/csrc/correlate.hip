@@ -620,6 +620,193 @@ __global__ void __launch_bounds__(256) correlate1d_kernel(const Corr1dArgs<T> a)
     a.out[i[0] * a.so[0] + i[1] * a.so[1] + i[2] * a.so[2] + i[3] * a.so[3]] = (T)o;
 }
 
+// LDS-tiled form for x-contiguous arrays: a block computes 32 rows x 128 columns of outputs, where
+// "rows" run along the filtered axis (ALONG_X = false) or along any other axis (ALONG_X = true, the
+// filter then runs along the contiguous axis).  The tile plus the kernel's reach is staged as
+// doubles with the line extension applied (NI_ExtendLine keeps the line in a double buffer, cval
+// included), so every input element is read from memory once per tile instead of once per tap.
+// Like the 2-D tiled kernel the block keeps its tile position and walks `ppb` steps along one of
+// the two remaining axes: the extension and every thread's source offsets are computed once, and
+// the loads of the next step are in flight while the current one is computed.  A thread owns one
+// column and 16 rows; lanes read consecutive doubles (conflict-free).  Taps outermost, the 16
+// outputs innermost: each output still receives its terms in the order of the generic kernel.
+constexpr int kT1X = 128, kT1R = 32, kT1MaxW = 31;
+
+template <typename T>
+struct Corr1dTiledArgs {
+    const T *in;
+    T *out;
+    int64_t nrows, nx;          // extent of the row axis and of the contiguous axis
+    int64_t sr_in, sr_out;      // strides of the row axis
+    int64_t nb1;                // the two remaining axes; axis b1 is the one a block walks
+    int64_t sb0_in, sb1_in, sb0_out, sb1_out;
+    int tiles_x, tiles_r;
+    int ppb;                    // steps along b1 per block
+    int n, size1, size2, symmetric, mode;
+    double cval;
+    double w[kT1MaxW];
+};
+
+// NW: the largest number of weights the instantiation can stage (array sizes, LDS pitch).
+template <typename T, bool ALONG_X, int NW>
+__global__ void __launch_bounds__(256) correlate1d_tiled_kernel(const Corr1dTiledArgs<T> a)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_1[];
+    double *tile = reinterpret_cast<double *>(nd_smem_1);
+    const int tid = threadIdx.x;
+    const int reach = a.n - 1;                                   // size1 + size2
+    const int trows = ALONG_X ? kT1R : kT1R + reach;             // staged rows
+    const int ucols = ALONG_X ? kT1X + reach : kT1X;             // staged columns in use
+    constexpr int tcols = ALONG_X ? kT1X + NW - 1 : kT1X;        // row pitch of the image
+    constexpr int kMaxRows = ALONG_X ? kT1R : kT1R + NW - 1;
+    int *map = reinterpret_cast<int *>(tile + kMaxRows * tcols); // extended index per staged position
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int tr = (int)(b % a.tiles_r);
+    b /= a.tiles_r;
+    const int64_t ngroups = (a.nb1 + a.ppb - 1) / a.ppb;
+    const int64_t s0 = (b % ngroups) * a.ppb, b0 = b / ngroups;
+    const int64_t s1 = s0 + a.ppb < a.nb1 ? s0 + a.ppb : a.nb1;
+    const int64_t x0 = (int64_t)tx * kT1X, r0 = (int64_t)tr * kT1R;
+
+    // extended index of every staged position along the filtered axis (-1: cval); positions of
+    // the other axis beyond the array are clamped (their outputs are never stored)
+    const int nmap = ALONG_X ? ucols : trows;
+    const int64_t flen = ALONG_X ? a.nx : a.nrows, f0 = (ALONG_X ? x0 : r0) - a.size1;
+    for (int i = tid; i < nmap; i += 256) map[i] = (int)extend_line(f0 + i, flen, a.mode);
+    __syncthreads();
+
+    // Staging map: thread (row parity, column) takes every second row of its column.  ALONG_X: the
+    // `reach` extra columns right of the 128th go to (row = tid / 32 + 8 i, column = 128 + tid % 32).
+    // Offsets are relative to the step's base and fit 31 bits (host); -1 = constant extension.
+    constexpr int NR = ALONG_X ? kT1R / 2 : (kT1R + NW - 1 + 1) / 2;
+    const int sc = tid & (kT1X - 1), sp = tid >> 7;
+    int off[NR];
+    {
+        const int64_t col = ALONG_X ? (int64_t)map[sc] : (x0 + sc < a.nx ? x0 + sc : a.nx - 1);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int rr = sp + 2 * i;
+            off[i] = -1;
+            if (rr < trows) {
+                const int64_t row = ALONG_X ? (r0 + rr < a.nrows ? r0 + rr : a.nrows - 1) : (int64_t)map[rr];
+                if (row >= 0 && col >= 0) off[i] = (int)(row * a.sr_in + col);
+            }
+        }
+    }
+    int off2[4];
+    const int ec = kT1X + (tid & 31), er = tid >> 5;
+    if (ALONG_X) {
+        const int64_t ecol = ec < ucols ? (int64_t)map[ec] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = er + 8 * i;
+            const int64_t row = r0 + rr < a.nrows ? r0 + rr : a.nrows - 1;
+            off2[i] = ecol < 0 ? -1 : (int)(row * a.sr_in + ecol);
+        }
+    }
+
+    T buf[NR], buf2[4];
+    auto load_step = [&](int64_t st) {
+        const T *src = a.in + b0 * a.sb0_in + st * a.sb1_in;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            if (sp + 2 * i < trows && off[i] >= 0) buf[i] = src[off[i]];
+        if (ALONG_X && ec < ucols) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (off2[i] >= 0) buf2[i] = src[off2[i]];
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int rr = sp + 2 * i;
+            if (rr < trows) tile[rr * tcols + sc] = off[i] >= 0 ? (double)buf[i] : a.cval;
+        }
+        if (ALONG_X && ec < ucols) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                tile[(er + 8 * i) * tcols + ec] = off2[i] >= 0 ? (double)buf2[i] : a.cval;
+        }
+    };
+    if (s0 < s1) {
+        load_step(s0);
+        store_step();
+    }
+    __syncthreads();
+
+    const int c = sc, rpar = sp;
+    const int64_t x = x0 + c;
+    const double *fw = a.w + a.size1;
+    constexpr int step = ALONG_X ? 1 : tcols;             // distance between taps in the image
+    const double *p0 = ALONG_X ? tile + rpar * tcols + c + a.size1 : tile + (rpar + a.size1) * tcols + c;
+    constexpr int rstep = 2 * tcols;                      // distance between this thread's rows
+    constexpr int NO = kT1R / 2;
+    for (int64_t st = s0; st < s1; ++st) {
+        const bool has_next = st + 1 < s1;
+        if (has_next) load_step(st + 1);
+        // The thread's 16 rows go in two halves of 8, one after the other (a scheduling barrier
+        // keeps the halves apart: 16 outputs with their 32 operands in flight next to the prefetch
+        // buffer cost a wave of occupancy).
+        T *dst = a.out + b0 * a.sb0_out + st * a.sb1_out + x;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            constexpr int NH = NO / 2;
+            const double *ph = p0 + h * NH * rstep;
+            double o[NH];
+            if (a.symmetric != 0) {
+                const double w0 = fw[0];
+#pragma unroll
+                for (int i = 0; i < NH; ++i) o[i] = ph[i * rstep] * w0;
+                if (a.symmetric > 0) {
+#pragma unroll 1
+                    for (int j = -a.size1; j < 0; ++j) {
+                        const double wj = fw[j];
+                        const double *pa = ph + j * step, *pb = ph - j * step;
+#pragma unroll
+                        for (int i = 0; i < NH; ++i) o[i] = o[i] + (pa[i * rstep] + pb[i * rstep]) * wj;
+                    }
+                } else {
+#pragma unroll 1
+                    for (int j = -a.size1; j < 0; ++j) {
+                        const double wj = fw[j];
+                        const double *pa = ph + j * step, *pb = ph - j * step;
+#pragma unroll
+                        for (int i = 0; i < NH; ++i) o[i] = o[i] + (pa[i * rstep] - pb[i * rstep]) * wj;
+                    }
+                }
+            } else {
+                const double w0 = fw[a.size2];
+                const double *pz = ph + a.size2 * step;
+#pragma unroll
+                for (int i = 0; i < NH; ++i) o[i] = pz[i * rstep] * w0;
+#pragma unroll 1
+                for (int j = -a.size1; j < a.size2; ++j) {
+                    const double wj = fw[j];
+                    const double *pa = ph + j * step;
+#pragma unroll
+                    for (int i = 0; i < NH; ++i) o[i] = o[i] + pa[i * rstep] * wj;
+                }
+            }
+            if (x < a.nx) {
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const int64_t r = r0 + rpar + 2 * (h * NH + i);
+                    if (r < a.nrows) dst[r * a.sr_out] = (T)o[i];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (has_next) {
+            __syncthreads();
+            store_step();
+            __syncthreads();
+        }
+    }
+}
+
 template <typename T>
 static int correlate1d_impl(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
                             const int64_t so[4], int axis, int n, const double *weights, int mode,
@@ -661,6 +848,87 @@ static int correlate1d_impl(const void *in, void *out, const int64_t dims[4], co
         }
     }
     if (a.total == 0) return ND_AMD_OK;
+    static const bool no_tiled = getenv("ND_AMD_NO_TILED") != nullptr;
+    if (!no_tiled && n <= kT1MaxW && si[3] == 1 && so[3] == 1) {
+        // rows = the filtered axis, or (filter along the contiguous axis) axis 2; the two
+        // remaining axes form the batch
+        Corr1dTiledArgs<T> t;
+        const bool along_x = (axis == 3);
+        const int rax = along_x ? 2 : axis;
+        int bax[2], nbx = 0;
+        for (int d = 0; d < 3; ++d)
+            if (d != rax) bax[nbx++] = d;
+        t.in = a.in;
+        t.out = a.out;
+        t.nrows = dims[rax];
+        t.nx = dims[3];
+        t.sr_in = si[rax];
+        t.sr_out = so[rax];
+        t.nb1 = dims[bax[1]];
+        t.sb0_in = si[bax[0]];
+        t.sb1_in = si[bax[1]];
+        t.sb0_out = so[bax[0]];
+        t.sb1_out = so[bax[1]];
+        t.tiles_x = (int)ceil_div(dims[3], kT1X);
+        t.tiles_r = (int)ceil_div(dims[rax], kT1R);
+        t.n = n;
+        t.size1 = a.size1;
+        t.size2 = a.size2;
+        t.symmetric = a.symmetric;
+        t.mode = mode;
+        t.cval = cval;
+        for (int j = 0; j < kT1MaxW; ++j) t.w[j] = j < n ? weights[j] : 0.0;
+        // walk the longer of the two remaining axes; keep >= ~2048 blocks in flight
+        if (dims[bax[0]] > dims[bax[1]]) {
+            const int tmp = bax[0];
+            bax[0] = bax[1];
+            bax[1] = tmp;
+            t.nb1 = dims[bax[1]];
+            t.sb0_in = si[bax[0]];
+            t.sb1_in = si[bax[1]];
+            t.sb0_out = so[bax[0]];
+            t.sb1_out = so[bax[1]];
+        }
+        int64_t groups = 1;
+        {
+            const int64_t base_blocks = (int64_t)t.tiles_x * t.tiles_r * dims[bax[0]];
+            groups = ceil_div(2048, base_blocks < 1 ? 1 : base_blocks);
+            if (groups > t.nb1) groups = t.nb1;
+            if (groups < 1) groups = 1;
+            t.ppb = (int)ceil_div(t.nb1, groups);
+            if (t.ppb < 1) t.ppb = 1;
+            groups = ceil_div(t.nb1, (int64_t)t.ppb);
+        }
+        const int64_t nb = (int64_t)t.tiles_x * t.tiles_r * dims[bax[0]] * groups;
+        const int nwc = n <= 9 ? 9 : (n <= 17 ? 17 : (n <= 25 ? 25 : kT1MaxW));      // size class of the instantiation
+        const size_t trows = along_x ? kT1R : kT1R + nwc - 1, tcols = along_x ? kT1X + nwc - 1 : kT1X;
+        const size_t lds = trows * tcols * sizeof(double) + (along_x ? tcols : trows) * sizeof(int);
+        bool fits = nb <= 0x7fffffffLL && lds <= 64 * 1024 && si[rax] >= 0 && so[rax] >= 0;
+        for (int d = 0; d < 4; ++d)
+            if (dims[d] > 0x3fffffffLL) fits = false;
+        // offsets inside one step (row axis x contiguous axis) are kept as 32-bit integers
+        if ((dims[rax] - 1) * si[rax] + dims[3] > 0x7fffffffLL) fits = false;
+        if (fits) {
+            KernelTimer timer(ND_AMD_KERNEL_CORRELATE1D, stream);
+            const dim3 grid((unsigned)nb), block(256);
+#define ND_LAUNCH_1D(AX, NWC) \
+    hipLaunchKernelGGL((correlate1d_tiled_kernel<T, AX, NWC>), grid, block, lds, stream, t)
+            if (along_x) {
+                if (nwc == 9) ND_LAUNCH_1D(true, 9);
+                else if (nwc == 17) ND_LAUNCH_1D(true, 17);
+                else if (nwc == 25) ND_LAUNCH_1D(true, 25);
+                else ND_LAUNCH_1D(true, kT1MaxW);
+            } else {
+                if (nwc == 9) ND_LAUNCH_1D(false, 9);
+                else if (nwc == 17) ND_LAUNCH_1D(false, 17);
+                else if (nwc == 25) ND_LAUNCH_1D(false, 25);
+                else ND_LAUNCH_1D(false, kT1MaxW);
+            }
+#undef ND_LAUNCH_1D
+            ND_HIP_CHECK(hipGetLastError());
+            return ND_AMD_OK;
+        }
+    }
     const int64_t nblocks = ceil_div(a.total, 256);
     if (nblocks > 0x7fffffffLL) {
         set_error("nd_amd_correlate1d: array too large for one launch");

@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--what', default='boxcar')
     ap.add_argument('--k', type=int, default=24); ap.add_argument('--ny', type=int, default=4096); ap.add_argument('--nx', type=int, default=4096)
     ap.add_argument('--w', type=int, default=5); ap.add_argument('--r', type=int, default=10); ap.add_argument('--f', type=int, default=3)
-    ap.add_argument('--patch-mode', type=int, default=1)
+    ap.add_argument('--patch-mode', type=int, default=1); ap.add_argument('--sigma', type=float, default=1.0)
     ap.add_argument('--steps', type=int, default=5); ap.add_argument('--warmup', type=int, default=2)
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -42,6 +42,15 @@ def main():
                           'ms': dt * 1e3, 'Mpx_t_per_s': n / dt / 1e6, 'GBps_algorithmic': 8 * n / dt / 1e9,
                           'frac_hbm_peak': 8 * n / dt / 8e12, 'kernels_ms': km,
                           'tiled': os.environ.get('ND_AMD_NO_TILED') is None}))
+    elif a.what == 'gaussian':
+        x = torch.rand((a.k, a.ny, a.nx), generator=g, device=dev) + 0.5
+        out = torch.empty_like(x)
+        sig = (0.0, float(a.sigma), float(a.sigma))
+        dt, km = timed(lambda: kernels.gaussian_filter(x, sig, out=out), a.steps, a.warmup)
+        n = x.numel()
+        print(json.dumps({'workload': 'gaussian sigma=%g (y, x) on %dt x %d x %d f32' % (a.sigma, a.k, a.ny, a.nx),
+                          'ms': dt * 1e3, 'Mpx_t_per_s': n / dt / 1e6, 'GBps_algorithmic': 16 * n / dt / 1e9,
+                          'kernels_ms': km}))
     elif a.what == 'nlmeans':
         x = torch.empty((1, a.k, a.ny, a.nx), device=dev)
         x.copy_(torch.distributions.Gamma(4.0, 4.0).sample((1, a.k, a.ny, a.nx)).to(dev))
