@@ -1,4 +1,4 @@
-"""Tuning experiment (GPU box): ablations of omnibus pass A (retain form). Builds patched copies of
+"""Tuning experiment (GPU box): ablations of the omnibus kernels. Builds patched copies of
 nd_amd/csrc/omnibus.hip into gpurun_out/exp and times pass A / pass B with the library's event timers."""
 import os, subprocess, sys, json, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,12 +46,16 @@ def build_variant(name, patches, extra=()):
     subprocess.check_call([HIPCC] + FLAGS + list(extra) + ['-shared', '-o', so] + srcs)
     return so
 
+# name -> [(text in omnibus.hip, replacement)]; each patch must still match the current source
 VARIANTS = {
     'base': [],
+    # pass B: stop after the first sweep / never run marginal tests / never evaluate any test
     'b_onesweep': [("                        if (l >= k - 1) {\n                            done = true;                   // :256",
                     "                        if (true) {\n                            done = true;                   // :256")],
-    'b_tabuniform': [("const OmniTabEntry &e = tabp[jj];", "const OmniTabEntry &e = tabp[k];")],
     'b_nofirst': [("const bool need = (jj >= 2) && (fire_at < 0 || last);", "const bool need = (jj >= 2) && last;")],
+    'b_notests': [("const bool need = (jj >= 2) && (fire_at < 0 || last);", "const bool need = false && (jj >= 2) && (fire_at < 0 || last);")],
+    # pass A block size
+    't128': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 128")],
 }
 
 if __name__ == '__main__':
