@@ -12,7 +12,6 @@ import torch
 
 from . import _adapter, _device, _lib, kernels, synth
 from .algorithm import Algorithm, wrap_algorithm
-from .filters import BoxcarFilter
 from .io import disassemble_complex
 
 __all__ = ['ChangeDetection', 'OmnibusTest', 'omnibus', 'omnibus_statistics', 'change_count',
@@ -56,16 +55,27 @@ def _covariance_planes(ds_m, device):
     return stack
 
 
+def _multilook_planes(stack, ml):
+    """BoxcarFilter(w=ml) with dims ('y', 'x') (nd/change.py:61-63) applied to the planar stack
+    (4, time, y, x): every (variable, date) plane is filtered on its own, exactly as the filter
+    does variable by variable on the dataset -- same window, same weights ones / ml**2, scipy's
+    'reflect' border -- but without leaving the layout the omnibus kernel reads."""
+    kernel = (np.ones((ml, ml), dtype=np.float64) / ml ** 2).reshape(1, 1, ml, ml)
+    out = synth.empty_stack(stack.shape[0], stack.shape[1], stack.shape[2], stack.shape[3],
+                            stack.device, stack.dtype)
+    return kernels.convolve(stack, kernel, out=out)
+
+
 def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None, stats=False):
     ns = _adapter.namespace(ds)
     ds.persist() if hasattr(ds, 'persist') else None
     ds_m = disassemble_complex(ds)
-    if ml is not None:          # spatial multilooking first; the looks multiply accordingly
-        ds_m, n = BoxcarFilter(w=ml).apply(ds_m), ml * ml
     host = not any(_device.is_tensor(ds_m[v].values) for v in _VARS if v in ds_m.data_vars)
     dev = _device.device_of(*[ds_m[v].values for v in _VARS if v in ds_m.data_vars], device=device)
     with torch.cuda.device(dev):
         stack = _covariance_planes(ds_m, dev)
+        if ml is not None:      # spatial multilooking first; the looks multiply accordingly
+            stack, n = _multilook_planes(stack, int(ml)), ml * ml
         res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
                                        n=int(n), dims=('time', 'y', 'x'), stats=stats)
     change = res[0] if stats else res

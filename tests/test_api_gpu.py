@@ -387,3 +387,28 @@ def test_host_streamed_pipeline_equals_whole_raster(oracle, device, tmp_path):
         whole = streaming.nlmeans_omnibus_streamed(mm, r, f, 0.5, 0.5, alpha=0.9, n=9, n_eff=ne,
                                                    patch_mode=pm, rows_per_tile=90)
         np.testing.assert_array_equal(got, whole)
+
+
+def test_change_multilook_device_dataset_and_complex(oracle, device):
+    """ml on a device-resident dataset with a complex C12 (the form nd/change.py:59-63 sees): the
+    planar multilook path equals BoxcarFilter + OmnibusTest applied one after the other."""
+    import torch
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    from nd_amd.filters import BoxcarFilter
+    planes = synth.omnibus_stack(seed=16, k=7, ny=40, nx=150, looks=1, dtype=np.float32,
+                                 change_frac=0.3, factor=6.0)
+    yxt = [torch.from_numpy(np.ascontiguousarray(np.moveaxis(p, 0, -1))).to(device) for p in planes]
+    ds = xr_lite.Dataset()
+    ds['C11'] = (('y', 'x', 'time'), yxt[0])
+    ds['C12'] = (('y', 'x', 'time'), torch.complex(yxt[1], yxt[2]))
+    ds['C22'] = (('y', 'x', 'time'), yxt[3])
+    got = OmnibusTest(ml=5, alpha=0.9).apply(ds)
+    assert torch.is_tensor(got.values) and got.dims == ('y', 'x', 'time')
+    two_step = OmnibusTest(n=25, alpha=0.9).apply(BoxcarFilter(w=5).apply(ds))
+    assert torch.equal(got.values, two_step.values)
+    import scipy.ndimage as ndi
+    k = (np.ones((5, 5)) / 25).reshape(5, 5, 1)
+    ml = [ndi.convolve(np.moveaxis(p, 0, -1), k) for p in planes]
+    want = oracle.change_detection_planes([np.ascontiguousarray(a) for a in ml], 0.9, 25)
+    np.testing.assert_array_equal(got.values.cpu().numpy(), want.astype(bool))
