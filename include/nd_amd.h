@@ -52,6 +52,7 @@ extern "C" {
 #define ND_AMD_KERNEL_BOXCAR_TILED   5
 #define ND_AMD_KERNEL_NLMEANS_TILED  6
 #define ND_AMD_KERNEL_CORRELATE1D    7
+#define ND_AMD_KERNEL_RELAYOUT       8
 
 int nd_amd_abi_version(void);
 const char *nd_amd_last_error(void);
@@ -196,6 +197,30 @@ int nd_amd_nlmeans3d(const void *arr, void *out, int dtype,
                      const int64_t global_N[3], const int64_t tile_off[3],
                      const int64_t core_lo[3], const int64_t core_hi[3],
                      void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Layout change in front of the hot path.  The reference hands its native
+ * code a (y, x, time, variable) view with time (and variable) fastest
+ * (nd/change.py:66-67: to_array().transpose('y','x','time','variable'));
+ * the kernels above read planar (time, y, x) stacks.  For one variable that
+ * is already on the device:
+ *     out[t * out_date_stride + p] = in[p * k * in_date_stride + t * in_date_stride]
+ * p = flattened (y, x) pixel.  in_date_stride = 1 for a real (y, x, time)
+ * array, 2 for the real (in = base) or imaginary (in = base + 1) half of an
+ * interleaved complex array (C12).  out_date_stride >= npix.
+ * ---------------------------------------------------------------------- */
+int nd_amd_relayout_planar(const void *in, void *out, int dtype,
+                           int64_t npix, int64_t k, int64_t in_date_stride,
+                           int64_t out_date_stride, void *hip_stream);
+
+/* The way back (filter outputs handed to a caller that keeps the reference's
+ * layout, nd/filters.py:139-176):
+ *     out[p * k * out_date_stride + t * out_date_stride] = in[t * in_date_stride + p]
+ * out_date_stride = 1 or 2 (one half of an interleaved complex array),
+ * in_date_stride >= npix. */
+int nd_amd_relayout_pixel_major(const void *in, void *out, int dtype,
+                                int64_t npix, int64_t k, int64_t in_date_stride,
+                                int64_t out_date_stride, void *hip_stream);
 
 /* ------------------------------------------------------------------------
  * Per-kernel timing with HIP events recorded on the caller's stream

@@ -16,13 +16,15 @@ OK, EINVAL, EWORKSPACE, EHIP, ENOSOLUTION, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 MODES = {'reflect': 0, 'constant': 1, 'nearest': 2, 'mirror': 3, 'wrap': 4,
          'grid-constant': 1, 'grid-mirror': 0, 'grid-wrap': 4}
 KERNEL_NAMES = {1: 'omnibus_c2_global', 2: 'omnibus_c2_search', 3: 'correlate',
-                4: 'nlmeans', 5: 'boxcar_tiled', 6: 'nlmeans_tiled', 7: 'correlate1d'}
+                4: 'nlmeans', 5: 'boxcar_tiled', 6: 'nlmeans_tiled', 7: 'correlate1d',
+                8: 'relayout'}
 
 # every symbol include/nd_amd.h declares
 SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_omnibus_c2_workspace_bytes', 'nd_amd_omnibus_c2',
            'nd_amd_omnibus_c3_workspace_bytes', 'nd_amd_omnibus_c3',
            'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_nlmeans3d',
+           'nd_amd_relayout_planar', 'nd_amd_relayout_pixel_major',
            'nd_amd_timing_enable', 'nd_amd_timing_collect')
 
 _lib = None
@@ -73,6 +75,10 @@ def lib():
                                    C.POINTER(C.c_uint32), dbl, dbl, dbl, i32, i32, vp,
                                    C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(i64), vp]
+    L.nd_amd_relayout_planar.restype = i32
+    L.nd_amd_relayout_planar.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp]
+    L.nd_amd_relayout_pixel_major.restype = i32
+    L.nd_amd_relayout_pixel_major.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp]
     L.nd_amd_timing_enable.restype = i32
     L.nd_amd_timing_enable.argtypes = [i32]
     L.nd_amd_timing_collect.restype = i32

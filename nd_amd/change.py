@@ -43,15 +43,18 @@ def _covariance_planes(ds_m, device):
                 raise ValueError("variable %s lacks dimension '%s'" % (v, d))
         if len(da.dims) != 3:
             raise ValueError('variable %s must have exactly the dimensions y, x, time' % v)
-        arrs.append(da.transpose('time', 'y', 'x').values)
-    dtype = np.result_type(*[_device.np_dtype(a) for a in arrs])
+        arrs.append((da.transpose('time', 'y', 'x').values,
+                     da.transpose('y', 'x', 'time').values))
+    dtype = np.result_type(*[_device.np_dtype(a) for a, _ in arrs])
     if dtype not in (np.float32, np.float64):
         dtype = np.dtype(np.float64)           # integer / half input: the reference would refuse
     tdtype = torch.float32 if dtype == np.float32 else torch.float64
-    k, ny, nx = arrs[0].shape
+    k, ny, nx = arrs[0][0].shape
     stack = synth.empty_stack(4, k, ny, nx, device, tdtype)
-    for i, a in enumerate(arrs):
-        stack[i].copy_(_device.to_device(a, device))
+    for i, (tyx, yxt) in enumerate(arrs):
+        # device data in the reference's (y, x, time) layout goes through the transpose kernel
+        if not (_device.is_tensor(yxt) and yxt.dtype == tdtype and kernels.relayout_planar(yxt, stack[i])):
+            stack[i].copy_(_device.to_device(tyx, device))
     return stack
 
 
@@ -79,7 +82,7 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
         res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
                                        n=int(n), dims=('time', 'y', 'x'), stats=stats)
     change = res[0] if stats else res
-    change = change.bool()
+    change = change.view(torch.bool)            # 0 / 1 bytes: reinterpreted, not copied
     dims = ['y', 'x', 'time']
     data = change.cpu().numpy() if host else change
     change_arr = ns.DataArray(data, dims=dims, coords=ds.coords, attrs=ds.attrs, name='change')

@@ -134,6 +134,56 @@ def change_detection_c3(planes, alpha, n=1, dims=('time', 'y', 'x'), stats=False
 
 
 # ---------------------------------------------------------------------------
+# layout change in front of the hot path
+# ---------------------------------------------------------------------------
+def relayout_planar(src, dst):
+    """Copy a device variable laid out (y, x, time) with time fastest -- the reference's own
+    layout -- into the planar (time, y, x) view `dst` (x fastest, any plane pitch).  `src` may be
+    a real tensor, or the `.real` / `.imag` view of an interleaved complex tensor.  Returns False
+    (nothing done) when the layouts are not of that form; the caller then copies through torch."""
+    if not (torch.is_tensor(src) and src.is_cuda and src.dim() == 3 and dst.dim() == 3):
+        return False
+    ny, nx, k = src.shape
+    if tuple(dst.shape) != (k, ny, nx) or src.dtype != dst.dtype or src.dtype not in _DT:
+        return False
+    if ny * nx * k == 0:
+        return True
+    ids = src.stride(2)
+    if ids not in (1, 2) or src.stride(1) != k * ids or src.stride(0) != nx * k * ids:
+        return False
+    if dst.stride(2) != 1 or dst.stride(1) != nx or dst.stride(0) < ny * nx:
+        return False
+    dev = src.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nd_amd_relayout_planar(
+            _ptr(src), _ptr(dst), _DT[src.dtype], ny * nx, k, ids, dst.stride(0), _stream_ptr(dev)))
+    return True
+
+
+def relayout_pixel_major(src, dst):
+    """Inverse of relayout_planar: planar (time, y, x) `src` (x fastest, any plane pitch) into
+    `dst` laid out (y, x, time) with time fastest (a real tensor or one half of a complex one).
+    Returns False when the layouts are not of that form."""
+    if not (torch.is_tensor(dst) and dst.is_cuda and src.is_cuda and src.dim() == 3 and dst.dim() == 3):
+        return False
+    ny, nx, k = dst.shape
+    if tuple(src.shape) != (k, ny, nx) or src.dtype != dst.dtype or src.dtype not in _DT:
+        return False
+    if ny * nx * k == 0:
+        return True
+    ods = dst.stride(2)
+    if ods not in (1, 2) or dst.stride(1) != k * ods or dst.stride(0) != nx * k * ods:
+        return False
+    if src.stride(2) != 1 or src.stride(1) != nx or src.stride(0) < ny * nx:
+        return False
+    dev = src.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nd_amd_relayout_pixel_major(
+            _ptr(src), _ptr(dst), _DT[src.dtype], ny * nx, k, src.stride(0), ods, _stream_ptr(dev)))
+    return True
+
+
+# ---------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------
 def footprint(weights, origin=0, convolution=True):
@@ -219,13 +269,21 @@ def convolve(inp, kernel, out=None, mode='reflect', cval=0.0, origin=0):
             and inp.numel() >= (1 << 16)):
         perm = [d for d in range(nd) if d not in span] + span
         origins = [int(origin)] * nd if np.isscalar(origin) else [int(o) for o in origin]
-        t = inp.permute(*perm).contiguous()
         k = np.transpose(kernel, perm)
-        o = torch.empty_like(t)
         offs, w = footprint(k, [origins[d] for d in perm], convolution=True)
+        # the reference's (y, x, time) layout with a (y, x) window: dedicated transpose kernels
+        t = None
+        if nd == 3 and span == [0, 1]:
+            t = torch.empty((inp.shape[2], inp.shape[0], inp.shape[1]), dtype=inp.dtype, device=inp.device)
+            if not relayout_planar(inp, t):
+                t = None
+        if t is None:
+            t = inp.permute(*perm).contiguous()
+        o = torch.empty_like(t)
         correlate_footprint(t, o, offs, w, mode, cval)
-        inv = [perm.index(d) for d in range(nd)]
-        out.copy_(o.permute(*inv))
+        if not (nd == 3 and span == [0, 1] and relayout_pixel_major(o, out)):
+            inv = [perm.index(d) for d in range(nd)]
+            out.copy_(o.permute(*inv))
         return out
     offs, w = footprint(kernel, origin, convolution=True)
     return correlate_footprint(inp, out, offs, w, mode, cval)

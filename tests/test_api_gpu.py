@@ -412,3 +412,58 @@ def test_change_multilook_device_dataset_and_complex(oracle, device):
     ml = [ndi.convolve(np.moveaxis(p, 0, -1), k) for p in planes]
     want = oracle.change_detection_planes([np.ascontiguousarray(a) for a in ml], 0.9, 25)
     np.testing.assert_array_equal(got.values.cpu().numpy(), want.astype(bool))
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_relayout_planar_kernel(device, dtype):
+    """(y, x, time) -> planar (time, y, x): real arrays, the two halves of a complex array, odd
+    sizes, long series, padded destination planes; anything else is declined."""
+    import torch
+    from nd_amd import kernels, synth as dsynth
+    rng = np.random.default_rng(61)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    for ny, nx, k in [(1, 1, 1), (3, 5, 2), (17, 33, 24), (64, 64, 7), (9, 300, 100), (2, 70, 700), (32, 32, 24)]:
+        a = rng.normal(size=(ny, nx, k)).astype(dtype)
+        src = torch.from_numpy(a).to(device)
+        dst = dsynth.empty_stack(1, k, ny, nx, device, tdt)[0]
+        assert kernels.relayout_planar(src, dst)
+        np.testing.assert_array_equal(dst.cpu().numpy(), a.transpose(2, 0, 1))
+        c = torch.complex(src, torch.from_numpy(rng.normal(size=(ny, nx, k)).astype(dtype)).to(device))
+        for part in (c.real, c.imag):
+            out = torch.full((k, ny, nx), 7.0, dtype=tdt, device=device)
+            assert kernels.relayout_planar(part, out)
+            assert torch.equal(out, part.permute(2, 0, 1))
+    # not the reference layout: declined, destination untouched
+    src = torch.zeros((4, 6, 5), dtype=tdt, device=device)
+    dst = torch.ones((5, 4, 6), dtype=tdt, device=device)
+    assert not kernels.relayout_planar(src.permute(1, 0, 2), dst.permute(0, 2, 1))
+    assert not kernels.relayout_planar(src[:, ::2], torch.ones((5, 4, 3), dtype=tdt, device=device))
+    assert bool((dst == 1).all())
+
+
+def test_relayout_round_trip_and_filter_on_reference_layout(device):
+    """planar -> (y, x, time) inverse kernel; BoxcarFilter on device variables in the reference's
+    layout (real and complex) goes through both transposes and still equals scipy bit for bit."""
+    import scipy.ndimage as ndi
+    import torch
+    from nd_amd import kernels, xr_lite
+    from nd_amd.filters import BoxcarFilter
+    rng = np.random.default_rng(62)
+    for ny, nx, k in [(1, 1, 1), (5, 7, 3), (33, 65, 24), (10, 300, 90)]:
+        a = torch.from_numpy(rng.normal(size=(k, ny, nx)).astype(np.float32)).to(device)
+        out = torch.full((ny, nx, k), 3.0, device=device)
+        assert kernels.relayout_pixel_major(a, out)
+        assert torch.equal(out, a.permute(1, 2, 0))
+        c = torch.zeros((ny, nx, k), dtype=torch.complex64, device=device)
+        assert kernels.relayout_pixel_major(a, c.imag) and kernels.relayout_pixel_major(a * 2, c.real)
+        assert torch.equal(c.imag, a.permute(1, 2, 0)) and torch.equal(c.real, (a * 2).permute(1, 2, 0))
+    re = rng.normal(size=(70, 260, 5)).astype(np.float32)
+    im = rng.normal(size=(70, 260, 5)).astype(np.float32)
+    ds = xr_lite.Dataset()
+    ds['A'] = (('y', 'x', 'time'), torch.from_numpy(re).to(device))
+    ds['B'] = (('y', 'x', 'time'), torch.complex(torch.from_numpy(re), torch.from_numpy(im)).to(device))
+    res = BoxcarFilter(w=3).apply(ds)
+    kern = (np.ones((3, 3)) / 9).reshape(3, 3, 1)
+    np.testing.assert_array_equal(res['A'].values.cpu().numpy(), ndi.convolve(re, kern))
+    np.testing.assert_array_equal(res['B'].values.real.cpu().numpy(), ndi.convolve(re, kern))
+    np.testing.assert_array_equal(res['B'].values.imag.cpu().numpy(), ndi.convolve(im, kern))
