@@ -326,8 +326,10 @@ class NLMeansFilter(Filter):
             t = _device.to_device(arr, dev)
             t4 = t[(None,) * (4 - t.dim())]
             # The tiled kernels want planar memory (variable outermost) with the last windowed
-            # axis contiguous; datasets arrive with the variable axis fastest.  Re-lay the data out
-            # on the device (one transpose pass each way) when that is the case.
+            # axis contiguous; datasets arrive with the variable axis fastest or -- stacked from
+            # the reference's (y, x, time) variables -- with time fastest.  Re-lay the data out on
+            # the device when that is the case: through the transpose kernels where each variable
+            # is a (y, x, time)-ordered block, through a torch copy otherwise.
             if r[2] == 0 and f[2] == 0:
                 fwd, back = (3, 2, 0, 1), (2, 3, 1, 0)       # memory (var, axis2, axis0, axis1)
                 fast = t4.stride(1) == 1
@@ -335,16 +337,27 @@ class NLMeansFilter(Filter):
                 fwd, back = (3, 0, 1, 2), (1, 2, 3, 0)       # memory (var, axis0, axis1, axis2)
                 fast = t4.stride(2) == 1
             relayout = (not fast) and t4.dtype == torch.float32 and t4.numel() >= (1 << 14)
-            src = t4.permute(*fwd).contiguous().permute(*back) if relayout else t4
-            if _device.is_tensor(output) and not relayout:
-                out4 = output[(None,) * (4 - output.dim())]
-            elif relayout:
-                out4 = torch.empty_like(src.permute(*fwd)).permute(*back)
+            pm = 0 if self.patch_distances == 'reference' else 1
+            if not relayout:
+                out4 = (output[(None,) * (4 - output.dim())] if _device.is_tensor(output)
+                        else torch.empty_like(t4))
+                kernels.pixelwise_nlmeans_3d(t4, out4, r, f, self.sigma, self.h, self.n_eff,
+                                             patch_mode=pm)
             else:
-                out4 = torch.empty_like(t4)
-            kernels.pixelwise_nlmeans_3d(
-                src, out4, r, f, self.sigma, self.h, self.n_eff,
-                patch_mode=0 if self.patch_distances == 'reference' else 1)
+                pv = t4.permute(*fwd)                                      # (var, A, B, C) view
+                planar = torch.empty(pv.shape, dtype=t4.dtype, device=dev)
+                if not all(kernels.relayout_planar(pv[v].permute(1, 2, 0), planar[v])
+                           for v in range(pv.shape[0])):
+                    planar.copy_(pv)
+                planar_out = torch.empty_like(planar)
+                kernels.pixelwise_nlmeans_3d(planar.permute(*back), planar_out.permute(*back), r, f,
+                                             self.sigma, self.h, self.n_eff, patch_mode=pm)
+                out4 = planar_out.permute(*back)
+                if _device.is_tensor(output):
+                    ov = output[(None,) * (4 - output.dim())].permute(*fwd)
+                    if all(kernels.relayout_pixel_major(planar_out[v], ov[v].permute(1, 2, 0))
+                           for v in range(ov.shape[0])):
+                        return
             if _device.is_tensor(output):
                 if out4.data_ptr() != output.data_ptr():
                     output.copy_(out4.reshape(output.shape))
