@@ -1,4 +1,6 @@
 """nd_amd/_device.py -- host <-> device plumbing (numpy arrays in, torch ROCm tensors on the GPU)."""
+import warnings
+
 import numpy as np
 import torch
 
@@ -27,9 +29,10 @@ def to_device(a, device):
     a = np.asarray(a)
     if not a.flags.c_contiguous:
         a = np.ascontiguousarray(a)
-    if not a.flags.writeable:
-        a = a.copy()
-    return torch.from_numpy(a).to(device)
+    with warnings.catch_warnings():
+        # read-only sources (memory maps, xarray views) are only read
+        warnings.filterwarnings('ignore', message='The given NumPy array is not writable')
+        return torch.from_numpy(a).to(device)
 
 
 def write_back(result, output):
@@ -37,8 +40,20 @@ def write_back(result, output):
     if is_tensor(output):
         output.copy_(result)
     else:
-        output[...] = result.cpu().numpy()
+        output[...] = to_host(result)
     return output
+
+
+def to_host(t):
+    """Device tensor -> numpy array.  The download goes into page-locked memory (several times
+    faster than into pageable memory) and the returned array is a view of that buffer."""
+    if not t.is_cuda:
+        return t.numpy()
+    if t.numel() * t.element_size() < (32 << 20):
+        return t.cpu().numpy()              # small: a page-locked allocation costs more than it saves
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t)
+    return host.numpy()
 
 
 _TORCH2NP = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16,
