@@ -62,6 +62,17 @@ def expand_variables(da, dim='variable'):
     return out
 
 
+def empty_like(da):
+    """A DataArray with the dims / coords / attrs / name of `da` and uninitialised values of the same
+    type, dtype and device: the output buffer of a filter, which overwrites every element."""
+    vals = da.values
+    blank = torch.empty_like(vals) if (torch is not None and isinstance(vals, torch.Tensor)) \
+        else np.empty_like(vals)
+    if namespace(da) is xr_lite:
+        return xr_lite.DataArray(blank, da.dims, da.coords, da.attrs, da.name)
+    return da.copy(deep=False, data=blank)
+
+
 def is_complex(ds):
     ns = namespace(ds)
     if isinstance(ds, ns.DataArray):

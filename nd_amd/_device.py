@@ -39,6 +39,13 @@ def write_back(result, output):
     """Store a device tensor into `output` in place (numpy array view or torch tensor)."""
     if is_tensor(output):
         output.copy_(result)
+    elif (result.is_cuda and output.flags.c_contiguous and output.flags.writeable
+          and result.numel() * result.element_size() >= (32 << 20)
+          and output.dtype == np_dtype(result)):
+        # large host target: download into page-locked memory, then a multi-threaded host copy
+        host = torch.empty(result.shape, dtype=result.dtype, pin_memory=True)
+        host.copy_(result)
+        torch.from_numpy(output).copy_(host.reshape(output.shape))
     else:
         output[...] = to_host(result)
     return output

@@ -79,33 +79,83 @@ class Filter(Algorithm):
         (nd/filters.py:121-123)."""
         if inplace:
             raise NotImplementedError('Inplace filtering is not currently implemented.')
-        split_complex = (not self.supports_complex) and _adapter.is_complex(ds)
+        staged = self._stage_on_device(ds)
+        work = ds if staged is None else staged
+        split_complex = (not self.supports_complex) and _adapter.is_complex(work)
         if split_complex:
-            disassemble_complex(ds, inplace=True)
-        if isinstance(ds, _adapter.namespace(ds).DataArray):
-            result = self._apply_array(ds)
+            # on `ds` itself like the reference does (and undoes below), or on the private staged
+            # copy, which leaves the caller's dataset alone altogether
+            disassemble_complex(work, inplace=True)
+        if isinstance(work, _adapter.namespace(work).DataArray):
+            result = self._apply_array(work)
         elif self.per_variable:
-            result = self._apply_each(ds)
+            result = self._apply_each(work)
         else:
-            result = self._apply_stacked(ds)
-        if split_complex:
+            result = self._apply_stacked(work)
+        if staged is not None:
+            result = self._fetch_to_host(result, ds)
+        elif split_complex:
             # the caller's dataset gets its complex variables back; the result keeps the split
             # form, as it does in the reference (nd/filters.py:186-188)
             assemble_complex(ds, inplace=True)
         return result
 
+    def _stage_on_device(self, ds):
+        """Host-resident nd_amd.xr_lite data: upload every variable the filter touches once, in its
+        own layout, and let the device-resident path do all the re-ordering (stacking, transposes)
+        at HBM speed -- on the host the same steps run at 1-2 GB/s.  None = leave `ds` as it is
+        (already on the device, or an xarray object, whose variables must stay numpy)."""
+        from . import xr_lite
+        if _adapter.namespace(ds) is not xr_lite:
+            return None
+        if isinstance(ds, xr_lite.DataArray):
+            if _device.is_tensor(ds.values):
+                return None
+            dev = _device.device_of(ds.values)
+            return xr_lite.DataArray(_device.to_device(ds.values, dev), ds.dims, ds.coords, ds.attrs,
+                                     ds.name)
+        names = _adapter.get_vars_for_dims(ds, self.dims)
+        if not names or any(_device.is_tensor(ds[n].values) for n in names):
+            return None
+        dev = _device.device_of(*[ds[n].values for n in names])
+        out = ds.copy(deep=False)
+        for n in names:
+            out[n] = (tuple(ds[n].dims), _device.to_device(ds[n].values, dev), ds[n].attrs)
+        return out
+
+    def _fetch_to_host(self, result, ds):
+        """Results of a staged run back as numpy (page-locked downloads for large arrays)."""
+        from . import xr_lite
+        if isinstance(result, xr_lite.DataArray):
+            return xr_lite.DataArray(_device.to_host(result.values), result.dims, result.coords,
+                                     result.attrs, result.name)
+        for n in list(result.data_vars):
+            if _device.is_tensor(result[n].values):
+                result[n] = (tuple(result[n].dims), _device.to_host(result[n].values),
+                             result[n].attrs)
+        return result
+
     def _axes_in(self, dims):
         return tuple(dims.index(d) for d in self.dims)
 
+    # `_filter` overwrites every element of its output, so the result starts from uninitialised
+    # buffers instead of the reference's deep copy of the input (a host copy of the whole dataset
+    # would cost more than the filter); variables that are not filtered are still copied.
     def _apply_array(self, da):
-        out = da.copy(deep=True)
+        out = _adapter.empty_like(da)
         self._filter(da.values, self._axes_in(out.dims), output=out.values)
         return out
 
     def _apply_each(self, ds):
-        out = ds.copy(deep=True)
-        for name in _adapter.get_vars_for_dims(ds, self.dims):
-            self._filter(ds[name].values, self._axes_in(out[name].dims), output=out[name].values)
+        out = ds.copy(deep=False)
+        names = _adapter.get_vars_for_dims(ds, self.dims)
+        for name in ds.data_vars:
+            if name in names:
+                target = _adapter.empty_like(ds[name])
+                self._filter(ds[name].values, self._axes_in(target.dims), output=target.values)
+                out[name] = target
+            else:
+                out[name] = ds[name].copy(deep=True)
         return out
 
     def _apply_stacked(self, ds):
@@ -113,7 +163,7 @@ class Filter(Algorithm):
         passthrough = _adapter.get_vars_for_dims(ds, self.dims, invert=True)
         order = self.dims + tuple(d for d in ds.dims if d not in self.dims) + ('variable',)
         stacked = ds[names].to_array().transpose(*order)
-        filtered = stacked.copy(deep=True)
+        filtered = _adapter.empty_like(stacked)
         self._filter(stacked.values, self._axes_in(stacked.dims), output=filtered.values)
         out = _adapter.expand_variables(filtered)
         for name in list(out.data_vars):
@@ -203,8 +253,16 @@ class ConvolutionFilter(Filter):
                                          torch.view_as_real(output).unbind(-1)):
                 _convolve_into(part_in, nd_kernel, part_out, **self.kwargs)
         else:
-            _convolve_into(arr.real, nd_kernel, output.real, **self.kwargs)
-            _convolve_into(arr.imag, nd_kernel, output.imag, **self.kwargs)
+            # host complex array: one upload and one download of the interleaved data, the two
+            # halves are filtered as strided views on the device
+            dev = _device.device_of(arr, output)
+            with torch.cuda.device(dev):
+                t = _device.to_device(arr, dev)
+                o = torch.empty_like(t)
+                for part_in, part_out in zip(torch.view_as_real(t).unbind(-1),
+                                             torch.view_as_real(o).unbind(-1)):
+                    _convolve_into(part_in, nd_kernel, part_out, **self.kwargs)
+                _device.write_back(o, output)
 
 
 convolution = wrap_algorithm(ConvolutionFilter, 'convolution')

@@ -467,3 +467,34 @@ def test_relayout_round_trip_and_filter_on_reference_layout(device):
     np.testing.assert_array_equal(res['A'].values.cpu().numpy(), ndi.convolve(re, kern))
     np.testing.assert_array_equal(res['B'].values.real.cpu().numpy(), ndi.convolve(re, kern))
     np.testing.assert_array_equal(res['B'].values.imag.cpu().numpy(), ndi.convolve(im, kern))
+
+
+def test_host_dataset_is_staged_once_and_left_untouched(oracle, device):
+    """numpy datasets go to the device variable by variable in their own layout; the caller's
+    dataset (complex variable, attributes, values) is the same afterwards, the result is numpy and
+    equals the oracle."""
+    from nd_amd import xr_lite
+    from nd_amd.filters import NLMeansFilter, BoxcarFilter
+    rng = np.random.default_rng(71)
+    a = rng.gamma(4.0, 0.25, (30, 40, 4)).astype(np.float32)
+    c = (rng.normal(size=(30, 40, 4)) + 1j * rng.normal(size=(30, 40, 4))).astype(np.complex64)
+    ds = xr_lite.Dataset()
+    ds['A'] = (('y', 'x', 'time'), a.copy(), {'unit': 'dB'})
+    ds['C'] = (('y', 'x', 'time'), c.copy())
+    ds['scalar_per_date'] = (('time',), np.arange(4.0))
+    out = NLMeansFilter(dims=('y', 'x'), r=2, f=1, sigma=0.5, h=0.5).apply(ds)
+    assert sorted(ds.data_vars) == ['A', 'C', 'scalar_per_date'] and np.iscomplexobj(ds['C'].values)
+    np.testing.assert_array_equal(ds['A'].values, a)
+    np.testing.assert_array_equal(ds['C'].values, c)
+    assert sorted(out.data_vars) == ['A', 'C__im', 'C__re', 'scalar_per_date']
+    assert all(isinstance(out[n].values, np.ndarray) for n in out.data_vars)
+    names = ['A', 'C__re', 'C__im']
+    order = [n for n in out.data_vars if n in names]
+    stacked = np.ascontiguousarray(np.stack([{'A': a, 'C__re': c.real, 'C__im': c.imag}[n] for n in order], axis=-1))
+    want = np.empty_like(stacked)
+    oracle.pixelwise_nlmeans_3d(stacked, want, (2, 2, 0), (1, 1, 0), 0.5, 0.5, -1, njobs=4, patch_mode=0)
+    for i, n in enumerate(order):
+        np.testing.assert_array_equal(out[n].values, want[..., i])
+    np.testing.assert_array_equal(out['scalar_per_date'].values, np.arange(4.0))
+    box = BoxcarFilter(w=3).apply(ds)
+    assert np.iscomplexobj(box['C'].values) and box['A'].attrs.get('unit') == 'dB'
