@@ -18,6 +18,9 @@ __all__ = ['ChangeDetection', 'OmnibusTest', 'omnibus', 'omnibus_statistics', 'c
            'first_change']
 
 _VARS = ['C11', 'C12__re', 'C12__im', 'C22']      # column order of nd/change.py:66
+# full-pol extension (no reference counterpart): plane order of nd_amd_omnibus_c3
+_VARS3 = ['C11', 'C22', 'C33', 'C12__re', 'C12__im', 'C13__re', 'C13__im', 'C23__re', 'C23__im']
+_COMPLEX = {'C12', 'C13', 'C23'}
 
 
 class ChangeDetection(Algorithm):
@@ -29,14 +32,14 @@ class ChangeDetection(Algorithm):
         self.njobs = njobs
 
 
-def _covariance_planes(ds_m, device):
-    """The four variables as one planar device stack (4, time, y, x), x fastest -- the layout the
-    streaming kernel wants (coalesced along x, one plane per date)."""
+def _covariance_planes(ds_m, device, names=_VARS):
+    """The covariance terms `names` as one planar device stack (len(names), time, y, x), x fastest
+    -- the layout the streaming kernel wants (coalesced along x, one plane per date)."""
     arrs = []
-    for v in _VARS:
+    for v in names:
         if v not in ds_m.data_vars:
             raise KeyError("OmnibusTest needs the variables C11, C12 (or C12__re/C12__im) and "
-                           "C22; '%s' is missing" % v)
+                           "C22 (plus C33, C13, C23 for full-pol data); '%s' is missing" % v)
         da = ds_m[v]
         for d in ('y', 'x', 'time'):
             if d not in da.dims:
@@ -50,7 +53,7 @@ def _covariance_planes(ds_m, device):
         dtype = np.dtype(np.float64)           # integer / half input: the reference would refuse
     tdtype = torch.float32 if dtype == np.float32 else torch.float64
     k, ny, nx = arrs[0][0].shape
-    stack = synth.empty_stack(4, k, ny, nx, device, tdtype)
+    stack = synth.empty_stack(len(names), k, ny, nx, device, tdtype)
     for i, (tyx, yxt) in enumerate(arrs):
         # device data in the reference's (y, x, time) layout goes through the transpose kernel
         if not (_device.is_tensor(yxt) and yxt.dtype == tdtype and kernels.relayout_planar(yxt, stack[i])):
@@ -73,7 +76,7 @@ def _on_device(ds, device):
     """The covariance variables of a host dataset as device tensors in their own layout (complex
     C12 included): one plain upload each -- re-ordering 6 GB on the host would take seconds, on the
     device it is a 3 ms transpose (nd_amd_relayout_planar)."""
-    wanted = set(_VARS) | {'C12'}
+    wanted = set(_VARS3) | _COMPLEX
     out = xr_lite.Dataset()
     for name in ds.data_vars:
         if name in wanted:
@@ -85,16 +88,21 @@ def _on_device(ds, device):
 def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None, stats=False):
     ns = _adapter.namespace(ds)
     ds.persist() if hasattr(ds, 'persist') else None
-    present = [v for v in list(ds.data_vars) if v in set(_VARS) | {'C12'}]
+    present = [v for v in list(ds.data_vars) if v in set(_VARS3) | _COMPLEX]
+    full_pol = 'C33' in present            # 3 x 3 covariance: the extension kernel
     host = not any(_device.is_tensor(ds[v].values) for v in present)
     dev = _device.device_of(*[ds[v].values for v in present], device=device)
     with torch.cuda.device(dev):
         ds_m = disassemble_complex(_on_device(ds, dev) if host else ds)
-        stack = _covariance_planes(ds_m, dev)
+        stack = _covariance_planes(ds_m, dev, _VARS3 if full_pol else _VARS)
         if ml is not None:      # spatial multilooking first; the looks multiply accordingly
             stack, n = _multilook_planes(stack, int(ml)), ml * ml
-        res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
-                                       n=int(n), dims=('time', 'y', 'x'), stats=stats)
+        if full_pol:
+            res = kernels.change_detection_c3(list(stack), alpha=alpha, n=int(n),
+                                              dims=('time', 'y', 'x'), stats=stats)
+        else:
+            res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
+                                           n=int(n), dims=('time', 'y', 'x'), stats=stats)
     change = res[0] if stats else res
     change = change.view(torch.bool)            # 0 / 1 bytes: reinterpreted, not copied
     dims = ['y', 'x', 'time']
@@ -121,7 +129,9 @@ class OmnibusTest(ChangeDetection):
     device  optional torch device for host inputs (default: the current ROCm device)
     njobs   accepted and stored like in the reference; one GPU launch covers the whole raster
 
-    `apply(ds)` returns the boolean DataArray 'change' with dimensions ('y', 'x', 'time')."""
+    `apply(ds)` returns the boolean DataArray 'change' with dimensions ('y', 'x', 'time').
+    A dataset that also carries C33 (and C13, C23) is treated as full-pol 3 x 3 data: same test
+    with p = 3 (an extension; the reference is dual-pol only)."""
 
     def __init__(self, ml=None, n=1, alpha=0.01, *args, **kwargs):
         _lib.lib()          # ImportError when libnd_amd.so is missing, like nd/change.py:106-108

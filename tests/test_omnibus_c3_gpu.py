@@ -45,3 +45,36 @@ def test_c3_layouts_and_tails(oracle, device):
     for layout in ('tyx', 'yxt'):
         ch, _, _ = _run(planes, 0.9, 4, device, layout)
         np.testing.assert_array_equal(ch, want)
+
+
+def test_omnibus_test_class_detects_full_pol(oracle, device):
+    """OmnibusTest.apply on a dataset with C33 / C13 / C23 runs the 3 x 3 test (host and device
+    datasets, complex cross terms)."""
+    import torch
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    rng = np.random.default_rng(81)
+    k, ny, nx, looks = 8, 12, 70, 9
+    s = (rng.normal(size=(3, looks, k, ny, nx)) + 1j * rng.normal(size=(3, looks, k, ny, nx))) / np.sqrt(2)
+    gain = np.where((np.arange(k)[:, None, None] >= 4) & (rng.random((ny, nx)) < 0.4)[None], 3.0, 1.0)
+    s = s * np.sqrt(gain)[None, None]
+    cov = lambda i, j: (s[i] * np.conj(s[j])).mean(axis=0)                     # (k, ny, nx)
+    yxt = lambda a: np.ascontiguousarray(np.moveaxis(a, 0, -1))
+    host = xr_lite.Dataset()
+    for i, name in enumerate(('C11', 'C22', 'C33')):
+        host[name] = (('y', 'x', 'time'), yxt(cov(i, i).real.astype(np.float32)))
+    for (i, j), name in (((0, 1), 'C12'), ((0, 2), 'C13'), ((1, 2), 'C23')):
+        host[name] = (('y', 'x', 'time'), yxt(cov(i, j).astype(np.complex64)))
+    planes = [host['C11'].values, host['C22'].values, host['C33'].values]
+    for name in ('C12', 'C13', 'C23'):
+        planes += [np.ascontiguousarray(host[name].values.real), np.ascontiguousarray(host[name].values.imag)]
+    want = oracle.change_detection_pol(planes, 3, 0.9, looks, njobs=4).astype(bool)
+    assert want.any()
+    got = OmnibusTest(n=looks, alpha=0.9).apply(host)
+    assert isinstance(got.values, np.ndarray) and got.dims == ('y', 'x', 'time')
+    np.testing.assert_array_equal(got.values, want)
+    dev_ds = xr_lite.Dataset()
+    for name in host.data_vars:
+        dev_ds[name] = (('y', 'x', 'time'), torch.from_numpy(host[name].values).to(device))
+    got_dev = OmnibusTest(n=looks, alpha=0.9).apply(dev_ds)
+    np.testing.assert_array_equal(got_dev.values.cpu().numpy(), want)
