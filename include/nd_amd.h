@@ -53,6 +53,7 @@ extern "C" {
 #define ND_AMD_KERNEL_NLMEANS_TILED  6
 #define ND_AMD_KERNEL_CORRELATE1D    7
 #define ND_AMD_KERNEL_RELAYOUT       8
+#define ND_AMD_KERNEL_OMNIBUS_DENSE  9
 
 int nd_amd_abi_version(void);
 const char *nd_amd_last_error(void);

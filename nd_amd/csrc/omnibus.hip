@@ -1,7 +1,7 @@
 // nd_amd/csrc/omnibus.hip -- OmnibusTest (complex-Wishart change detector), dual-pol C2,
 // for gfx950.  Replaces nd._change.change_detection (nd/_change.pyx:263-287).
 //
-// Two kernels per call:
+// Two kernels per call (three at low thresholds, see omnibus_c2_dense_kernel):
 //
 //   omnibus_c2_global_kernel   ("pass A", HBM-bound)  one thread owns PPT adjacent pixels,
 //       streams the k x 4 planes once with 16-byte loads (coalesced along x, time outer),
@@ -143,6 +143,12 @@ struct OmniGlobalArgs {
     OmniTabEntry *tab_dev;
     T *dump;                  // [kShards][dump_cap][date][4] series of the first dump_cap pixels of a shard
     uint32_t dump_cap;
+    // Waves in which at least `dense_min` pixels are listed are not listed pixel by pixel: one
+    // entry (the pixel index of lane 0) goes to the dense list and omnibus_c2_dense_kernel searches
+    // all 64 pixels from registers.  Counter: word 1 of the shard's counter line.
+    uint32_t *dense_idx;      // [kShards][segd]
+    uint32_t segd;
+    int dense_min;            // 65 = never
 };
 
 constexpr int kGlobalThreads = 256;
@@ -399,24 +405,33 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     if (__any(flag)) {
         const unsigned long long m = __ballot(flag);
         const unsigned shard = (unsigned)(b % kShards);
-        unsigned base = 0;
-        if (lane == 0)
-            base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
-        base = __shfl(base, 0);
-        if (flag) {
-            const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
-            if (slot < g.dump_cap) {
-                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+        if (__popcll(m) >= g.dense_min) {
+            // dense wave: one entry for all 64 pixels, no dump (the dense kernel reloads them,
+            // coalesced, and decides every pixel itself)
+            if (lane == 0) {
+                const unsigned slot = atomicAdd(g.flag_count + shard * kCounterStride + 1, 1u);
+                g.dense_idx[(size_t)shard * g.segd + slot] = (uint32_t)(row * g.nx + bpx0 + (tid & ~63));
+            }
+        } else {
+            unsigned base = 0;
+            if (lane == 0)
+                base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
+            base = __shfl(base, 0);
+            if (flag) {
+                const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
+                if (slot < g.dump_cap) {
+                    T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
 #pragma unroll
-                for (int t = 0; t < KMAX; ++t) {
-                    if (EXACT || t < k) {
-                        Pack<T, 4> q;
-                        q.v[0] = v[t][0];
-                        q.v[1] = v[t][1];
-                        q.v[2] = v[t][2];
-                        q.v[3] = v[t][3];
-                        *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                    for (int t = 0; t < KMAX; ++t) {
+                        if (EXACT || t < k) {
+                            Pack<T, 4> q;
+                            q.v[0] = v[t][0];
+                            q.v[1] = v[t][1];
+                            q.v[2] = v[t][2];
+                            q.v[3] = v[t][3];
+                            *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                        }
                     }
                 }
             }
@@ -439,6 +454,160 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
         for (int i = tid; i < nvec; i += kRetainThreads) store_zero16_nt(vz + i);
         const int tail0 = head + (nvec << 4);
         if (tail0 + tid < nb) ob[tail0 + tid] = 0;
+    }
+}
+
+// =========================================================================================
+// dense waves: the change-point search from registers
+// =========================================================================================
+// Where a large share of the pixels is listed (low thresholds: the reference's default alpha = 0.01
+// lists 99 % of them) pass B's one-lane-per-candidate LDS image is the wrong shape: it pays for a
+// compaction nobody needs and runs at 1.5 waves per SIMD.  A dense wave is searched in place
+// instead: one thread per pixel reloads its series (coalesced, all loads in flight, like pass A)
+// and runs nd/_change.pyx:235-257 on registers.  Register arrays can only be indexed statically, so
+// every segment is a pass over all k dates with the dates before the segment start predicated off
+// -- the same additions in the same order as the sweep of pass B, hence the same decisions.
+// Only the f32-log screen lives here.  A lane whose statistic falls inside the screen's band
+// (~1e-5 of the tests) stops and appends its pixel to pass B's list, which then redoes that pixel
+// from its first date with the exact evaluation (rewriting the same change bytes): the exact code
+// would otherwise be instantiated 24 times and cost every wave 80 registers.
+template <typename T>
+struct OmniDenseArgs {
+    const T *c11, *c12r, *c12i, *c22;
+    int64_t nx, npix;         // pixels per row of the raster, pixels in all
+    int64_t sy, sx, st;
+    int k, flat;              // flat: rows are contiguous, a wave may run across a row end
+    double nlooks, alpha;
+    uint8_t *change;
+    uint32_t *flag_count;     // word 0: pixel list (appended to here), word 1: dense list
+    const uint32_t *dense_idx;
+    uint32_t segd;
+    const OmniTabEntry *tab;
+    // a pixel whose test falls inside the screen's band is handed to pass B through the ordinary
+    // pixel list (with its series in the dump, as pass A would have written it)
+    uint32_t *flag_idx;
+    uint32_t seg;
+    T *dump;
+    uint32_t dump_cap;
+};
+
+template <typename T, int KMAX>
+__global__ void __launch_bounds__(64) omnibus_c2_dense_kernel(const OmniDenseArgs<T> s)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_d[];
+    double *scr = reinterpret_cast<double *>(nd_smem_d);      // screen constants, as in pass B
+    const int lane = threadIdx.x;
+    const int k = s.k, kp = k + 1;
+    for (int j = lane; j <= k; j += 64) {
+        const OmniTabEntry e = s.tab[j];
+        scr[j] = e.m2rho;
+        scr[kp + j] = e.pklogk;
+        scr[2 * kp + j] = e.zlo_a;
+        scr[3 * kp + j] = e.zhi_a;
+    }
+    __syncthreads();
+    const unsigned shard = blockIdx.x % kShards;
+    const unsigned lblock = blockIdx.x / kShards, nlblock = gridDim.x / kShards;
+    const uint32_t n = s.flag_count[shard * kCounterStride + 1];
+    const uint32_t *list = s.dense_idx + (size_t)shard * s.segd;
+
+    for (uint32_t w = lblock; w < n; w += nlblock) {
+        const int64_t pix0 = (int64_t)list[w];
+        const int64_t pix = pix0 + lane;
+        const int64_t row0 = pix0 / s.nx;
+        int64_t row = pix / s.nx, col = pix - row * s.nx;
+        // a wave of pass A never leaves its row unless the rows are contiguous
+        bool active = s.flat ? (pix < s.npix) : (row == row0);
+        if (!active) {
+            row = row0;
+            col = s.nx - 1;
+        }
+        const int64_t off = row * s.sy + col * s.sx;
+        T v[KMAX][4];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+            if (t < k) {
+                const int64_t o = off + (int64_t)t * s.st;
+                v[t][0] = s.c11[o];
+                v[t][1] = s.c12r[o];
+                v[t][2] = s.c12i[o];
+                v[t][3] = s.c22[o];
+            }
+        uint8_t *res = s.change + pix * (int64_t)k;
+        int l = 0;
+        bool done = !active, handoff = false;
+        while (__any(!done)) {
+            Accum<T> A;
+            A.reset();
+            int fire_at = -1;
+            bool gfire = false;
+            // no lane of the wave needs the dates before the earliest segment start
+            int lmin = done ? 0x7fffffff : l;
+#pragma unroll
+            for (int m_ = 32; m_ >= 1; m_ >>= 1) {
+                const int other = __shfl_xor(lmin, m_);
+                lmin = other < lmin ? other : lmin;
+            }
+            lmin = __builtin_amdgcn_readfirstlane(lmin);
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                if (t < k && t >= lmin) {
+                    const bool on = !done && t >= l;
+                    if (on) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+                    const int jj = t - l + 1;
+                    const bool last = (t == k - 1);
+                    // a marginal test while none has fired yet (j >= 2); at the last date the
+                    // same evaluation is the global test, needed even if a marginal fired earlier
+                    const bool need = on && jj >= 2 && (fire_at < 0 || last);
+                    if (__any(need)) {
+                        bool fires = false, inband = false;
+                        if (need) {
+                            const double za = z_approx<T>(A, jj, s.nlooks, scr[jj], scr[kp + jj]);
+                            fires = (za > scr[3 * kp + jj]) && (za < INFINITY);
+                            inband = (za >= scr[2 * kp + jj]) && !fires;
+                        }
+                        if (inband) {
+                            handoff = true;            // pass B decides this pixel
+                            done = true;
+                        }
+                        if (fires && fire_at < 0) fire_at = t;
+                        if (last) gfire = fires;
+                    }
+                }
+            }
+            if (!done) {
+                if (gfire) {                           // implies k - l >= 2
+                    res[fire_at] = 1;                  // :252, l + r with r = j - 1
+                    l = fire_at;                       // :255
+                    if (l >= k - 1) done = true;       // :256
+                } else {
+                    done = true;                       // :241-242
+                }
+            }
+        }
+        if (__any(handoff)) {
+            const unsigned long long m = __ballot(handoff);
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(s.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
+            base = __shfl(base, 0);
+            if (handoff) {
+                const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                s.flag_idx[(size_t)shard * s.seg + slot] = (uint32_t)pix;
+                if (slot < s.dump_cap) {
+                    T *d = s.dump + ((int64_t)shard * s.dump_cap + slot) * (int64_t)(4 * k);
+#pragma unroll
+                    for (int t = 0; t < KMAX; ++t)
+                        if (t < k) {
+                            Pack<T, 4> q;
+                            q.v[0] = v[t][0];
+                            q.v[1] = v[t][1];
+                            q.v[2] = v[t][2];
+                            q.v[3] = v[t][3];
+                            *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                        }
+                }
+            }
+        }
     }
 }
 
@@ -696,12 +865,13 @@ std::vector<OmniTabEntry> get_table_impl(int k, uint32_t n_looks, double alpha, 
     return tab;
 }
 
-// workspace: [counter][per-j table][pixel list: npix x u32][dump: cap x k x 4 x T]
+// workspace: [counters][per-j table][pixel list: npix x u32][dense-wave list][dump: cap x k x 4 x T]
 // `min_total` is what the call needs; everything beyond it is used as dump capacity.  The
 // recommended size holds the series of 1/8 of the pixels (a listed pixel beyond the capacity is
 // gathered from the planes by pass B instead: slower, never wrong).
 struct OmniWorkspace {
-    size_t off_count, off_tab, off_idx, off_dump, min_total, recommended;
+    size_t off_count, off_tab, off_idx, off_dense, off_dump, min_total, recommended;
+    uint32_t segd;
 };
 
 constexpr int kRetainMaxF32 = 48, kRetainMaxF64 = 24;
@@ -725,7 +895,10 @@ static OmniWorkspace omni_layout(int64_t npix, int64_t ny, int64_t k, size_t ele
     w.off_count = 0;
     w.off_tab = align256(kCounterBytes);
     w.off_idx = w.off_tab + align256((size_t)(k + 1) * sizeof(OmniTabEntry));
-    w.off_dump = w.off_idx + align256((size_t)omni_seg(npix, ny) * kShards * sizeof(uint32_t));
+    w.off_dense = w.off_idx + align256((size_t)omni_seg(npix, ny) * kShards * sizeof(uint32_t));
+    // dense-wave list: at most one entry per 64 listed pixels of a shard
+    w.segd = omni_seg(npix, ny) / 64 + 8;
+    w.off_dump = w.off_dense + align256((size_t)w.segd * kShards * sizeof(uint32_t));
     w.min_total = w.off_dump;
     const size_t per = (size_t)k * 4 * elem;
     size_t cap = ((size_t)npix / 8 / kShards + 63) & ~(size_t)63;   // per shard
@@ -852,6 +1025,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     g.flag_count = flag_count;
     g.flag_idx = flag_idx;
     g.tab_dev = tab_dev;
+    g.dense_idx = reinterpret_cast<uint32_t *>(ws + w.off_dense);
+    g.segd = w.segd;
+    // the register search exists for the series lengths whose arrays fit the register file
+    static const int dense_env = [] {
+        const char *e = getenv("ND_AMD_DENSE_MIN");
+        return e ? atoi(e) : 16;
+    }();
+    const bool dense_ok = k <= (sizeof(T) == 4 ? 32 : 16);
+    g.dense_min = dense_ok ? dense_env : 65;
     const bool stats = (z_out != nullptr) || (p_out != nullptr);
     const bool retain = k <= (sizeof(T) == 4 ? kRetainMaxF32 : kRetainMaxF64);
     {
@@ -887,6 +1069,50 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             launch_global<T, VPPT>(g, tab, nblocks, stats, stream);
         else
             launch_global<T, 1>(g, tab, nblocks, stats, stream);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+
+    // ---- dense waves (none in the sparse regime: every block then leaves at once) ----
+    if (retain && g.dense_min <= 64) {
+        OmniDenseArgs<T> d;
+        d.c11 = g.c11;
+        d.c12r = g.c12r;
+        d.c12i = g.c12i;
+        d.c22 = g.c22;
+        d.nx = nx;
+        d.npix = npix;
+        d.sy = sy;
+        d.sx = sx;
+        d.st = st;
+        d.k = (int)k;
+        d.flat = flat ? 1 : 0;
+        d.nlooks = g.nlooks;
+        d.alpha = alpha;
+        d.change = change;
+        d.flag_count = flag_count;
+        d.dense_idx = g.dense_idx;
+        d.segd = g.segd;
+        d.tab = tab_dev;
+        d.flag_idx = flag_idx;
+        d.seg = g.seg;
+        d.dump = g.dump;
+        d.dump_cap = g.dump_cap;
+        int64_t per_shard_d = ceil_div(ceil_div(npix, (int64_t)kShards), 64);
+        if (per_shard_d > 256) per_shard_d = 256;
+        if (per_shard_d < 1) per_shard_d = 1;
+        const dim3 gridd((unsigned)(per_shard_d * kShards)), blockd(64);
+        const size_t ldsd = (size_t)(k + 1) * 4 * sizeof(double);
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_DENSE, stream);
+        if (k <= 8)
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 8>), gridd, blockd, ldsd, stream, d);
+        else if (k <= 16)
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 16>), gridd, blockd, ldsd, stream, d);
+        else if (sizeof(T) == 4 && k <= 24)
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 24>), gridd, blockd, ldsd, stream,
+                               reinterpret_cast<const OmniDenseArgs<float> &>(d));
+        else if (sizeof(T) == 4)
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 32>), gridd, blockd, ldsd, stream,
+                               reinterpret_cast<const OmniDenseArgs<float> &>(d));
     }
     ND_HIP_CHECK(hipGetLastError());
 
