@@ -14,15 +14,17 @@ def child():
     dev = torch.device('cuda:0')
     st = synth.wishart_c2_stack(24, 4096, 4096, seed=1234, device=dev, change_frac=0.01)
     for _ in range(3):
-        kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9)
+        kernels.change_detection(st[0], st[1], st[2], st[3], alpha=float(os.environ.get('EXP_ALPHA', '0.99')), n=9)
     _lib.timing_enable(64)
     for _ in range(10):
-        kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9)
+        kernels.change_detection(st[0], st[1], st[2], st[3], alpha=float(os.environ.get('EXP_ALPHA', '0.99')), n=9)
     torch.cuda.synchronize()
     kt = _lib.timing_collect()
     a = [ms for n, ms in kt if n == 'omnibus_c2_global']
     b = [ms for n, ms in kt if n == 'omnibus_c2_search']
-    print(json.dumps({'passA_ms': round(sum(a) / len(a), 4), 'passB_ms': round(sum(b) / len(b), 4)}))
+    d = [ms for n, ms in kt if n == 'omnibus_c2_dense'] or [0.0]
+    print(json.dumps({'passA_ms': round(sum(a) / len(a), 4), 'passB_ms': round(sum(b) / len(b), 4),
+                      'dense_ms': round(sum(d) / len(d), 4)}))
 
 def build_variant(name, patches, extra=()):
     d = os.path.join(OUT, 'src_' + name)
@@ -54,6 +56,9 @@ VARIANTS = {
                     "                        if (true) {\n                            done = true;                   // :256")],
     'b_nofirst': [("const bool need = (jj >= 2) && (fire_at < 0 || last);", "const bool need = (jj >= 2) && last;")],
     'b_notests': [("const bool need = (jj >= 2) && (fire_at < 0 || last);", "const bool need = false && (jj >= 2) && (fire_at < 0 || last);")],
+    # dense kernel: occupancy hints
+    'd_w3': [("__launch_bounds__(64) omnibus_c2_dense_kernel", "__launch_bounds__(64, 3) omnibus_c2_dense_kernel")],
+    'd_w4': [("__launch_bounds__(64) omnibus_c2_dense_kernel", "__launch_bounds__(64, 4) omnibus_c2_dense_kernel")],
     # pass A block size
     't128': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 128")],
 }
