@@ -498,6 +498,11 @@ __global__ void __launch_bounds__(64) omnibus_c2_dense_kernel(const OmniDenseArg
     double *scr = reinterpret_cast<double *>(nd_smem_d);      // screen constants, as in pass B
     const int lane = threadIdx.x;
     const int k = s.k, kp = k + 1;
+    const unsigned shard = blockIdx.x % kShards;
+    const unsigned lblock = blockIdx.x / kShards, nlblock = gridDim.x / kShards;
+    const uint32_t n = s.flag_count[shard * kCounterStride + 1];
+    if (lblock >= n) return;                  // the usual case in the sparse regime: nothing listed
+    const uint32_t *list = s.dense_idx + (size_t)shard * s.segd;
     for (int j = lane; j <= k; j += 64) {
         const OmniTabEntry e = s.tab[j];
         scr[j] = e.m2rho;
@@ -506,10 +511,6 @@ __global__ void __launch_bounds__(64) omnibus_c2_dense_kernel(const OmniDenseArg
         scr[3 * kp + j] = e.zhi_a;
     }
     __syncthreads();
-    const unsigned shard = blockIdx.x % kShards;
-    const unsigned lblock = blockIdx.x / kShards, nlblock = gridDim.x / kShards;
-    const uint32_t n = s.flag_count[shard * kCounterStride + 1];
-    const uint32_t *list = s.dense_idx + (size_t)shard * s.segd;
 
     for (uint32_t w = lblock; w < n; w += nlblock) {
         const int64_t pix0 = (int64_t)list[w];
@@ -1098,7 +1099,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         d.dump = g.dump;
         d.dump_cap = g.dump_cap;
         int64_t per_shard_d = ceil_div(ceil_div(npix, (int64_t)kShards), 64);
-        if (per_shard_d > 256) per_shard_d = 256;
+        if (per_shard_d > 128) per_shard_d = 128;
         if (per_shard_d < 1) per_shard_d = 1;
         const dim3 gridd((unsigned)(per_shard_d * kShards)), blockd(64);
         const size_t ldsd = (size_t)(k + 1) * 4 * sizeof(double);
