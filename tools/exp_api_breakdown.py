@@ -1,3 +1,4 @@
+"""Tuning experiment (GPU box): where OmnibusTest.apply spends its time on a device-resident dataset."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch

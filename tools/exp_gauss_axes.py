@@ -1,3 +1,4 @@
+"""Tuning experiment (GPU box): time of one Gaussian pass per axis (correlate1d kernels)."""
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nd_amd import kernels, _lib

@@ -1,3 +1,5 @@
+"""Tuning experiment (GPU box): three Gaussian passes along one axis of a 24 x 4096 x 4096 stack, for
+rocprofv3 counter runs:  python tools/exp_gauss_one.py <axis> <sigma>."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nd_amd import kernels

@@ -1,3 +1,5 @@
+"""Tuning experiment (GPU box): host <-> device copy rates (pageable, pinned, staged) and the cost of
+a host-side transpose -- the numbers behind the host-dataset path of nd_amd/change.py and filters.py."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""Tuning experiment (GPU box): the (y, x, time) -> planar transpose kernel against torch's permuted copy."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
