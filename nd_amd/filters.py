@@ -321,6 +321,17 @@ class GaussianFilter(Filter):
             out_t = output if _device.is_tensor(output) else torch.empty_like(t)
             if out_t.data_ptr() == t.data_ptr():
                 t = t.clone()
+            # a variable in the reference's (y, x, time) layout smoothed along y and x: transpose
+            # to planar on the device, filter there (x contiguous: the tiled passes), transpose back
+            if t.dim() == 3 and per_axis[2] == 0 and t.numel() >= (1 << 16):
+                planar = torch.empty((t.shape[2], t.shape[0], t.shape[1]), dtype=t.dtype, device=dev)
+                if kernels.relayout_planar(t, planar):
+                    smooth = kernels.gaussian_filter(planar, [0, per_axis[0], per_axis[1]], **self.kwargs)
+                    if not kernels.relayout_pixel_major(smooth, out_t):
+                        out_t.copy_(smooth.permute(1, 2, 0))
+                    if out_t is not output:
+                        _device.write_back(out_t, output)
+                    return
             kernels.gaussian_filter(t, per_axis, out=out_t, **self.kwargs)
             if out_t is not output:
                 _device.write_back(out_t, output)

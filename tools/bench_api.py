@@ -29,10 +29,13 @@ if a.what == 'omnibus':
 elif a.what == 'boxcar':
     from nd_amd.filters import BoxcarFilter
     algo = BoxcarFilter(w=a.ml or 3)
+elif a.what == 'gaussian':
+    from nd_amd.filters import GaussianFilter
+    algo = GaussianFilter(sigma=1.0)
 else:
     from nd_amd.filters import NLMeansFilter
     algo = NLMeansFilter(dims=('time', 'y', 'x'), r=(1, 3, 3), f=1, sigma=0.5, h=0.5, n_eff=50)
-out = algo.apply(ds); torch.cuda.synchronize()
+out = algo.apply(ds); out = algo.apply(ds); out = algo.apply(ds); torch.cuda.synchronize()      # allocator warm
 t0 = time.perf_counter()
 for _ in range(a.steps): out = algo.apply(ds)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
