@@ -214,6 +214,13 @@ int nd_amd_relayout_planar(const void *in, void *out, int dtype,
                            int64_t npix, int64_t k, int64_t in_date_stride,
                            int64_t out_date_stride, void *hip_stream);
 
+/* Both halves of an interleaved complex (y, x, time) array in one pass (the C12 term):
+ *     out_re[t * s + p] = in[(p * k + t) * 2],  out_im[t * s + p] = in[(p * k + t) * 2 + 1]
+ * dtype is that of the real components. */
+int nd_amd_relayout_planar_complex(const void *in, void *out_re, void *out_im,
+                                   int dtype, int64_t npix, int64_t k,
+                                   int64_t out_date_stride, void *hip_stream);
+
 /* The way back (filter outputs handed to a caller that keeps the reference's
  * layout, nd/filters.py:139-176):
  *     out[p * k * out_date_stride + t * out_date_stride] = in[t * in_date_stride + p]

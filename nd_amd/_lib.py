@@ -24,7 +24,8 @@ SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_omnibus_c2_workspace_bytes', 'nd_amd_omnibus_c2',
            'nd_amd_omnibus_c3_workspace_bytes', 'nd_amd_omnibus_c3',
            'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_nlmeans3d',
-           'nd_amd_relayout_planar', 'nd_amd_relayout_pixel_major',
+           'nd_amd_relayout_planar', 'nd_amd_relayout_planar_complex',
+           'nd_amd_relayout_pixel_major',
            'nd_amd_timing_enable', 'nd_amd_timing_collect')
 
 _lib = None
@@ -77,6 +78,8 @@ def lib():
                                    C.POINTER(i64), vp]
     L.nd_amd_relayout_planar.restype = i32
     L.nd_amd_relayout_planar.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp]
+    L.nd_amd_relayout_planar_complex.restype = i32
+    L.nd_amd_relayout_planar_complex.argtypes = [vp, vp, vp, i32, i64, i64, i64, vp]
     L.nd_amd_relayout_pixel_major.restype = i32
     L.nd_amd_relayout_pixel_major.argtypes = [vp, vp, i32, i64, i64, i64, i64, vp]
     L.nd_amd_timing_enable.restype = i32

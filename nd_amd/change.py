@@ -54,7 +54,18 @@ def _covariance_planes(ds_m, device, names=_VARS):
     tdtype = torch.float32 if dtype == np.float32 else torch.float64
     k, ny, nx = arrs[0][0].shape
     stack = synth.empty_stack(len(names), k, ny, nx, device, tdtype)
+    placed = set()
+    for i, v in enumerate(names):
+        # the two halves of an interleaved complex term: one pass over its memory
+        if v.endswith('__re') and v[:-4] + '__im' in names:
+            j = names.index(v[:-4] + '__im')
+            re, im = arrs[i][1], arrs[j][1]
+            if (_device.is_tensor(re) and re.dtype == tdtype
+                    and kernels.relayout_planar_complex(re, im, stack[i], stack[j])):
+                placed.update((i, j))
     for i, (tyx, yxt) in enumerate(arrs):
+        if i in placed:
+            continue
         # device data in the reference's (y, x, time) layout goes through the transpose kernel
         if not (_device.is_tensor(yxt) and yxt.dtype == tdtype and kernels.relayout_planar(yxt, stack[i])):
             stack[i].copy_(_device.to_device(tyx, device))

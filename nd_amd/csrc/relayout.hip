@@ -17,6 +17,7 @@ template <typename T>
 struct RelayoutArgs {
     const T *in;
     T *out;
+    T *out2;                    // second half of an interleaved source (planar direction only), or null
     int64_t npix, out_date_stride;
     int k, ids;                 // dates, element distance between dates in the source (1 or 2)
     int span_per_pixel;         // k * ids: source elements per pixel
@@ -33,7 +34,8 @@ __global__ void __launch_bounds__(256) relayout_planar_kernel(const RelayoutArgs
     const int64_t p0 = (int64_t)blockIdx.x * a.pb;
     const int64_t left = a.npix - p0;
     const int np = left < a.pb ? (int)left : a.pb;
-    const int spp = a.span_per_pixel, pitch = a.k | 1;
+    const bool both = a.out2 != nullptr;                  // keep both halves of an interleaved source
+    const int spp = a.span_per_pixel, pitch = both ? (spp | 1) : (a.k | 1);
     const int total = np * spp;
     const T *src = a.in + p0 * spp;
     for (int e0 = 0; e0 < total; e0 += 256 * 8) {
@@ -46,9 +48,9 @@ __global__ void __launch_bounds__(256) relayout_planar_kernel(const RelayoutArgs
             if (e < total) {
                 const int q = (int)__umulhi((unsigned)e, a.magic);      // pixel within the block
                 const int r = e - q * spp;                              // element within the pixel
-                // interleaved source: only this half's elements are touched (the other half's
-                // last element may lie beyond the end of the allocation)
-                if (a.ids == 1) {
+                // interleaved source, one half wanted: only that half's elements are touched (the
+                // other half's last element may lie beyond the end of the allocation)
+                if (a.ids == 1 || both) {
                     dsti[u] = q * pitch + r;
                 } else if ((r & 1) == 0) {
                     dsti[u] = q * pitch + (r >> 1);
@@ -64,8 +66,16 @@ __global__ void __launch_bounds__(256) relayout_planar_kernel(const RelayoutArgs
     const int p = tid & (a.pb - 1), tg = tid / a.pb, ntg = 256 / a.pb;
     if (p < np) {
         T *dst = a.out + p0 + p;
-        for (int t = tg; t < a.k; t += ntg)
-            __builtin_nontemporal_store(lds[p * pitch + t], dst + (int64_t)t * a.out_date_stride);
+        if (!both) {
+            for (int t = tg; t < a.k; t += ntg)
+                __builtin_nontemporal_store(lds[p * pitch + t], dst + (int64_t)t * a.out_date_stride);
+        } else {
+            T *dst2 = a.out2 + p0 + p;
+            for (int t = tg; t < a.k; t += ntg) {
+                __builtin_nontemporal_store(lds[p * pitch + 2 * t], dst + (int64_t)t * a.out_date_stride);
+                __builtin_nontemporal_store(lds[p * pitch + 2 * t + 1], dst2 + (int64_t)t * a.out_date_stride);
+            }
+        }
     }
 }
 
@@ -113,12 +123,13 @@ __global__ void __launch_bounds__(256) relayout_pixel_major_kernel(const Relayou
 }
 
 template <typename T>
-static int relayout_impl(const void *in, void *out, int64_t npix, int64_t k, int64_t ids,
+static int relayout_impl(const void *in, void *out, void *out2, int64_t npix, int64_t k, int64_t ids,
                          int64_t out_date_stride, bool to_planar, hipStream_t stream)
 {
     RelayoutArgs<T> a;
     a.in = static_cast<const T *>(in);
     a.out = static_cast<T *>(out);
+    a.out2 = static_cast<T *>(out2);
     a.npix = npix;
     a.out_date_stride = out_date_stride;
     a.k = (int)k;
@@ -126,9 +137,10 @@ static int relayout_impl(const void *in, void *out, int64_t npix, int64_t k, int
     a.span_per_pixel = (int)(k * ids);
     a.magic = (unsigned)((0x100000000ULL + (unsigned)a.span_per_pixel - 1) / (unsigned)a.span_per_pixel);
     // LDS image pb x (k | 1) elements, at most 48 KiB
+    const size_t row_elems = out2 ? (size_t)((k * ids) | 1) : (size_t)(k | 1);
     int pb = 256;
-    while (pb > 1 && (size_t)pb * (size_t)(k | 1) * sizeof(T) > 48 * 1024) pb >>= 1;
-    if ((size_t)pb * (size_t)(k | 1) * sizeof(T) > 48 * 1024) {
+    while (pb > 1 && (size_t)pb * row_elems * sizeof(T) > 48 * 1024) pb >>= 1;
+    if ((size_t)pb * row_elems * sizeof(T) > 48 * 1024) {
         set_error("nd_amd_relayout_planar: %lld dates do not fit the staging buffer", (long long)k);
         return ND_AMD_EUNSUPPORTED;
     }
@@ -143,7 +155,7 @@ static int relayout_impl(const void *in, void *out, int64_t npix, int64_t k, int
         set_error("nd_amd_relayout_planar: raster too large for one launch");
         return ND_AMD_EUNSUPPORTED;
     }
-    const size_t lds = (size_t)pb * (size_t)(k | 1) * sizeof(T);
+    const size_t lds = (size_t)pb * row_elems * sizeof(T);
     {
         KernelTimer timer(ND_AMD_KERNEL_RELAYOUT, stream);
         if (to_planar)
@@ -179,8 +191,8 @@ extern "C" int nd_amd_relayout_planar(const void *in, void *out, int dtype, int6
     }
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (dtype == ND_AMD_F32)
-        return relayout_impl<float>(in, out, npix, k, in_date_stride, out_date_stride, true, stream);
-    return relayout_impl<double>(in, out, npix, k, in_date_stride, out_date_stride, true, stream);
+        return relayout_impl<float>(in, out, nullptr, npix, k, in_date_stride, out_date_stride, true, stream);
+    return relayout_impl<double>(in, out, nullptr, npix, k, in_date_stride, out_date_stride, true, stream);
 }
 
 extern "C" int nd_amd_relayout_pixel_major(const void *in, void *out, int dtype, int64_t npix,
@@ -204,6 +216,29 @@ extern "C" int nd_amd_relayout_pixel_major(const void *in, void *out, int dtype,
     // `out_date_stride` the plane pitch on the planar side, whichever direction the copy runs
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (dtype == ND_AMD_F32)
-        return relayout_impl<float>(in, out, npix, k, out_date_stride, in_date_stride, false, stream);
-    return relayout_impl<double>(in, out, npix, k, out_date_stride, in_date_stride, false, stream);
+        return relayout_impl<float>(in, out, nullptr, npix, k, out_date_stride, in_date_stride, false, stream);
+    return relayout_impl<double>(in, out, nullptr, npix, k, out_date_stride, in_date_stride, false, stream);
+}
+
+extern "C" int nd_amd_relayout_planar_complex(const void *in, void *out_re, void *out_im, int dtype,
+                                              int64_t npix, int64_t k, int64_t out_date_stride,
+                                              void *hip_stream)
+{
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_relayout_planar_complex: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (npix < 0 || k < 0 || out_date_stride < npix) {
+        set_error("nd_amd_relayout_planar_complex: bad shape or strides");
+        return ND_AMD_EINVAL;
+    }
+    if (npix == 0 || k == 0) return ND_AMD_OK;
+    if (!in || !out_re || !out_im) {
+        set_error("nd_amd_relayout_planar_complex: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (dtype == ND_AMD_F32)
+        return relayout_impl<float>(in, out_re, out_im, npix, k, 2, out_date_stride, true, stream);
+    return relayout_impl<double>(in, out_re, out_im, npix, k, 2, out_date_stride, true, stream);
 }

@@ -160,6 +160,32 @@ def relayout_planar(src, dst):
     return True
 
 
+def relayout_planar_complex(src_re, src_im, dst_re, dst_im):
+    """relayout_planar for both halves of one interleaved complex (y, x, time) tensor at once
+    (`src_re`, `src_im` = its `.real` / `.imag` views): the source is read once.  False when the two
+    views are not the halves of one such tensor."""
+    if not (torch.is_tensor(src_re) and torch.is_tensor(src_im) and src_re.is_cuda and src_re.dim() == 3):
+        return False
+    ny, nx, k = src_re.shape
+    es = src_re.element_size()
+    if (src_im.shape != src_re.shape or src_im.stride() != src_re.stride() or src_re.dtype not in _DT
+            or src_im.dtype != src_re.dtype or src_im.data_ptr() != src_re.data_ptr() + es
+            or src_re.stride() != (nx * k * 2, k * 2, 2)):
+        return False
+    for d in (dst_re, dst_im):
+        if (tuple(d.shape) != (k, ny, nx) or d.dtype != src_re.dtype or d.stride(2) != 1
+                or d.stride(1) != nx or d.stride(0) < ny * nx or d.stride(0) != dst_re.stride(0)):
+            return False
+    if ny * nx * k == 0:
+        return True
+    dev = src_re.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nd_amd_relayout_planar_complex(
+            _ptr(src_re), _ptr(dst_re), _ptr(dst_im), _DT[src_re.dtype], ny * nx, k, dst_re.stride(0),
+            _stream_ptr(dev)))
+    return True
+
+
 def relayout_pixel_major(src, dst):
     """Inverse of relayout_planar: planar (time, y, x) `src` (x fastest, any plane pitch) into
     `dst` laid out (y, x, time) with time fastest (a real tensor or one half of a complex one).

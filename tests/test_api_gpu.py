@@ -498,3 +498,23 @@ def test_host_dataset_is_staged_once_and_left_untouched(oracle, device):
     np.testing.assert_array_equal(out['scalar_per_date'].values, np.arange(4.0))
     box = BoxcarFilter(w=3).apply(ds)
     assert np.iscomplexobj(box['C'].values) and box['A'].attrs.get('unit') == 'dB'
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_relayout_planar_complex_both_halves(device, dtype):
+    import torch
+    from nd_amd import kernels, synth as dsynth
+    rng = np.random.default_rng(63)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    for ny, nx, k in [(1, 1, 1), (7, 9, 3), (40, 70, 24), (3, 200, 130)]:
+        c = torch.complex(torch.from_numpy(rng.normal(size=(ny, nx, k)).astype(dtype)),
+                          torch.from_numpy(rng.normal(size=(ny, nx, k)).astype(dtype))).to(device)
+        st = dsynth.empty_stack(2, k, ny, nx, device, tdt)
+        assert kernels.relayout_planar_complex(c.real, c.imag, st[0], st[1])
+        assert torch.equal(st[0], c.real.permute(2, 0, 1)) and torch.equal(st[1], c.imag.permute(2, 0, 1))
+    # two unrelated real tensors are not the halves of one complex tensor
+    a = torch.zeros((4, 5, 6), dtype=tdt, device=device)
+    b = torch.zeros((4, 5, 6), dtype=tdt, device=device)
+    o = torch.ones((2, 6, 4, 5), dtype=tdt, device=device)
+    assert not kernels.relayout_planar_complex(a, b, o[0], o[1])
+    assert bool((o == 1).all())
