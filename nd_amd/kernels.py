@@ -136,6 +136,9 @@ def change_detection_c3(planes, alpha, n=1, dims=('time', 'y', 'x'), stats=False
 # ---------------------------------------------------------------------------
 # layout change in front of the hot path
 # ---------------------------------------------------------------------------
+_RELAYOUT_LDS = 48 * 1024      # bytes of LDS one pixel's series may take in the transpose kernels
+
+
 def relayout_planar(src, dst):
     """Copy a device variable laid out (y, x, time) with time fastest -- the reference's own
     layout -- into the planar (time, y, x) view `dst` (x fastest, any plane pitch).  `src` may be
@@ -150,6 +153,8 @@ def relayout_planar(src, dst):
         return True
     ids = src.stride(2)
     if ids not in (1, 2) or src.stride(1) != k * ids or src.stride(0) != nx * k * ids:
+        return False
+    if (k | 1) * src.element_size() > _RELAYOUT_LDS:        # series too long for the staging buffer
         return False
     if dst.stride(2) != 1 or dst.stride(1) != nx or dst.stride(0) < ny * nx:
         return False
@@ -171,6 +176,8 @@ def relayout_planar_complex(src_re, src_im, dst_re, dst_im):
     if (src_im.shape != src_re.shape or src_im.stride() != src_re.stride() or src_re.dtype not in _DT
             or src_im.dtype != src_re.dtype or src_im.data_ptr() != src_re.data_ptr() + es
             or src_re.stride() != (nx * k * 2, k * 2, 2)):
+        return False
+    if ((2 * k) | 1) * es > _RELAYOUT_LDS:
         return False
     for d in (dst_re, dst_im):
         if (tuple(d.shape) != (k, ny, nx) or d.dtype != src_re.dtype or d.stride(2) != 1
@@ -199,6 +206,8 @@ def relayout_pixel_major(src, dst):
         return True
     ods = dst.stride(2)
     if ods not in (1, 2) or dst.stride(1) != k * ods or dst.stride(0) != nx * k * ods:
+        return False
+    if (k | 1) * src.element_size() > _RELAYOUT_LDS:
         return False
     if src.stride(2) != 1 or src.stride(1) != nx or src.stride(0) < ny * nx:
         return False

@@ -518,3 +518,18 @@ def test_relayout_planar_complex_both_halves(device, dtype):
     o = torch.ones((2, 6, 4, 5), dtype=tdt, device=device)
     assert not kernels.relayout_planar_complex(a, b, o[0], o[1])
     assert bool((o == 1).all())
+
+
+def test_relayout_declines_series_beyond_the_staging_buffer(device):
+    """A series too long for the transpose kernels' LDS image is declined (torch copies then)."""
+    import torch
+    from nd_amd import kernels
+    k = 13000
+    src = torch.zeros((1, 2, k), device=device)
+    dst = torch.ones((k, 1, 2), device=device)
+    assert not kernels.relayout_planar(src, dst)
+    assert not kernels.relayout_pixel_major(dst, src)
+    c = torch.zeros((1, 2, 7000), dtype=torch.complex64, device=device)
+    o = torch.ones((2, 7000, 1, 2), device=device)
+    assert not kernels.relayout_planar_complex(c.real, c.imag, o[0], o[1])
+    assert bool((dst == 1).all()) and bool((o == 1).all())
