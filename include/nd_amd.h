@@ -200,6 +200,25 @@ int nd_amd_nlmeans3d(const void *arr, void *out, int dtype,
                      void *hip_stream);
 
 /* ------------------------------------------------------------------------
+ * nd_amd_omnibus_c2 for data in the reference's own layout, without a
+ * transpose: variable v holds element (y, x, t) at
+ *     ptr_v[((y * nx + x) * k + t) * date_stride[v]]
+ * (order C11, C12re, C12im, C22).  date_stride = 1 for a real (y, x, time)
+ * array; 2, with c12im == c12re + 1, for the two halves of an interleaved
+ * complex C12 (read once).  k <= 24 (float32; float64: k <= 12); larger
+ * series return ND_AMD_EUNSUPPORTED -- transpose with
+ * nd_amd_relayout_planar and call nd_amd_omnibus_c2.  Workspace as for
+ * nd_amd_omnibus_c2.
+ * ---------------------------------------------------------------------- */
+int nd_amd_omnibus_c2_pixel_major(const void *c11, const void *c12re, const void *c12im,
+                                  const void *c22, int dtype,
+                                  int64_t ny, int64_t nx, int64_t k,
+                                  const int64_t date_stride[4],
+                                  uint32_t n_looks, double alpha, uint8_t *change,
+                                  void *z_out, void *p_out,
+                                  void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/* ------------------------------------------------------------------------
  * Layout change in front of the hot path.  The reference hands its native
  * code a (y, x, time, variable) view with time (and variable) fastest
  * (nd/change.py:66-67: to_array().transpose('y','x','time','variable'));

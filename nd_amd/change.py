@@ -105,15 +105,25 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
     dev = _device.device_of(*[ds[v].values for v in present], device=device)
     with torch.cuda.device(dev):
         ds_m = disassemble_complex(_on_device(ds, dev) if host else ds)
-        stack = _covariance_planes(ds_m, dev, _VARS3 if full_pol else _VARS)
-        if ml is not None:      # spatial multilooking first; the looks multiply accordingly
-            stack, n = _multilook_planes(stack, int(ml)), ml * ml
-        if full_pol:
-            res = kernels.change_detection_c3(list(stack), alpha=alpha, n=int(n),
-                                              dims=('time', 'y', 'x'), stats=stats)
-        else:
-            res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
-                                           n=int(n), dims=('time', 'y', 'x'), stats=stats)
+        res = None
+        if not full_pol and ml is None and all(v in ds_m.data_vars for v in _VARS):
+            # the reference's own layout on the device (numpy inputs were uploaded as they are):
+            # the pixel-major kernel reads it directly, no transpose at all
+            vals = [ds_m[v] for v in _VARS]
+            if all(set(da.dims) == {'y', 'x', 'time'} and len(da.dims) == 3 for da in vals):
+                res = kernels.change_detection_pixel_major(
+                    *[da.transpose('y', 'x', 'time').values for da in vals], alpha=alpha, n=int(n),
+                    stats=stats)
+        if res is None:
+            stack = _covariance_planes(ds_m, dev, _VARS3 if full_pol else _VARS)
+            if ml is not None:      # spatial multilooking first; the looks multiply accordingly
+                stack, n = _multilook_planes(stack, int(ml)), ml * ml
+            if full_pol:
+                res = kernels.change_detection_c3(list(stack), alpha=alpha, n=int(n),
+                                                  dims=('time', 'y', 'x'), stats=stats)
+            else:
+                res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
+                                               n=int(n), dims=('time', 'y', 'x'), stats=stats)
     change = res[0] if stats else res
     change = change.view(torch.bool)            # 0 / 1 bytes: reinterpreted, not copied
     dims = ['y', 'x', 'time']

@@ -457,6 +457,187 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// pass A for data in the reference's own layout: every variable is [pixel][date] with the dates
+// of a pixel adjacent (nd/change.py:66-67 hands (y, x, time, variable) views of such arrays to the
+// native code), C12 possibly interleaved complex.  A block's 256 pixels are one contiguous span
+// per variable: the spans are read with fully coalesced loads into an LDS image (pixel-major,
+// odd pitch), each thread then picks its own pixel's series out of it, and the kernel continues
+// exactly like the register-retaining form above (same fold, screen, list, dump, zero-fill).
+// Two variables are staged per round: C11 with C22, then the two halves of C12.
+// -----------------------------------------------------------------------------------------
+template <typename T>
+struct OmniPmArgs {
+    int ids[4];               // element distance between consecutive dates, per variable (1 or 2)
+    unsigned magic[4];        // ceil(2^32 / (k * ids)): span element -> pixel without a division
+    int c12_joint;            // C12 re / im are the halves of one interleaved array: one read
+};
+
+template <typename T, int KMAX, bool STATS>
+__global__ void __launch_bounds__(kRetainThreads)
+omnibus_c2_retain_pm_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const OmniPmArgs<T> pm)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_pm[];
+    T *img = reinterpret_cast<T *>(nd_smem_pm);            // two images of kRetainThreads x (k | 1)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = 0;                                 // the raster is flat in this layout
+    const int64_t bpx0 = b * (int64_t)kRetainThreads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+    const int64_t left = g.nx - bpx0;
+    const int np = left > kRetainThreads ? kRetainThreads : (int)left;
+    const int pitch = k | 1;
+    const int imgsz = kRetainThreads * pitch;
+
+    // stage the contiguous span of `np` pixels of one variable into image `slot`
+    auto stage = [&](const T *base, int vi, int slot, bool both_halves) {
+        const int ids = pm.ids[vi];
+        const int spp = k * ids;
+        const int total = np * spp;
+        const T *src = base + bpx0 * spp;
+        T *dst = img + slot * imgsz;
+        for (int e0 = 0; e0 < total; e0 += kRetainThreads * 8) {
+            T buf[8];
+            int di[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * kRetainThreads + tid;
+                di[u] = -1;
+                if (e < total) {
+                    const int q = (int)__umulhi((unsigned)e, pm.magic[vi]);
+                    const int r = e - q * spp;
+                    if (ids == 1)
+                        di[u] = q * pitch + r;
+                    else if (both_halves)                    // even -> this image, odd -> the next
+                        di[u] = (r & 1) * imgsz + q * pitch + (r >> 1);
+                    else if ((r & 1) == 0)
+                        di[u] = q * pitch + (r >> 1);
+                    if (di[u] >= 0) buf[u] = __builtin_nontemporal_load(src + e);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (di[u] >= 0) dst[di[u]] = buf[u];
+        }
+    };
+
+    T v[KMAX][4];
+    const int own = (in ? tid : np - 1) * pitch;            // idle lanes copy the last pixel
+    // round 1: C11 and C22
+    stage(g.c11, 0, 0, false);
+    stage(g.c22, 3, 1, false);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (t < k) {
+            v[t][0] = img[own + t];
+            v[t][3] = img[imgsz + own + t];
+        }
+    __syncthreads();
+    // round 2: the two halves of C12
+    if (pm.c12_joint) {
+        stage(g.c12r, 1, 0, true);
+    } else {
+        stage(g.c12r, 1, 0, false);
+        stage(g.c12i, 2, 1, false);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (t < k) {
+            v[t][1] = img[own + t];
+            v[t][2] = img[imgsz + own + t];
+        }
+    constexpr bool EXACT = false;
+    (void)EXACT;
+
+    if (g.write_tab && b == 0) {
+        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
+    }
+
+    // ---- fold in time order ----
+    Accum<T> A;
+    A.reset();
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+
+    bool flag;
+    if (STATS) {
+        const T z = z_stat<T>(A, k, g.nlooks, g.e);
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        flag = in && ((double)P > g.alpha);
+        if (in) {
+            const int64_t pix = row * g.nx + x0;
+            if (g.z_out) g.z_out[pix] = z;
+            if (g.p_out) g.p_out[pix] = P;
+        }
+    } else {
+        flag = in && (z_approx<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
+    }
+
+    // ---- list + dump ----
+    if (__any(flag)) {
+        const unsigned long long m = __ballot(flag);
+        const unsigned shard = (unsigned)(b % kShards);
+        if (__popcll(m) >= g.dense_min) {
+            // dense wave: one entry for all 64 pixels, no dump (the dense kernel reloads them,
+            // coalesced, and decides every pixel itself)
+            if (lane == 0) {
+                const unsigned slot = atomicAdd(g.flag_count + shard * kCounterStride + 1, 1u);
+                g.dense_idx[(size_t)shard * g.segd + slot] = (uint32_t)(row * g.nx + bpx0 + (tid & ~63));
+            }
+        } else {
+            unsigned base = 0;
+            if (lane == 0)
+                base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
+            base = __shfl(base, 0);
+            if (flag) {
+                const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
+                if (slot < g.dump_cap) {
+                    T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+#pragma unroll
+                    for (int t = 0; t < KMAX; ++t) {
+                        if (t < k) {
+                            Pack<T, 4> q;
+                            q.v[0] = v[t][0];
+                            q.v[1] = v[t][1];
+                            q.v[2] = v[t][2];
+                            q.v[3] = v[t][3];
+                            *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- zero-fill this block's slice of the change map (np.zeros at nd/_change.pyx:275).
+    // Issued last so that no wait on the loads or on the atomic above also has to wait for
+    // these stores (vmcnt retires in order). ----
+    {
+        const int64_t left = g.nx - bpx0;
+        const int npx = left > kRetainThreads ? kRetainThreads : (int)left;
+        uint8_t *ob = g.change + (row * g.nx + bpx0) * (int64_t)k;
+        const int nb = npx * k;                              // <= 256 * k bytes
+        int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (tid < head) ob[tid] = 0;
+        const int nvec = (nb - head) >> 4;
+        uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
+        for (int i = tid; i < nvec; i += kRetainThreads) store_zero16_nt(vz + i);
+        const int tail0 = head + (nvec << 4);
+        if (tail0 + tid < nb) ob[tail0 + tid] = 0;
+    }
+}
+
+
 // =========================================================================================
 // dense waves: the change-point search from registers
 // =========================================================================================
@@ -620,6 +801,7 @@ struct OmniSearchArgs {
     const T *c11, *c12r, *c12i, *c22;
     int64_t nx;
     int64_t sy, sx, st;
+    int m11, m12, m22;        // element-offset multipliers per variable (pixel-major inputs: 1 or 2)
     int k;
     double nlooks, alpha;
     uint8_t *change;
@@ -708,10 +890,10 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     for (int u = 0; u < 4; ++u)
                         if (t0 + u < k) {
                             const int64_t o = off + (int64_t)(t0 + u) * s.st;
-                            q[u][0] = s.c11[o];
-                            q[u][1] = s.c12r[o];
-                            q[u][2] = s.c12i[o];
-                            q[u][3] = s.c22[o];
+                            q[u][0] = s.c11[o * s.m11];
+                            q[u][1] = s.c12r[o * s.m12];
+                            q[u][2] = s.c12i[o * s.m12];
+                            q[u][3] = s.c22[o * s.m22];
                         }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
@@ -736,10 +918,10 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                 q = *reinterpret_cast<const Pack<T, 4> *>(dsrc + 4 * t);
             } else {
                 const int64_t o = off + (int64_t)t * s.st;
-                q.v[0] = s.c11[o];
-                q.v[1] = s.c12r[o];
-                q.v[2] = s.c12i[o];
-                q.v[3] = s.c22[o];
+                q.v[0] = s.c11[o * s.m11];
+                q.v[1] = s.c12r[o * s.m12];
+                q.v[2] = s.c12i[o * s.m12];
+                q.v[3] = s.c22[o * s.m22];
             }
             return q;
         };
@@ -971,8 +1153,10 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                            int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int64_t st,
                            uint32_t n_looks, double alpha, uint8_t *change, void *z_out,
                            void *p_out, void *workspace, size_t workspace_bytes,
-                           hipStream_t stream)
+                           hipStream_t stream, const int64_t *pm_ids = nullptr)
 {
+    // pm_ids != null: pixel-major inputs, element (y, x, t) of variable v at
+    // ptr_v[((y * nx + x) * k + t) * pm_ids[v]]; sy / sx / st then describe the unit-stride case
     const int64_t npix = ny * nx;
     const OmniWorkspace w = omni_layout(npix, ny, k, sizeof(T));
     if (workspace == nullptr || workspace_bytes < w.min_total) {
@@ -1033,7 +1217,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const char *e = getenv("ND_AMD_DENSE_MIN");
         return e ? atoi(e) : 16;
     }();
-    const bool dense_ok = k <= (sizeof(T) == 4 ? 32 : 16);
+    const bool dense_ok = k <= (sizeof(T) == 4 ? 32 : 16) && pm_ids == nullptr;
     g.dense_min = dense_ok ? dense_env : 65;
     const bool stats = (z_out != nullptr) || (p_out != nullptr);
     const bool retain = k <= (sizeof(T) == 4 ? kRetainMaxF32 : kRetainMaxF64);
@@ -1051,7 +1235,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     const bool aligned = (sx == 1) && (((uintptr_t)c11 | (uintptr_t)c12re | (uintptr_t)c12im |
                                         (uintptr_t)c22) & 15) == 0 &&
                          ((sy * (int64_t)es) % 16 == 0) && ((st * (int64_t)es) % 16 == 0);
-    const bool flat = (sx == 1) && (sy == nx);
+    // pixel-major inputs are walked as one flat row of pixels as well
+    const bool flat = ((sx == 1) && (sy == nx)) || pm_ids != nullptr;
     g.nx = flat ? npix : nx;
     g.nrows = flat ? 1 : ny;
     const int ppt = retain ? 1 : (aligned ? VPPT : 1);
@@ -1062,7 +1247,47 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                   (long long)nblocks);
         return ND_AMD_EUNSUPPORTED;
     }
-    {
+    if (pm_ids != nullptr) {
+        if (!retain || !flat) {
+            set_error("nd_amd_omnibus_c2_pixel_major: %lld dates exceed the register-retaining sizes",
+                      (long long)k);
+            return ND_AMD_EUNSUPPORTED;
+        }
+        OmniPmArgs<T> pm;
+        for (int vi = 0; vi < 4; ++vi) {
+            pm.ids[vi] = (int)pm_ids[vi];
+            const unsigned spp = (unsigned)(k * pm_ids[vi]);
+            pm.magic[vi] = (unsigned)((0x100000000ULL + spp - 1) / spp);
+        }
+        pm.c12_joint = (pm_ids[1] == 2 && pm_ids[2] == 2 &&
+                        static_cast<const T *>(c12im) == static_cast<const T *>(c12re) + 1) ? 1 : 0;
+        const size_t lds = 2 * (size_t)kRetainThreads * (size_t)(k | 1) * sizeof(T);
+        if (lds > 64 * 1024) {
+            set_error("nd_amd_omnibus_c2_pixel_major: %lld dates of this type do not fit the staging image",
+                      (long long)k);
+            return ND_AMD_EUNSUPPORTED;
+        }
+        const dim3 grid((unsigned)nblocks), block(kRetainThreads);
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+#define ND_LAUNCH_PM(KM)                                                                              \
+    do {                                                                                              \
+        if (stats)                                                                                    \
+            hipLaunchKernelGGL((omnibus_c2_retain_pm_kernel<T, KM, true>), grid, block, lds, stream, g, tab, pm);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((omnibus_c2_retain_pm_kernel<T, KM, false>), grid, block, lds, stream, g, tab, pm); \
+    } while (0)
+        if (k <= 8)
+            ND_LAUNCH_PM(8);
+        else if (k <= 16)
+            ND_LAUNCH_PM(16);
+        else if (k <= 24)
+            ND_LAUNCH_PM(24);
+        else {
+            set_error("nd_amd_omnibus_c2_pixel_major: at most 24 dates");
+            return ND_AMD_EUNSUPPORTED;
+        }
+#undef ND_LAUNCH_PM
+    } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (retain)
             launch_retain<T>(g, tab, nblocks, stats, stream);
@@ -1127,6 +1352,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     s.sy = sy;
     s.sx = sx;
     s.st = st;
+    s.m11 = pm_ids ? (int)pm_ids[0] : 1;
+    s.m12 = pm_ids ? (int)pm_ids[1] : 1;
+    s.m22 = pm_ids ? (int)pm_ids[3] : 1;
     s.k = (int)k;
     s.nlooks = g.nlooks;
     s.alpha = alpha;
@@ -1214,4 +1442,52 @@ extern "C" int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void 
     return omnibus_c2_impl<double>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x,
                                    stride_t, n_looks, alpha, change, z_out, p_out, workspace,
                                    workspace_bytes, stream);
+}
+
+extern "C" int nd_amd_omnibus_c2_pixel_major(const void *c11, const void *c12re, const void *c12im,
+                                             const void *c22, int dtype, int64_t ny, int64_t nx,
+                                             int64_t k, const int64_t date_stride[4],
+                                             uint32_t n_looks, double alpha, uint8_t *change,
+                                             void *z_out, void *p_out, void *workspace,
+                                             size_t workspace_bytes, void *hip_stream)
+{
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_omnibus_c2_pixel_major: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (ny < 0 || nx < 0 || k < 0 || !date_stride) {
+        set_error("nd_amd_omnibus_c2_pixel_major: bad shape");
+        return ND_AMD_EINVAL;
+    }
+    for (int vi = 0; vi < 4; ++vi)
+        if (date_stride[vi] != 1 && date_stride[vi] != 2) {
+            set_error("nd_amd_omnibus_c2_pixel_major: date strides must be 1 or 2");
+            return ND_AMD_EINVAL;
+        }
+    if (date_stride[1] != date_stride[2]) {
+        set_error("nd_amd_omnibus_c2_pixel_major: the two halves of C12 must share their stride");
+        return ND_AMD_EINVAL;
+    }
+    if (ny == 0 || nx == 0 || k == 0) return ND_AMD_OK;
+    if (!c11 || !c12re || !c12im || !c22 || !change) {
+        set_error("nd_amd_omnibus_c2_pixel_major: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    if (n_looks == 0) {
+        set_error("nd_amd_omnibus_c2_pixel_major: n_looks must be >= 1");
+        return ND_AMD_EINVAL;
+    }
+    if (ny * nx >= 0xffffffffLL || k > 24) {
+        set_error("nd_amd_omnibus_c2_pixel_major: at most 24 dates and 2^32 - 1 pixels");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    // unit-stride geometry of the layout: (y, x, t) -> (y * nx + x) * k + t
+    if (dtype == ND_AMD_F32)
+        return omnibus_c2_impl<float>(c11, c12re, c12im, c22, ny, nx, k, nx * k, k, 1, n_looks, alpha,
+                                      change, z_out, p_out, workspace, workspace_bytes, stream,
+                                      date_stride);
+    return omnibus_c2_impl<double>(c11, c12re, c12im, c22, ny, nx, k, nx * k, k, 1, n_looks, alpha,
+                                   change, z_out, p_out, workspace, workspace_bytes, stream,
+                                   date_stride);
 }

@@ -94,6 +94,45 @@ def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x')
     return change
 
 
+def change_detection_pixel_major(c11, c12re, c12im, c22, alpha, n=1, stats=False):
+    """change_detection for four device variables in the reference's own layout, (y, x, time) with
+    time fastest; `c12re` / `c12im` may be the `.real` / `.imag` views of one complex tensor (read
+    once).  Returns None when the layout or the series length is not one the pixel-major kernel
+    takes (the caller then transposes and uses change_detection)."""
+    vs = (c11, c12re, c12im, c22)
+    if not all(torch.is_tensor(t) and t.is_cuda and t.dim() == 3 for t in vs):
+        return None
+    ny, nx, k = c11.shape
+    dt = c11.dtype
+    if dt not in _DT or k > (24 if dt == torch.float32 else 12) or ny * nx * k == 0:
+        return None
+    ids = []
+    for t in vs:
+        if t.shape != c11.shape or t.dtype != dt or t.device != c11.device:
+            return None
+        ids.append(_pixel_major_stride(t))
+        if ids[-1] is None:
+            return None
+    if c12im.data_ptr() == c12re.data_ptr() + c12re.element_size():
+        ids[1] = ids[2] = 2                   # the halves of one interleaved tensor (any size)
+    if ids[1] != ids[2]:
+        return None
+    dev = c11.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        change = torch.empty((ny, nx, k), dtype=torch.uint8, device=dev)
+        z = torch.empty((ny, nx), dtype=dt, device=dev) if stats else None
+        P = torch.empty((ny, nx), dtype=dt, device=dev) if stats else None
+        nbytes = L.nd_amd_omnibus_c2_workspace_bytes(_DT[dt], ny, nx, k, None)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(L.nd_amd_omnibus_c2_pixel_major(
+            _ptr(c11), _ptr(c12re), _ptr(c12im), _ptr(c22), _DT[dt], ny, nx, k,
+            _lib.i64_array(ids), int(n), float(alpha), _ptr(change), _ptr(z), _ptr(P), _ptr(ws), nbytes,
+            _stream_ptr(dev)))
+        ws.record_stream(torch.cuda.current_stream(dev))
+    return (change, z, P) if stats else change
+
+
 def change_detection_c3(planes, alpha, n=1, dims=('time', 'y', 'x'), stats=False):
     """Full-pol (3 x 3) omnibus change detection -- an extension, the reference is dual-pol only.
     planes: nine CUDA tensors [C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im] of
@@ -136,6 +175,24 @@ def change_detection_c3(planes, alpha, n=1, dims=('time', 'y', 'x'), stats=False
 # ---------------------------------------------------------------------------
 # layout change in front of the hot path
 # ---------------------------------------------------------------------------
+def _pixel_major_stride(t):
+    """1 if the 3-D tensor `t` (y, x, time) is C-contiguous, 2 if it is one half of an interleaved
+    complex tensor of that layout, else None.  Strides of length-1 axes carry no information."""
+    ny, nx, k = t.shape
+    for ids in (1, 2):
+        want = (nx * k * ids, k * ids, ids)
+        if all(n == 1 or s == w for n, s, w in zip(t.shape, t.stride(), want)):
+            return ids
+    return None
+
+
+def _planar_ok(t, ny, nx):
+    """(time, y, x) tensor with x contiguous, rows adjacent, any plane pitch >= ny * nx."""
+    k = t.shape[0]
+    return ((nx == 1 or t.stride(2) == 1) and (ny == 1 or t.stride(1) == nx)
+            and (k == 1 or t.stride(0) >= ny * nx))
+
+
 _RELAYOUT_LDS = 48 * 1024      # bytes of LDS one pixel's series may take in the transpose kernels
 
 
@@ -151,17 +208,16 @@ def relayout_planar(src, dst):
         return False
     if ny * nx * k == 0:
         return True
-    ids = src.stride(2)
-    if ids not in (1, 2) or src.stride(1) != k * ids or src.stride(0) != nx * k * ids:
+    ids = _pixel_major_stride(src)
+    if ids is None or not _planar_ok(dst, ny, nx):
         return False
     if (k | 1) * src.element_size() > _RELAYOUT_LDS:        # series too long for the staging buffer
-        return False
-    if dst.stride(2) != 1 or dst.stride(1) != nx or dst.stride(0) < ny * nx:
         return False
     dev = src.device
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nd_amd_relayout_planar(
-            _ptr(src), _ptr(dst), _DT[src.dtype], ny * nx, k, ids, dst.stride(0), _stream_ptr(dev)))
+            _ptr(src), _ptr(dst), _DT[src.dtype], ny * nx, k, ids, max(dst.stride(0), ny * nx),
+            _stream_ptr(dev)))
     return True
 
 
@@ -173,22 +229,24 @@ def relayout_planar_complex(src_re, src_im, dst_re, dst_im):
         return False
     ny, nx, k = src_re.shape
     es = src_re.element_size()
-    if (src_im.shape != src_re.shape or src_im.stride() != src_re.stride() or src_re.dtype not in _DT
+    if (src_im.shape != src_re.shape or src_re.dtype not in _DT
             or src_im.dtype != src_re.dtype or src_im.data_ptr() != src_re.data_ptr() + es
-            or src_re.stride() != (nx * k * 2, k * 2, 2)):
+            or _pixel_major_stride(src_re) is None or _pixel_major_stride(src_im) is None
+            or (ny * nx * k > 1 and (_pixel_major_stride(src_re) != 2 or _pixel_major_stride(src_im) != 2))):
         return False
     if ((2 * k) | 1) * es > _RELAYOUT_LDS:
         return False
     for d in (dst_re, dst_im):
-        if (tuple(d.shape) != (k, ny, nx) or d.dtype != src_re.dtype or d.stride(2) != 1
-                or d.stride(1) != nx or d.stride(0) < ny * nx or d.stride(0) != dst_re.stride(0)):
+        if (tuple(d.shape) != (k, ny, nx) or d.dtype != src_re.dtype or not _planar_ok(d, ny, nx)
+                or (k > 1 and d.stride(0) != dst_re.stride(0))):
             return False
     if ny * nx * k == 0:
         return True
     dev = src_re.device
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nd_amd_relayout_planar_complex(
-            _ptr(src_re), _ptr(dst_re), _ptr(dst_im), _DT[src_re.dtype], ny * nx, k, dst_re.stride(0),
+            _ptr(src_re), _ptr(dst_re), _ptr(dst_im), _DT[src_re.dtype], ny * nx, k,
+            max(dst_re.stride(0), ny * nx),
             _stream_ptr(dev)))
     return True
 
@@ -204,17 +262,16 @@ def relayout_pixel_major(src, dst):
         return False
     if ny * nx * k == 0:
         return True
-    ods = dst.stride(2)
-    if ods not in (1, 2) or dst.stride(1) != k * ods or dst.stride(0) != nx * k * ods:
+    ods = _pixel_major_stride(dst)
+    if ods is None or not _planar_ok(src, ny, nx):
         return False
     if (k | 1) * src.element_size() > _RELAYOUT_LDS:
-        return False
-    if src.stride(2) != 1 or src.stride(1) != nx or src.stride(0) < ny * nx:
         return False
     dev = src.device
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nd_amd_relayout_pixel_major(
-            _ptr(src), _ptr(dst), _DT[src.dtype], ny * nx, k, src.stride(0), ods, _stream_ptr(dev)))
+            _ptr(src), _ptr(dst), _DT[src.dtype], ny * nx, k, max(src.stride(0), ny * nx), ods,
+            _stream_ptr(dev)))
     return True
 
 

@@ -132,3 +132,33 @@ def test_minimal_workspace_gathers_from_planes(oracle, device, dtype):
         for ws in ('minimal', 'recommended'):
             got = kernels.change_detection(*ts, alpha=alpha, n=n, workspace=ws)
             np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('dtype,k', [(np.float32, 24), (np.float32, 7), (np.float32, 16), (np.float64, 12),
+                                     (np.float64, 5)])
+def test_pixel_major_kernel_equals_planar(oracle, device, dtype, k):
+    """nd_amd_omnibus_c2_pixel_major: variables in the reference's (y, x, time) layout, C12 as one
+    interleaved complex tensor or as two real ones; ragged raster sizes; z / P output; equal to the
+    oracle and to the planar entry point."""
+    import torch
+    from nd_amd import kernels
+    from tests import synth as tsynth
+    for ny, nx in [(1, 1), (3, 70), (33, 257), (64, 64)]:
+        planes = tsynth.omnibus_stack(seed=ny * nx + k, k=k, ny=ny, nx=nx, dtype=dtype, change_frac=0.3)
+        yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+        want, zw, pw = oracle.change_detection_planes(yxt, 0.9, 9, njobs=4, stats=True)
+        dev = [torch.from_numpy(a).to(device) for a in yxt]
+        got = kernels.change_detection_pixel_major(dev[0], dev[1], dev[2], dev[3], alpha=0.9, n=9)
+        assert got is not None
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        c12 = torch.complex(dev[1], dev[2])
+        res = kernels.change_detection_pixel_major(dev[0], c12.real, c12.imag, dev[3], alpha=0.9, n=9,
+                                                   stats=True)
+        np.testing.assert_array_equal(res[0].cpu().numpy(), want)
+        np.testing.assert_allclose(res[1].cpu().numpy(), zw, rtol=1e-5, equal_nan=True)
+        np.testing.assert_allclose(res[2].cpu().numpy(), pw, rtol=1e-5, atol=1e-7, equal_nan=True)
+    # not that layout / too long a series: declined
+    t = torch.zeros((4, 5, 30), device=device)
+    assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
+    t = torch.zeros((6, 4, 5), device=device).permute(1, 2, 0)
+    assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
