@@ -47,11 +47,11 @@ def case_omnibus(rng):
         bad = rng.random((k, ny, nx)) < 0.01
         val = rng.choice([0.0, np.nan, np.inf, -1.0])
         planes[int(rng.integers(0, 4))][bad] = val
-    layout = rng.choice(['tyx', 'yxt', 'pad'])
+    layout = rng.choice(['tyx', 'yxt', 'pad', 'pm', 'pmc'])
     desc = dict(k=k, ny=ny, nx=nx, looks=looks, dtype=np.dtype(dtype).name, alpha=alpha, n=n, layout=str(layout))
     with np.errstate(all='ignore'):
         want, zw, pw = O.change_detection_planes([np.moveaxis(p, 0, -1) for p in planes], alpha, n, njobs=8, stats=True)
-    if layout == 'tyx':
+    if layout in ('tyx', 'pm', 'pmc'):
         dev = [torch.from_numpy(p).to(DEV) for p in planes]
         dims = ('time', 'y', 'x')
     elif layout == 'yxt':
@@ -66,7 +66,19 @@ def case_omnibus(rng):
     stats = bool(rng.random() < 0.5)
     ws = str(rng.choice(['recommended', 'minimal']))
     desc.update(stats=stats, workspace=ws)
-    res = kernels.change_detection(*dev, alpha=alpha, n=n, dims=dims, stats=stats, workspace=ws)
+    res = None
+    if layout in ('pm', 'pmc'):
+        # the reference's own layout through the pixel-major kernel (C12 interleaved for 'pmc')
+        dev = [torch.from_numpy(np.ascontiguousarray(np.moveaxis(p, 0, -1))).to(DEV) for p in planes]
+        dims = ('y', 'x', 'time')
+        if layout == 'pmc':
+            c12 = torch.complex(dev[1], dev[2])
+            dev = [dev[0], c12.real, c12.imag, dev[3]]
+        res = kernels.change_detection_pixel_major(*dev, alpha=alpha, n=n, stats=stats)
+        if res is None and layout == 'pmc':
+            dev = [d.contiguous() for d in dev]
+    if res is None:
+        res = kernels.change_detection(*dev, alpha=alpha, n=n, dims=dims, stats=stats, workspace=ws)
     got = (res[0] if stats else res).cpu().numpy()
     ok = np.array_equal(got, want)
     if ok and stats:
