@@ -217,3 +217,24 @@ def test_change_summaries():
     fc = first_change(da).values
     assert fc[0, 0] == 2 and fc[1, 2] == 1 and fc[0, 1] == -1
     assert change_count(da).dims == ('y', 'x')
+
+
+def test_layout_recognition_helpers():
+    """Pure stride logic of the transpose / pixel-major wrappers (no GPU needed)."""
+    import torch
+    from nd_amd import kernels
+    t = torch.zeros((3, 5, 7))
+    assert kernels._pixel_major_stride(t) == 1
+    c = torch.zeros((3, 5, 7), dtype=torch.complex64)
+    assert kernels._pixel_major_stride(c.real) == 2 and kernels._pixel_major_stride(c.imag) == 2
+    assert kernels._pixel_major_stride(t.permute(1, 0, 2)) is None
+    assert kernels._pixel_major_stride(t[:, ::2]) is None
+    assert kernels._pixel_major_stride(torch.zeros((1, 1, 24))) == 1           # length-1 axes
+    assert kernels._pixel_major_stride(torch.zeros((1, 4, 1))) == 1
+    p = torch.zeros((7, 3, 5))
+    assert kernels._planar_ok(p, 3, 5)
+    assert kernels._planar_ok(torch.zeros((7, 20))[:, :15].view(7, 3, 5), 3, 5)    # padded planes
+    assert not kernels._planar_ok(p.permute(0, 2, 1), 5, 3)
+    # CPU tensors are declined by the wrappers themselves
+    assert kernels.relayout_planar(t, p) is False
+    assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
