@@ -65,13 +65,19 @@ __device__ __forceinline__ T z_stat3(const Accum3<T> &A, int j, double nlooks, c
 }
 
 template <typename T>
+__device__ __forceinline__ double z_approx3(const Accum3<T> &A, int j, double nlooks, double m2rho,
+                                            double pklogk)
+{
+    const T det_of_sum = det3<T>(A.s);
+    const double logQ = nlooks * ((pklogk + approx_ln(A.prod)) -
+                                  ((double)j * approx_ln((double)det_of_sum)));
+    return m2rho * logQ;
+}
+template <typename T>
 __device__ __forceinline__ double z_approx3(const Accum3<T> &A, int j, double nlooks,
                                             const OmniTabEntry &e)
 {
-    const T det_of_sum = det3<T>(A.s);
-    const double logQ = nlooks * ((e.pklogk + approx_ln(A.prod)) -
-                                  ((double)j * approx_ln((double)det_of_sum)));
-    return e.m2rho * logQ;
+    return z_approx3<T>(A, j, nlooks, e.m2rho, e.pklogk);
 }
 
 template <typename T>
@@ -185,6 +191,19 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
     const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
     const uint32_t n = s.flag_count[shard * kC3CounterStride];
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+    if (lblock * 64u >= n) return;            // nothing for this block
+    // per-j constants of the screen as four LDS arrays behind the series image (omnibus.hip): every
+    // lane looks up its own j in every iteration
+    const int kp = k + 1;
+    double *scr = reinterpret_cast<double *>(nd_smem3 + (USE_LDS ? (size_t)k * 9 * 64 * sizeof(T) : 0));
+    for (int j = lane; j <= k; j += 64) {
+        const OmniTabEntry e = s.tab_dev[j];
+        scr[j] = e.m2rho;
+        scr[kp + j] = e.pklogk;
+        scr[2 * kp + j] = e.zlo_a;
+        scr[3 * kp + j] = e.zhi_a;
+    }
+    __syncthreads();
 
     for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
         const uint32_t idx = base + lane;
@@ -193,10 +212,22 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
         const int64_t row = pix / s.nx_orig, col = pix - row * s.nx_orig;
         const int64_t off = row * s.sy + col * s.sx;
         if (USE_LDS) {
-            for (int t = 0; t < k; ++t) {
-                const int64_t o = off + (int64_t)t * s.st;
+            // eight dates (72 independent loads per lane) in flight at a time
+            for (int t0 = 0; t0 < k; t0 += 8) {
+                T q[8][9];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) lds[(t * 9 + c) * 64 + lane] = s.pl[c][o];
+                for (int u = 0; u < 8; ++u)
+                    if (t0 + u < k) {
+                        const int64_t o = off + (int64_t)(t0 + u) * s.st;
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) q[u][c] = s.pl[c][o];
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (t0 + u < k) {
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) lds[((t0 + u) * 9 + c) * 64 + lane] = q[u][c];
+                    }
             }
         }
         auto load_step = [&](Accum3<T> &A, int t) {
@@ -228,10 +259,9 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
                 // wave-uniform branch so that it is not folded into the loop body (omnibus.hip)
                 bool fires = false, inband = false;
                 if (need) {
-                    const OmniTabEntry &e = s.tab_dev[jj];
-                    const double za = z_approx3<T>(A, jj, s.nlooks, e);
-                    fires = (za > e.zhi_a) && (za < INFINITY);
-                    inband = (za >= e.zlo_a) && !fires;
+                    const double za = z_approx3<T>(A, jj, s.nlooks, scr[jj], scr[kp + jj]);
+                    fires = (za > scr[3 * kp + jj]) && (za < INFINITY);
+                    inband = (za >= scr[2 * kp + jj]) && !fires;
                 }
                 if (__any(inband)) {
                     if (inband) {
@@ -354,8 +384,15 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     }
     ND_HIP_CHECK(hipGetLastError());
 
-    const size_t lds_bytes = (size_t)k * 9 * 64 * sizeof(T);
-    const bool use_lds = lds_bytes <= 64 * 1024;
+    // the LDS image of 64 series: up to 150 KB of the CU's 160 KB (one wave per CU then, which still
+    // beats a dependent, TLB-missing plane access per date and lane)
+    const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);
+    const size_t lds_bytes = (size_t)k * 9 * 64 * sizeof(T) + scr_bytes;
+    const bool use_lds = lds_bytes <= 150 * 1024;
+    if (use_lds && lds_bytes > 64 * 1024) {
+        ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c3_search_kernel<T, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
     int64_t per_shard = ceil_div(ceil_div(npix, kC3Shards), 64);
     if (per_shard > 64) per_shard = 64;
     if (per_shard < 1) per_shard = 1;
@@ -367,7 +404,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
                                lds_bytes, stream, g);
         else
             hipLaunchKernelGGL((omnibus_c3_search_kernel<T, false>), dim3((unsigned)sblocks),
-                               dim3(64), 0, stream, g);
+                               dim3(64), scr_bytes, stream, g);
     }
     ND_HIP_CHECK(hipGetLastError());
     return ND_AMD_OK;
