@@ -1367,7 +1367,13 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     s.dump_cap = g.dump_cap;
     const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);      // screen constants
     const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T) + scr_bytes;
-    const bool use_lds = lds_bytes <= 64 * 1024;
+    // the LDS image of 64 series may take up to 150 KB of the CU's 160 KB: for long series that is
+    // one or two waves per CU, still well ahead of a dependent plane access per date and lane
+    const bool use_lds = lds_bytes <= 150 * 1024;
+    if (use_lds && lds_bytes > 64 * 1024) {
+        ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
     // kShards x (blocks per shard); a shard's blocks stride through its list
     int64_t per_shard = ceil_div(ceil_div(npix, kShards), 64);
     if (per_shard > 64) per_shard = 64;
