@@ -59,6 +59,8 @@ VARIANTS = {
     # dense kernel: occupancy hints
     'd_w3': [("__launch_bounds__(64) omnibus_c2_dense_kernel", "__launch_bounds__(64, 3) omnibus_c2_dense_kernel")],
     'd_w4': [("__launch_bounds__(64) omnibus_c2_dense_kernel", "__launch_bounds__(64, 4) omnibus_c2_dense_kernel")],
+    # pass A: product of determinants as a float32 sum of logs (timing only, not exact)
+    'a_logsum': [('    // ---- fold in time order ----\n    Accum<T> A;\n    A.reset();\n#pragma unroll\n    for (int t = 0; t < KMAX; ++t)\n        if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);\n\n    bool flag;\n    if (STATS) {', '    // ---- fold in time order ----\n    Accum<T> A;\n    A.reset();\n    float lsum = 0.f;\n    if (STATS) {\n#pragma unroll\n    for (int t = 0; t < KMAX; ++t)\n        if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);\n    } else {\n#pragma unroll\n    for (int t = 0; t < KMAX; ++t)\n        if (EXACT || t < k) {\n            const T a_ = v[t][0], b_ = v[t][1], c_ = v[t][2], d_ = v[t][3];\n            const T det = (a_ * d_) - ((b_ * b_) + (c_ * c_));\n            lsum = lsum + __log2f(fabsf((float)det));\n            A.s11 = A.s11 + a_; A.s12r = A.s12r + b_; A.s12i = A.s12i + c_; A.s22 = A.s22 + d_;\n        }\n    A.prod = exp2((double)lsum);\n    }\n\n    bool flag;\n    if (STATS) {')],
     # pass A block size
     't128': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 128")],
 }
