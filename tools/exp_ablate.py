@@ -61,6 +61,9 @@ VARIANTS = {
     'd_w4': [("__launch_bounds__(64) omnibus_c2_dense_kernel", "__launch_bounds__(64, 4) omnibus_c2_dense_kernel")],
     # pass A: product of determinants as a float32 sum of logs (timing only, not exact)
     'a_logsum': [('    // ---- fold in time order ----\n    Accum<T> A;\n    A.reset();\n#pragma unroll\n    for (int t = 0; t < KMAX; ++t)\n        if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);\n\n    bool flag;\n    if (STATS) {', '    // ---- fold in time order ----\n    Accum<T> A;\n    A.reset();\n    float lsum = 0.f;\n    if (STATS) {\n#pragma unroll\n    for (int t = 0; t < KMAX; ++t)\n        if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);\n    } else {\n#pragma unroll\n    for (int t = 0; t < KMAX; ++t)\n        if (EXACT || t < k) {\n            const T a_ = v[t][0], b_ = v[t][1], c_ = v[t][2], d_ = v[t][3];\n            const T det = (a_ * d_) - ((b_ * b_) + (c_ * c_));\n            lsum = lsum + __log2f(fabsf((float)det));\n            A.s11 = A.s11 + a_; A.s12r = A.s12r + b_; A.s12i = A.s12i + c_; A.s22 = A.s22 + d_;\n        }\n    A.prod = exp2((double)lsum);\n    }\n\n    bool flag;\n    if (STATS) {')],
+    # pass A: each XCD (block index mod 8) / each of 32 groups walks its own contiguous part of the raster
+    'a_xcd8': [('omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)\n{\n    const int tid = threadIdx.x;\n    const int lane = tid & 63;\n    const int64_t b = blockIdx.x;', 'omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)\n{\n    const int tid = threadIdx.x;\n    const int lane = tid & 63;\n    const int64_t nb_ = gridDim.x, per_ = nb_ >> 3;\n    const int64_t b = (nb_ & 7) ? (int64_t)blockIdx.x : ((int64_t)(blockIdx.x & 7) * per_ + (blockIdx.x >> 3));')],
+    'a_grp32': [('omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)\n{\n    const int tid = threadIdx.x;\n    const int lane = tid & 63;\n    const int64_t b = blockIdx.x;', 'omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)\n{\n    const int tid = threadIdx.x;\n    const int lane = tid & 63;\n    const int64_t nb_ = gridDim.x, per_ = nb_ >> 5;\n    const int64_t b = (nb_ & 31) ? (int64_t)blockIdx.x : ((int64_t)(blockIdx.x & 31) * per_ + (blockIdx.x >> 5));')],
     # pass A block size
     't128': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 128")],
 }
