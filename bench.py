@@ -1,17 +1,30 @@
 #!/usr/bin/env python3
 """
-bench.py -- headline benchmark of the nd_amd hot path on MI355X.
+bench.py -- benchmark of the nd_amd hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload omnibus|c3|pipeline]
+                    [--scaling weak|strong] [--no-extra]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): Mpixels/s of OmnibusTest on a dual-pol C2 stack,
-24 dates x 4096 x 4096 float32 per GPU, plus the achieved HBM GB/s of the
-dominant kernel against the chip's peak.  One "step" = one full OmnibusTest
-pass (both kernels) over the rank's device-resident stack.  With N ranks each
-rank owns one y-tile of a (N*4096) x 4096 raster (weak scaling; the omnibus test
-is per pixel, there is no data-path collective).
+Headline (default): BASELINE.json's metric, Mpixels/s of OmnibusTest on a dual-pol C2 stack of
+24 dates x 4096 x 4096 float32 (configs[1]), inputs resident in HBM, plus the achieved HBM GB/s of
+the dominant kernel against the chip's peak (kernel durations from HIP events recorded on the launch
+stream inside the timed region).  One "step" = one full pass of the workload over the rank's
+device-resident rows.
+
+Workloads (--workload), all row-sharded over the ranks (nd_amd/tiles.py):
+  omnibus   OmnibusTest C2, 24t x 4096 x 4096                       no collective
+  c3        OmnibusTest full-pol C3 (extension), 48t x 1024 x 8192  no collective (config 4's share)
+  pipeline  NLMeansFilter -> OmnibusTest with the tutorial's parameters, 24t x 2048 x 16384 x 4
+            variables (config 5's share); with N > 1 every step exchanges the halo rows with the
+            neighbouring ranks over RCCL (point-to-point), then filters tile+halo and tests.
+Scaling (--scaling): weak (default) = every rank owns a raster of the stated size, the job's raster
+is N times as tall; strong = the stated raster is split over the ranks by tiles.row_partition.
+
+At N = 1 with the default workload the line also carries `cpu_baseline` (the C oracle on the host's
+cores) and `extra`: the other kernels of the path (dense-threshold omnibus, C3, boxcar, non-local
+means in both patch modes, the pipeline) each with ms, Mpx/s, roofline and a sampled oracle check.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,10 +39,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes of pass A from the rocprofv3 PMC passes of an earlier run of the same command
+# (2 x FETCH_SIZE + WRITE_SIZE); reported with its source, never as a live measurement
+PROFILED_TRAFFIC = {('omnibus', 24, 4096, 4096, 0.99): (6.9769e9, 'profiles/r01_omnibus_rocprof.txt')}
 
-# HBM bytes per launch of the dominant kernel from the separate rocprofv3 PMC passes
-# (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_omnibus_rocprof.txt), keyed by (k, ny, nx, alpha, frac)
-MEASURED_TRAFFIC = {(24, 4096, 4096, 0.99, 0.01): 6.9769e9}
+DEFAULTS = {'omnibus': (24, 4096, 4096), 'c3': (48, 1024, 8192), 'pipeline': (24, 2048, 16384)}
+# tutorial parameters (examples/tutorial_s1.ipynb cells 11, 15; NLMeansFilter defaults sigma=h=f=1)
+TUT = dict(r=(1, 3, 3), f=(1, 1, 1), sigma=1.0, h=1.0, n_eff=50.0, n=50, alpha=1e-4)
 
 
 def parse():
@@ -37,18 +53,28 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--k', type=int, default=24)
-    ap.add_argument('--ny', type=int, default=4096)
-    ap.add_argument('--nx', type=int, default=4096)
+    ap.add_argument('--workload', choices=sorted(DEFAULTS), default='omnibus')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--k', type=int, default=None)
+    ap.add_argument('--ny', type=int, default=None)
+    ap.add_argument('--nx', type=int, default=None)
     ap.add_argument('--looks', type=int, default=9)
-    ap.add_argument('--alpha', type=float, default=0.99)
+    ap.add_argument('--alpha', type=float, default=None,
+                    help='omnibus / c3: 0.99 (SURVEY 8d); pipeline: the tutorial\'s 1e-4')
     ap.add_argument('--change-frac', type=float, default=0.01)
+    ap.add_argument('--patch-mode', type=int, default=0, help='pipeline: 0 reference, 1 signed')
     ap.add_argument('--cpu-rows', type=int, default=4096,
-                    help='rows of the stack the CPU baseline is timed on (0 = skip)')
+                    help='rows of the stack the all-core CPU baseline is timed on (0 = skip)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch of the dominant kernel from a separate '
-                         'rocprofv3 --pmc pass (profiles/), copied into roofline.traffic')
-    return ap.parse_args()
+                         'rocprofv3 --pmc pass, copied into roofline.traffic')
+    a = ap.parse_args()
+    dk, dy, dx = DEFAULTS[a.workload]
+    a.k, a.ny, a.nx = a.k or dk, a.ny or dy, a.nx or dx
+    if a.alpha is None:
+        a.alpha = TUT['alpha'] if a.workload == 'pipeline' else 0.99
+    return a
 
 
 def _usable_cores():
@@ -69,29 +95,341 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(stack, args, npix_rows):
-    """Time the CPU oracle (oracle/, a port of the reference's Cython path) on
-    the first `npix_rows` rows of the same stack, all host cores."""
+# ------------------------------------------------------------------------------------------
+# timing helpers
+# ------------------------------------------------------------------------------------------
+def _kernel_avgs(kt):
+    by = {}
+    for name, ms in kt:
+        by.setdefault(name, []).append(ms)
+    return {n: sum(v) / len(v) for n, v in by.items()}
+
+
+def timed(fn, steps, warmup, barrier, launches_per_step=8):
+    """W untimed calls, then EXACTLY `steps` calls between two barriers.  -> (seconds, kernel
+    averages from the library's HIP events on the launch stream, last result)."""
+    from nd_amd import _lib
+    _lib.timing_enable(launches_per_step * (steps + warmup) + 16)
+    out = None
+    for _ in range(warmup):
+        out = fn()
+    barrier()
+    _lib.timing_collect()          # drop the warm-up launches; the events themselves are reused
+    _lib.timing_dropped()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    kt = _lib.timing_collect()
+    dropped = _lib.timing_dropped()
+    _lib.timing_enable(0)
+    if dropped:
+        raise RuntimeError('%d kernel launches were not timed: timing ring too small' % dropped)
+    return dt, _kernel_avgs(kt), out
+
+
+def roofline(kernel, avg_ms, alg_bytes, note=None, traffic=None, traffic_source=None):
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    r = {'kernel': kernel, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'kernel_ms': avg_ms,
+         'algorithmic_bytes_per_launch': int(alg_bytes), 'traffic': traffic}
+    if traffic_source:
+        r['traffic_source'] = traffic_source
+    if note:
+        r['note'] = note
+    return r
+
+
+# ------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------
+class Workload:
+    """rows [r0, r1) of the job's raster on this rank."""
+
+    def __init__(self, a, rank, world, dev):
+        from nd_amd import tiles
+        self.a, self.rank, self.world, self.dev = a, rank, world, dev
+        self.k, self.nx = a.k, a.nx
+        self.global_ny = a.ny if a.scaling == 'strong' else a.ny * world
+        self.r0, self.r1 = tiles.row_partition(self.global_ny, world)[rank]
+        self.rows = self.r1 - self.r0
+        self.npix = self.rows * self.nx
+
+
+class OmnibusC2(Workload):
+    name, dom = 'omnibus', 'omnibus_c2_global'
+
+    def __init__(self, a, rank, world, dev):
+        super().__init__(a, rank, world, dev)
+        from nd_amd import synth
+        self.stack = synth.wishart_c2_stack(self.k, self.rows, self.nx, looks=a.looks,
+                                            seed=1234 + rank, device=dev, change_frac=a.change_frac)
+        # 384 B/px read (k = 24 float32 x 4 planes) + k B/px change map written by the same kernel
+        self.alg_bytes = self.npix * self.k * (4 * self.stack.element_size() + 1)
+        self.read_bytes = self.npix * self.k * 4 * self.stack.element_size()
+
+    def step(self):
+        from nd_amd import tiles
+        return tiles.omnibus_rows(self.stack, self.a.alpha, self.a.looks)
+
+    def metric(self):
+        return 'Mpixels/s OmnibusTest dual-pol %dt x %d x %d' % (self.k, self.a.ny, self.nx)
+
+    def describe(self):
+        return ('OmnibusTest dual-pol C2, synthetic %dt x %d x %d float32 %s (BASELINE.json '
+                'configs[1]), n=%d looks, alpha=%g, %.3g of pixels with a x4 step; inputs resident '
+                'in HBM' % (self.k, self.a.ny, self.nx,
+                            'per GPU' if self.a.scaling == 'weak' else 'in all, rows split over the GPUs',
+                            self.a.looks, self.a.alpha, self.a.change_frac))
+
+    def check(self, out, nsample=0):
+        from oracle import checks
+        return checks.omnibus_sample(self.stack, out, self.a.alpha, self.a.looks, nsample=nsample,
+                                     rows=(0, self.rows - 1), seed=4)
+
+
+class OmnibusC3(Workload):
+    name, dom = 'c3', 'omnibus_c2_global'          # the C3 pass A reports under the same id
+
+    def __init__(self, a, rank, world, dev):
+        super().__init__(a, rank, world, dev)
+        from nd_amd import synth
+        self.stack = synth.wishart_c3_stack(self.k, self.rows, self.nx, looks=a.looks,
+                                            seed=4321 + rank, device=dev, change_frac=a.change_frac)
+        self.alg_bytes = self.npix * self.k * (9 * self.stack.element_size() + 1)
+
+    def step(self):
+        from nd_amd import tiles
+        return tiles.omnibus_c3_rows(self.stack, self.a.alpha, self.a.looks)
+
+    def metric(self):
+        return 'Mpixels/s OmnibusTest full-pol C3 %dt x %d x %d' % (self.k, self.a.ny, self.nx)
+
+    def describe(self):
+        return ('OmnibusTest full-pol C3 (extension, no reference implementation), synthetic '
+                '%dt x %d x %d float32 x 9 planes %s (one GPU\'s share of BASELINE.json configs[3]), '
+                'n=%d looks, alpha=%g' % (self.k, self.a.ny, self.nx,
+                                          'per GPU' if self.a.scaling == 'weak' else 'in all',
+                                          self.a.looks, self.a.alpha))
+
+    def check(self, out, nsample=20000):
+        from oracle import checks
+        return checks.omnibus_sample(self.stack, out, self.a.alpha, self.a.looks, nsample=nsample,
+                                     rows=(), seed=4, pol=3)
+
+
+class Pipeline(Workload):
+    name, dom = 'pipeline', 'nlmeans_tiled'
+
+    def __init__(self, a, rank, world, dev):
+        super().__init__(a, rank, world, dev)
+        from nd_amd import synth, tiles
+        self.halo = TUT['r'][1] + TUT['f'][1]
+        self.shard = tiles.empty_shard((4, self.k), self.global_ny, self.nx, self.halo, dev,
+                                       rank=rank, world=world)
+        synth.wishart_c2_stack(self.k, self.rows, self.nx, looks=a.looks, seed=99 + rank,
+                               change_frac=a.change_frac, out=self.shard.core)
+        if world == 1:
+            self.stack = self.shard.core
+        # the filter reads and writes every (variable, date, pixel) once: 8 B per px.t.var
+        ext_px = self.shard.ext.shape[2] * self.nx
+        self.alg_bytes = ext_px * self.k * 4 * 8
+        self.filtered = None
+
+    def step(self):
+        from nd_amd import tiles
+        self.filtered = tiles.nlmeans_rows(self.shard, self.global_ny, TUT['r'], TUT['f'],
+                                           TUT['sigma'], TUT['h'], n_eff=TUT['n_eff'],
+                                           patch_mode=self.a.patch_mode)
+        return tiles.omnibus_rows(self.filtered, self.a.alpha, TUT['n'])
+
+    def metric(self):
+        return 'Mpixels/s NLMeans->OmnibusTest %dt x %d x %d' % (self.k, self.a.ny, self.nx)
+
+    def describe(self):
+        return ('NLMeansFilter(dims=(time,y,x), r=(1,3,3), f=1, sigma=1, h=1, n_eff=50, patch '
+                'distances %s) -> OmnibusTest(n=50, alpha=%g) (examples/tutorial_s1.ipynb cells 11, '
+                '15) on synthetic %dt x %d x %d float32 x 4 variables %s (one GPU\'s share of '
+                'BASELINE.json configs[4]); %s'
+                % ('as compiled (reference)' if self.a.patch_mode == 0 else 'signed', self.a.alpha,
+                   self.k, self.a.ny, self.nx, 'per GPU' if self.a.scaling == 'weak' else 'in all',
+                   'halo rows exchanged with the neighbour ranks over RCCL every step'
+                   if self.world > 1 else 'single rank: no exchange'))
+
+    def check(self, out, nsample=0):
+        from oracle import checks
+        crops = [(0, 0), (self.rows, self.nx), (self.rows // 2, self.nx // 3)]
+        return checks.nlmeans_crops(self.stack, self.filtered, TUT['r'], TUT['f'], TUT['sigma'],
+                                    TUT['h'], TUT['n_eff'], self.a.patch_mode, crops, size=(8, 64),
+                                    then_omnibus=(self.a.alpha, TUT['n']), change=out)
+
+
+WORKLOADS = {'omnibus': OmnibusC2, 'c3': OmnibusC3, 'pipeline': Pipeline}
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle timed on the host's cores, bounded samples
+# ------------------------------------------------------------------------------------------
+def cpu_baseline_omnibus(w, out):
     import numpy as np
     from oracle import oracle as O
     O.build()
-    rows = min(npix_rows, stack.shape[2])
-    host = stack[:, :, :rows, :].cpu().numpy()            # (4, k, rows, nx)
+    a = w.a
+    stack = w.stack
+    rows = min(a.cpu_rows, stack.shape[2])
+    host = stack[:, :, :rows, :].cpu().numpy()                 # (4, k, rows, nx)
     planes = [np.moveaxis(host[v], 0, -1) for v in range(4)]   # (rows, nx, k) strided views
     cores = _usable_cores()
     # warm (page-in + thread pool) on a sliver, then time
-    O.change_detection_planes([p[:8] for p in planes], args.alpha, args.looks, njobs=cores)
+    O.change_detection_planes([p[:8] for p in planes], a.alpha, a.looks, njobs=cores)
     t0 = time.perf_counter()
-    ch = O.change_detection_planes(planes, args.alpha, args.looks, njobs=cores)
+    ch = O.change_detection_planes(planes, a.alpha, a.looks, njobs=cores)
     dt = time.perf_counter() - t0
+    # one thread = the reference as shipped (its prange is serial: setup.py never passes -fopenmp)
+    rows1 = min(rows, 1024)
+    t0 = time.perf_counter()
+    O.change_detection_planes([p[:rows1] for p in planes], a.alpha, a.looks, njobs=1)
+    dt1 = time.perf_counter() - t0
     npx = rows * stack.shape[3]
-    return {
+    res = {
         'value': npx / dt / 1e6, 'unit': 'Mpixels/s', 'cores': int(cores), 'kind': 'port',
         'sample': 'oracle/nd_oracle.c (C port of nd/_change.pyx, reference-order arithmetic, '
                   'OpenMP over rows) on the first %d rows x %d cols x %d dates of the same '
                   'stack: %.2f s wall' % (rows, stack.shape[3], stack.shape[1], dt),
+        'one_thread': {'value': rows1 * stack.shape[3] / dt1 / 1e6, 'unit': 'Mpixels/s', 'cores': 1,
+                       'sample': 'first %d rows, %.2f s wall (the reference as shipped runs its '
+                                 'prange serially)' % (rows1, dt1)},
         'flagged_fraction': float((ch.sum(axis=2) > 0).mean()),
-    }, ch
+        'gpu_matches_cpu_on_sample': bool((out[:rows].cpu().numpy() == ch).all()),
+    }
+    return res
+
+
+# ------------------------------------------------------------------------------------------
+# secondary workloads (rank 0, N = 1)
+# ------------------------------------------------------------------------------------------
+def _free():
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def extras(main, barrier, dev):
+    import numpy as np
+    import torch
+    from nd_amd import kernels
+    from oracle import checks
+    from oracle import oracle as O
+    out = []
+    cores = _usable_cores()
+
+    def entry(workload, dt, steps, npix, km, roof, match, **more):
+        e = {'workload': workload, 'ms': dt / steps * 1e3, 'Mpx_per_s': npix * steps / dt / 1e6,
+             'kernels_ms': km, 'roofline': roof, 'matches_oracle_on_sample': match}
+        e.update(more)
+        out.append(e)
+
+    # -- OmnibusTest at the thresholds users actually pass: the reference default and the tutorial's
+    a = main.a
+    for alpha in (0.01, 1e-4):
+        fn = lambda: kernels.change_detection(*main.stack, alpha=alpha, n=a.looks)       # noqa: E731
+        dt, km, ch = timed(fn, 5, 2, barrier)
+        res = checks.omnibus_sample(main.stack, ch, alpha, a.looks, nsample=20000, seed=8)
+        dom = max(km, key=km.get)
+        entry('OmnibusTest C2 %dt x %d x %d f32, alpha=%g (dense regime: %.3f of pixels change)'
+              % (main.k, main.rows, main.nx, alpha, res['flagged_fraction']), dt, 5, main.npix, km,
+              roofline(dom, km[dom], main.read_bytes,
+                       note='FP64-issue bound search kernels; bytes = one read of the stack'),
+              res['bad'] == 0, sample=res)
+    del ch
+
+    # -- full-pol C3, config 4's single-GPU share
+    class A:
+        pass
+    a3 = A()
+    a3.__dict__.update(a.__dict__)
+    a3.k, a3.ny, a3.nx, a3.alpha, a3.scaling = 48, 1024, 8192, 0.99, 'weak'
+    w = OmnibusC3(a3, 0, 1, dev)
+    dt, km, ch = timed(w.step, 5, 2, barrier)
+    res = w.check(ch)
+    entry(w.describe(), dt, 5, w.npix, km, roofline(w.dom, km[w.dom], w.alg_bytes), res['bad'] == 0,
+          sample=res)
+    del w, ch
+    _free()
+
+    # -- boxcar 3x3 (the multilooking step in front of the test), 24t x 4096 x 4096
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.rand((24, 4096, 4096), generator=g, device=dev) + 0.5
+    y = torch.empty_like(x)
+    for wdt in (3, 5):
+        kern = np.ones((1, wdt, wdt)) / float(wdt * wdt)
+        dt, km, _ = timed(lambda: kernels.convolve(x, kern, out=y), 5, 2, barrier)
+        res = checks.convolve_bands(x, y, kern[0], [(0, 40), (2030, 2070), (4056, 4096)], [0, 23])
+        dom = max(km, key=km.get)
+        e = dict(sample=res)
+        if wdt == 5:
+            crop = np.ascontiguousarray(x[:, :1024, :1024].cpu().numpy())
+            t0 = time.perf_counter()
+            O.convolve_reflect_mt(crop, kern, njobs=cores)
+            dtc = time.perf_counter() - t0
+            e['cpu_baseline'] = {'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
+                                 'kind': 'port', 'sample': '24 x 1024 x 1024 crop, %.2f s' % dtc}
+        entry('BoxcarFilter %dx%d on 24t x 4096 x 4096 f32 (scipy.ndimage.convolve arithmetic)'
+              % (wdt, wdt), dt, 5, x.numel(), km, roofline(dom, km[dom], 8 * x.numel()),
+              res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
+    del x, y
+    _free()
+
+    # -- non-local means, BASELINE config 3: 7x7 patch / 21x21 search, 12t x 4096 x 4096
+    k, ny, nx = 12, 4096, 4096
+    x = torch.empty((1, k, ny, nx), device=dev)
+    for t in range(k):
+        u = torch.rand((4, ny, nx), generator=g, device=dev)
+        x[0, t] = -0.25 * torch.log(u).sum(dim=0)              # Gamma(4, 0.25)
+    y = torch.empty_like(x)
+    r, f = (0, 10, 10), (0, 3, 3)
+    for pm in (0, 1):
+        steps = 5 if pm == 0 else 2
+        fn = lambda: kernels.pixelwise_nlmeans_3d(x.permute(2, 3, 1, 0), y.permute(2, 3, 1, 0),    # noqa: E731
+                                                  (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, patch_mode=pm)
+        dt, km, _ = timed(fn, steps, 1, barrier)
+        res = checks.nlmeans_crops(x, y, r, f, 0.5, 0.5, -1, pm, [(2040, 3000), (0, 0)], size=(6, 48))
+        dom = max(km, key=km.get)
+        nq = 21 * 21 - 1
+        flop = x.numel() * nq * (49 * 3 + 8) if pm else x.numel() * nq * 2
+        e = dict(sample=res, TFLOPs_naive_formula=flop / (dt / steps) / 1e12)
+        if pm == 1:
+            crop = np.ascontiguousarray(x[:, :1, :160, :160].permute(2, 3, 1, 0).cpu().numpy())
+            o = np.empty_like(crop)
+            t0 = time.perf_counter()
+            O.pixelwise_nlmeans_3d(crop, o, (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, njobs=cores, patch_mode=1)
+            dtc = time.perf_counter() - t0
+            e['cpu_baseline'] = {'value': 160 * 160 / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
+                                 'kind': 'port', 'sample': '160 x 160 crop of one date, %.2f s' % dtc}
+        entry('NLMeansFilter 7x7 patch / 21x21 search on 12t x 4096 x 4096 f32, patch distances %s'
+              % ('as compiled (reference: window mean)' if pm == 0 else 'signed (true patch distances)'),
+              dt, steps, x.numel(), km,
+              roofline(dom, km[dom], 8 * x.numel(),
+                       note='VALU/LDS-bound: HBM traffic is 8 B per px.t, the fraction of HBM peak is '
+                            'reported for completeness'),
+              res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
+    del x, y
+    _free()
+
+    # -- the tutorial pipeline, config 5's single-GPU share
+    ap = A()
+    ap.__dict__.update(a.__dict__)
+    ap.k, ap.ny, ap.nx, ap.alpha, ap.scaling, ap.patch_mode = 24, 2048, 16384, TUT['alpha'], 'weak', 0
+    w = Pipeline(ap, 0, 1, dev)
+    dt, km, ch = timed(w.step, 3, 1, barrier)
+    res = w.check(ch)
+    entry(w.describe(), dt, 3, w.npix, km, roofline(w.dom, km[w.dom], w.alg_bytes),
+          res['bad'] == 0 and res['change_bad'] == 0, sample=res)
+    del w, ch
+    _free()
+    return out
 
 
 def main():
@@ -111,87 +449,62 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from nd_amd import _lib, kernels, synth
-
-    k, ny, nx = args.k, args.ny, args.nx
-    # rank r owns rows [r*ny, (r+1)*ny) of the (world*ny) x nx raster
-    stack = synth.wishart_c2_stack(k, ny, nx, looks=args.looks, seed=1234 + rank, device=dev,
-                                   change_frac=args.change_frac)
-    torch.cuda.synchronize()
-
-    def step():
-        return kernels.change_detection(stack[0], stack[1], stack[2], stack[3],
-                                        alpha=args.alpha, n=args.looks,
-                                        dims=('time', 'y', 'x'))
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    _lib.timing_enable(2 * (args.steps + args.warmup) + 8)
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    _lib.timing_collect()          # drop the warm-up launches; the events themselves are reused
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    kt = _lib.timing_collect()
-    _lib.timing_enable(0)
+    w = WORKLOADS[args.workload](args, rank, world, dev)
+    torch.cuda.synchronize()
+    dt, avg, out = timed(w.step, args.steps, args.warmup, barrier)
 
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
-    npix = ny * nx
-    value = world * npix * args.steps / dt / 1e6
+        tot = torch.tensor([w.npix], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_px = float(tot.item())
+    else:
+        total_px = float(w.npix)
+    value = total_px * args.steps / dt / 1e6
     flagged = float((out.sum(dim=2) > 0).float().mean().item())
 
     if rank == 0:
-        by = {}
-        for name, ms in kt:
-            by.setdefault(name, []).append(ms)
-        avg = {n: sum(v) / len(v) for n, v in by.items()}
-        dom = 'omnibus_c2_global'
-        alg_bytes = npix * k * 4 * stack.element_size()        # 384 B/px at k=24 f32
-        achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9
+        key = (w.name, w.k, args.ny, w.nx, args.alpha)
+        traffic, source = PROFILED_TRAFFIC.get(key, (None, None)) if world == 1 else (None, None)
+        if args.traffic_bytes is not None:
+            traffic, source = args.traffic_bytes, '--traffic-bytes'
         res = {
-            'metric': 'Mpixels/s OmnibusTest dual-pol %dt x %d x %d' % (k, ny, nx),
-            'value': value, 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32',
-            'data': 'synthetic',
+            'metric': w.metric(), 'value': value, 'unit': 'Mpixels/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
             'config': {
-                'workload': 'OmnibusTest dual-pol C2, synthetic %dt x %d x %d float32 per GPU '
-                            '(BASELINE.json configs[1]), n=%d looks, alpha=%g, %.3g of pixels '
-                            'with a x4 step; inputs resident in HBM'
-                            % (k, ny, nx, args.looks, args.alpha, args.change_frac),
+                'workload': w.describe(),
                 'arithmetic': 'float32 planes and running sums; float64 product of determinants, '
                               'logs and chi-square pair (the reference\'s rounding points)',
                 'flagged_pixel_fraction': flagged,
-                'sharding': 'y-tiles, one per rank, no collective',
+                'sharding': 'rows [%d, %d) of %d on rank 0; tiles.row_partition over %d rank(s); %s'
+                            % (w.r0, w.r1, w.global_ny, world,
+                               'no collective' if w.name != 'pipeline' or world == 1 else
+                               'one point-to-point halo exchange per step'),
             },
             'kernels_ms': avg,
-            'roofline': {
-                'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'algorithmic_bytes_per_launch': alg_bytes,
-                'traffic': args.traffic_bytes if args.traffic_bytes is not None else
-                MEASURED_TRAFFIC.get((k, ny, nx, args.alpha, args.change_frac)),
-            },
+            'roofline': roofline(w.dom, avg[w.dom], w.alg_bytes, traffic=traffic,
+                                 traffic_source=source,
+                                 note='algorithmic bytes = planes read once + change map written once'
+                                 if w.name != 'pipeline' else 'algorithmic bytes = filter input + output'),
         }
-        if world == 1 and args.cpu_rows > 0:
-            cb, ch_cpu = cpu_baseline(stack, args, args.cpu_rows)
-            rows = ch_cpu.shape[0]
-            same = bool((out[:rows].cpu().numpy() == ch_cpu).all())
-            cb['gpu_matches_cpu_on_sample'] = same
-            res['cpu_baseline'] = cb
+        if world == 1 and w.name == 'omnibus':
+            res['roofline']['achieved_read_only'] = w.read_bytes / (avg[w.dom] * 1e-3) / 1e9
+            if args.cpu_rows > 0:
+                res['cpu_baseline'] = cpu_baseline_omnibus(w, out)
+            if not args.no_extra:
+                res['extra'] = extras(w, barrier, dev)
+        elif world == 1:
+            res['matches_oracle_on_sample'] = w.check(out)
         print(json.dumps(res))
         sys.stdout.flush()
     if dist is not None:

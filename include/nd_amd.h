@@ -253,10 +253,13 @@ int nd_amd_relayout_pixel_major(const void *in, void *out, int dtype,
  * Per-kernel timing with HIP events recorded on the caller's stream
  * (bench.py's roofline figures).  enable(capacity) pre-creates the events;
  * collect() synchronises on them and returns (kernel id, milliseconds) pairs
- * in launch order, then resets.  enable(0) turns timing off.
+ * in launch order, then resets.  enable(0) turns timing off.  Launches beyond
+ * the capacity are not timed; timing_dropped() says how many that were since
+ * the last collect().
  * ---------------------------------------------------------------------- */
 int nd_amd_timing_enable(int capacity);
 int nd_amd_timing_collect(int32_t *kernel_ids, float *ms, int max_n, int *n_out);
+int nd_amd_timing_dropped(void);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,42 @@ def is_complex(ds):
     return bool(np.any([iscomplexobj(v.values) for v in ds.data_vars.values()]))
 
 
+def _map_values(obj, fn):
+    """A shallow copy of an xr_lite Dataset / DataArray with `fn` applied to every variable's
+    values (xarray objects hold numpy arrays only and are returned unchanged)."""
+    if namespace(obj) is not xr_lite:
+        return obj
+    if isinstance(obj, xr_lite.DataArray):
+        return xr_lite.DataArray(fn(obj.values), obj.dims, obj.coords, obj.attrs, obj.name)
+    out = obj.copy(deep=False)
+    for name in list(obj.data_vars):
+        da = obj[name]
+        out[name] = (tuple(da.dims), fn(da.values), da.attrs)
+    return out
+
+
+def home_device(obj):
+    """The device of the first device-resident variable of `obj`, None when all data is on the host."""
+    if torch is None or namespace(obj) is not xr_lite:
+        return None
+    vals = [obj.values] if isinstance(obj, xr_lite.DataArray) else [v.values for v in obj.data_vars.values()]
+    for v in vals:
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+            return v.device
+    return None
+
+
+def to_device(obj, device):
+    """Device-resident variables of `obj` moved to `device` (peer-to-peer copy when they live on
+    another GPU); host arrays stay where they are (the algorithms upload them themselves, to the
+    current device)."""
+    def move(v):
+        if torch is not None and isinstance(v, torch.Tensor) and v.is_cuda and v.device != device:
+            return v.to(device, non_blocking=True)
+        return v
+    return _map_values(obj, move)
+
+
 def split_bounds(n, chunks, buffer=0):
     """Index arithmetic of xr_split (nd/utils.py:305-310): chunk i covers
     [max(i*cs - buffer, 0), min((i+1)*cs + buffer, n)) with cs = ceil(n / chunks)."""

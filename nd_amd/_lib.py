@@ -27,7 +27,7 @@ SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_nlmeans3d',
            'nd_amd_relayout_planar', 'nd_amd_relayout_planar_complex',
            'nd_amd_relayout_pixel_major',
-           'nd_amd_timing_enable', 'nd_amd_timing_collect')
+           'nd_amd_timing_enable', 'nd_amd_timing_collect', 'nd_amd_timing_dropped')
 
 _lib = None
 
@@ -91,6 +91,8 @@ def lib():
     L.nd_amd_timing_collect.restype = i32
     L.nd_amd_timing_collect.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_float), i32,
                                         C.POINTER(i32)]
+    L.nd_amd_timing_dropped.restype = i32
+    L.nd_amd_timing_dropped.argtypes = []
     v = L.nd_amd_abi_version()
     if v != 1:
         raise ImportError('nd_amd: libnd_amd.so has ABI version %d, expected 1' % v)
@@ -113,6 +115,11 @@ def u32_array(values):
 
 def timing_enable(capacity):
     check(lib().nd_amd_timing_enable(int(capacity)))
+
+
+def timing_dropped():
+    """launches that found the timing ring full since the last call (0 = every launch was timed)."""
+    return int(lib().nd_amd_timing_dropped())
 
 
 def timing_collect(max_n=65536):

@@ -3,11 +3,15 @@ nd_amd/algorithm.py -- the plugin API of the reference, re-stated (nd/algorithm.
 
   Algorithm       abstract `apply(ds)`, overridable `_buffer(dim)` and `_parallel_dimension(ds)`
                   (nd/algorithm.py:15-35)
-  parallelize     decorator adding the keyword-only `njobs` (nd/algorithm.py:38-105).  The
-                  reference forks `njobs` processes over halo-buffered chunks of one dimension
-                  and concatenates; here the same chunks (same arithmetic: _adapter.split_bounds)
-                  are processed one after another on the GPU -- a GPU launch already covers the
-                  whole raster, the chunking is kept so that `njobs` means what it meant.
+  parallelize     decorator adding the keyword-only `njobs` (nd/algorithm.py:38-105) and
+                  `devices`.  The reference forks `njobs` processes over halo-buffered chunks of
+                  one dimension and concatenates.  Here the same chunks (same arithmetic:
+                  _adapter.split_bounds) go to the GPUs: with several devices (`devices=[0, 1, ..]`,
+                  or `njobs > 1` on a machine that has more than one) chunk i runs on device
+                  i mod n, one host thread and one HIP stream per device, halos included in the
+                  chunk exactly like xr_split's buffer; with one device the chunks run one after
+                  another on it (a GPU launch already covers the whole raster, the chunking is
+                  kept so that `njobs` means what it meant).
   wrap_algorithm  class -> function `(ds, *init_args, **init_kwargs)` (nd/algorithm.py:108-198)
 """
 import inspect
@@ -44,8 +48,34 @@ def _sorted_parameters(parameters):
     return out
 
 
-def parallel(fn, dim=None, chunks=None, buffer=0):
-    """Chunked application of `fn` along `dim` with halo `buffer` (nd/utils.py:343-401)."""
+def resolve_devices(devices=None, njobs=1):
+    """The list of torch devices a chunked run spreads over, or None for "the current device only".
+    `devices`: explicit list of device indices / torch.device objects.  Without it, `njobs` workers
+    map onto the visible GPUs when there is more than one (njobs = -1: all of them) -- the GPU
+    counterpart of the reference's process pool (nd/algorithm.py:57-68)."""
+    import torch
+    if devices is not None:
+        devs = [torch.device('cuda', d) if isinstance(d, int) else torch.device(d) for d in devices]
+        if not devs:
+            raise ValueError('`devices` must name at least one device')
+        for d in devs:
+            if d.type != 'cuda':
+                raise ValueError('nd_amd computes on ROCm devices only, got %s' % d)
+        return devs
+    if njobs in (0, 1):
+        return None
+    n = torch.cuda.device_count()
+    if n <= 1:
+        return None
+    want = n if njobs == -1 else min(int(njobs), n)
+    return [torch.device('cuda', i) for i in range(want)] if want > 1 else None
+
+
+def parallel(fn, dim=None, chunks=None, buffer=0, devices=None):
+    """Chunked application of `fn` along `dim` with halo `buffer` (nd/utils.py:343-401).
+    devices: list of torch devices; chunk i is processed on devices[i % len(devices)] by one host
+    thread per device (device tensors are moved there peer-to-peer, numpy chunks are uploaded
+    there), and the pieces are merged on the first device (or on the host for numpy data)."""
     if dim is None:
         dim = 'y'
     if chunks is None:
@@ -55,8 +85,29 @@ def parallel(fn, dim=None, chunks=None, buffer=0):
         if dim not in ds.dims:
             raise ValueError("The dataset has no dimension '{}'.".format(dim))
         parts = list(_adapter.xr_split(ds, dim=dim, chunks=chunks, buffer=buffer))
-        output = [fn(part, *args, **kwargs) for part in parts]
-        return _adapter.xr_merge(output, dim=dim, buffer=buffer)
+        if not devices:
+            output = [fn(part, *args, **kwargs) for part in parts]
+            return _adapter.xr_merge(output, dim=dim, buffer=buffer)
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        home = _adapter.home_device(ds)
+
+        def lane(j):
+            # everything chunk-related of one device happens in this thread, on that device's
+            # current stream; torch's current device is per thread
+            dev = devices[j]
+            done = []
+            with torch.cuda.device(dev):
+                for i in range(j, len(parts), len(devices)):
+                    res = fn(_adapter.to_device(parts[i], dev), *args, **kwargs)
+                    done.append((i, res if home is None else _adapter.to_device(res, home)))
+                torch.cuda.current_stream(dev).synchronize()
+            return done
+
+        with ThreadPoolExecutor(max_workers=len(devices)) as pool:
+            results = sorted((r for lst in pool.map(lane, range(len(devices))) for r in lst),
+                             key=lambda ir: ir[0])
+        return _adapter.xr_merge([r for _, r in results], dim=dim, buffer=buffer)
 
     return wrapper
 
@@ -66,26 +117,39 @@ def parallelize(func):
     1 = call `func` on the whole dataset, -1 = one chunk per CPU core, n = n chunks along
     `self._parallel_dimension(ds)`, each extended by `self._buffer(dim)` and trimmed on merge."""
 
-    def run(self, ds, *args, njobs=1, **kwargs):
+    def run(self, ds, *args, njobs=1, devices=None, **kwargs):
         call = partial(func, self)
-        chunks = mp.cpu_count() if njobs == -1 else int(njobs)
+        devs = resolve_devices(devices, njobs)
+        chunks = mp.cpu_count() if (njobs == -1 and not devs) else int(njobs)
+        if devs:
+            chunks = max(chunks, len(devs))
+            if chunks % len(devs):
+                chunks += len(devs) - chunks % len(devs)      # equal load per device
         if chunks > 1:
             dim = self._parallel_dimension(ds)
             halo = int(self._buffer(dim))
             # never more chunks than the dimension can carry with its halo
             chunks = max(1, min(chunks, ds.sizes[dim] // (2 * halo + 1)))
             if chunks > 1:
-                return parallel(call, dim=dim, chunks=chunks, buffer=halo)(ds, *args, **kwargs)
+                return parallel(call, dim=dim, chunks=chunks, buffer=halo,
+                                devices=devs)(ds, *args, **kwargs)
+        if devs:      # a single chunk after all: run it on the first listed device
+            import torch
+            with torch.cuda.device(devs[0]):
+                return call(ds, *args, **kwargs)
         return call(ds, *args, **kwargs)
 
     own = inspect.signature(func)
-    njobs_param = inspect.signature(run).parameters['njobs']
+    extra = tuple(inspect.signature(run).parameters[n] for n in ('njobs', 'devices'))
     run.__signature__ = own.replace(
-        parameters=_sorted_parameters(tuple(own.parameters.values()) + (njobs_param,)))
+        parameters=_sorted_parameters(tuple(own.parameters.values()) + extra))
     run.__doc__ = (func.__doc__ or '').rstrip() + (
         '\n        njobs : int, optional\n'
         '            Number of chunks to process separately (halo-buffered, merged afterwards).\n'
-        '            -1 uses the number of available cores; 1 disables chunking (default).\n')
+        '            -1 uses the number of available cores; 1 disables chunking (default).\n'
+        '        devices : list, optional\n'
+        '            ROCm devices to spread the chunks over (default: the current device; with\n'
+        '            njobs > 1 and several visible GPUs, the first njobs of them).\n')
     run.__name__ = getattr(func, '__name__', 'apply')
     return run
 

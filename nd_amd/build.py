@@ -49,7 +49,7 @@ def _build(force, verbose, extra_flags, LIB, OBJ):
     os.makedirs(OBJ, exist_ok=True)
     dep_mtime = max(os.path.getmtime(p) for p in _deps())
     objs = []
-    rebuilt = False
+    rebuilt = []
     procs = []
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
@@ -61,15 +61,21 @@ def _build(force, verbose, extra_flags, LIB, OBJ):
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
-        rebuilt = True
+        rebuilt.append(os.path.basename(src))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on %s' % src)
+    linked = False
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+        linked = True
+    # say what this call actually did: objects are reused by mtime, so "nothing compiled" is a
+    # legitimate outcome that the build log should show
+    print('nd_amd.build: hipcc --offload-arch=%s rebuilt=%s linked=%s lib=%s'
+          % (ARCH, rebuilt, linked, os.path.relpath(LIB)))
     return LIB
 
 

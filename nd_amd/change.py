@@ -83,11 +83,10 @@ def _multilook_planes(stack, ml):
     return kernels.convolve(stack, kernel, out=out)
 
 
-def _on_device(ds, device):
+def _on_device(ds, device, wanted):
     """The covariance variables of a host dataset as device tensors in their own layout (complex
     C12 included): one plain upload each -- re-ordering 6 GB on the host would take seconds, on the
     device it is a 3 ms transpose (nd_amd_relayout_planar)."""
-    wanted = set(_VARS3) | _COMPLEX
     out = xr_lite.Dataset()
     for name in ds.data_vars:
         if name in wanted:
@@ -96,15 +95,21 @@ def _on_device(ds, device):
     return out
 
 
-def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None, stats=False):
+def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None, stats=False,
+                              pol='dual'):
+    if pol not in ('dual', 'full'):
+        raise ValueError("pol must be 'dual' (C11, C12, C22: the reference's test) or 'full'")
     ns = _adapter.namespace(ds)
     ds.persist() if hasattr(ds, 'persist') else None
-    present = [v for v in list(ds.data_vars) if v in set(_VARS3) | _COMPLEX]
-    full_pol = 'C33' in present            # 3 x 3 covariance: the extension kernel
+    full_pol = pol == 'full'               # 3 x 3 covariance: the extension kernel, opt-in
+    # like nd/change.py:66 the dual-pol test picks C11 / C12 / C22 and ignores anything else the
+    # dataset carries (a C33 next to them changes nothing)
+    wanted = (set(_VARS3) | _COMPLEX) if full_pol else (set(_VARS) | {'C12'})
+    present = [v for v in list(ds.data_vars) if v in wanted]
     host = not any(_device.is_tensor(ds[v].values) for v in present)
     dev = _device.device_of(*[ds[v].values for v in present], device=device)
     with torch.cuda.device(dev):
-        ds_m = disassemble_complex(_on_device(ds, dev) if host else ds)
+        ds_m = disassemble_complex(_on_device(ds, dev, wanted) if host else ds)
         res = None
         if not full_pol and ml is None and all(v in ds_m.data_vars for v in _VARS):
             # the reference's own layout on the device (numpy inputs were uploaded as they are):
@@ -148,31 +153,54 @@ class OmnibusTest(ChangeDetection):
     alpha   threshold on the test's probability: a change is declared where P > alpha
             (nd/_change.pyx:239-249; default 0.01, the reference's tests use 0.9)
     device  optional torch device for host inputs (default: the current ROCm device)
-    njobs   accepted and stored like in the reference; one GPU launch covers the whole raster
+    njobs   the reference hands this to its OpenMP loop over image rows (nd/_change.pyx:280); here
+            the rows are cut into `njobs` blocks (plus ml // 2 halo rows when multilooking) that
+            are spread over the visible GPUs -- one block per GPU launch; with a single GPU the
+            whole raster is one launch whatever `njobs` says
+    devices explicit list of ROCm devices to spread the row blocks over
+    pol     'dual' (default): the reference's 2 x 2 test on C11, C12, C22, whatever else the
+            dataset holds.  'full': the same test with p = 3 on C11, C22, C33, C12, C13, C23 -- an
+            extension without a reference counterpart, hence opt-in.
 
-    `apply(ds)` returns the boolean DataArray 'change' with dimensions ('y', 'x', 'time').
-    A dataset that also carries C33 (and C13, C23) is treated as full-pol 3 x 3 data: same test
-    with p = 3 (an extension; the reference is dual-pol only)."""
+    `apply(ds)` returns the boolean DataArray 'change' with dimensions ('y', 'x', 'time')."""
 
     def __init__(self, ml=None, n=1, alpha=0.01, *args, **kwargs):
         _lib.lib()          # ImportError when libnd_amd.so is missing, like nd/change.py:106-108
         self.device = kwargs.pop('device', None)
+        self.devices = kwargs.pop('devices', None)
+        self.pol = kwargs.pop('pol', 'dual')
         ChangeDetection.__init__(self, *args, **kwargs)
         self.ml, self.n, self.alpha = ml, n, alpha
 
+    def _buffer(self, dim):
+        return int(self.ml) // 2 if (self.ml is not None and dim in ('y', 'x')) else 0
+
     def apply(self, ds):
-        return _omnibus_change_detection(ds, alpha=self.alpha, ml=self.ml, n=self.n,
-                                         njobs=self.njobs, device=self.device)
+        from .algorithm import parallel, resolve_devices
+        run = lambda part: _omnibus_change_detection(                      # noqa: E731
+            part, alpha=self.alpha, ml=self.ml, n=self.n, njobs=self.njobs, device=self.device,
+            pol=self.pol)
+        devs = resolve_devices(self.devices, self.njobs) if self.device is None else None
+        if devs and 'y' in ds.dims:
+            halo = self._buffer('y')
+            chunks = max(len(devs), int(self.njobs) if self.njobs and self.njobs > 1 else 1)
+            chunks -= chunks % len(devs)
+            chunks = max(1, min(chunks, ds.sizes['y'] // (2 * halo + 1)))
+            if chunks > 1:
+                return parallel(run, dim='y', chunks=chunks, buffer=halo, devices=devs)(ds)
+            with torch.cuda.device(devs[0]):
+                return run(ds)
+        return run(ds)
 
 
 omnibus = wrap_algorithm(OmnibusTest, 'omnibus')
 
 
-def omnibus_statistics(ds, ml=None, n=1, alpha=0.01, device=None):
+def omnibus_statistics(ds, ml=None, n=1, alpha=0.01, device=None, pol='dual'):
     """change map plus the rasters the reference only computes per pixel: the test statistic
     z = -2 rho ln Q and the probability P of the global test over the whole series
     (nd/_change.pyx:46-77, 133-151).  Returns (change, z, P)."""
-    return _omnibus_change_detection(ds, alpha=alpha, ml=ml, n=n, device=device, stats=True)
+    return _omnibus_change_detection(ds, alpha=alpha, ml=ml, n=n, device=device, stats=True, pol=pol)
 
 
 def change_count(change):

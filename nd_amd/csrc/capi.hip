@@ -23,6 +23,7 @@ struct TimingState {
     bool enabled = false;
     int capacity = 0;
     int used = 0;
+    int dropped = 0;
     std::vector<hipEvent_t> start, stop;
     std::vector<int32_t> ids;
 };
@@ -33,7 +34,11 @@ KernelTimer::KernelTimer(int kernel_id, hipStream_t s) : slot(-1), stream(s)
     TimingState &t = g_timing;
     if (!t.enabled) return;
     std::lock_guard<std::mutex> lk(t.mu);
-    if (!t.enabled || t.used >= t.capacity) return;
+    if (!t.enabled) return;
+    if (t.used >= t.capacity) {
+        t.dropped++;
+        return;
+    }
     slot = t.used++;
     t.ids[slot] = kernel_id;
     (void)hipEventRecord(t.start[slot], stream);
@@ -65,6 +70,7 @@ extern "C" int nd_amd_timing_enable(int capacity)
     t.stop.clear();
     t.ids.clear();
     t.used = 0;
+    t.dropped = 0;
     t.capacity = 0;
     t.enabled = false;
     if (capacity <= 0) return ND_AMD_OK;
@@ -95,4 +101,13 @@ extern "C" int nd_amd_timing_collect(int32_t *kernel_ids, float *ms, int max_n, 
     if (n_out) *n_out = n;
     t.used = 0;
     return ND_AMD_OK;
+}
+
+extern "C" int nd_amd_timing_dropped(void)
+{
+    TimingState &t = g_timing;
+    std::lock_guard<std::mutex> lk(t.mu);
+    const int d = t.dropped;
+    t.dropped = 0;
+    return d;
 }

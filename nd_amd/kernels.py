@@ -113,8 +113,10 @@ def change_detection_pixel_major(c11, c12re, c12im, c22, alpha, n=1, stats=False
         ids.append(_pixel_major_stride(t))
         if ids[-1] is None:
             return None
-    if c12im.data_ptr() == c12re.data_ptr() + c12re.element_size():
-        ids[1] = ids[2] = 2                   # the halves of one interleaved tensor (any size)
+    # The date strides come from the tensors' own strides only.  (Two views one element apart are
+    # NOT proof of an interleaved complex tensor: buf[:-1] and buf[1:] of a real buffer look the
+    # same.  The library pairs the two C12 reads itself when both strides are 2 and the pointers
+    # are adjacent.)
     if ids[1] != ids[2]:
         return None
     dev = c11.device

@@ -13,6 +13,11 @@ extra rows from each neighbour (kernel//2 for convolution, r+f for non-local mea
                     send/recv pairs batched in one group -- each pair rides its own xGMI link),
                     then the kernel runs on tile+halo; rows at the GLOBAL top/bottom use the
                     kernel's own reflection.  No all-reduce / all-gather is involved.
+
+Memory: a rank's block lives in a `RowShard`, a buffer that already has room for the neighbours'
+rows in front of and behind the block's own rows (288 GB of HBM make the two margins free).  The
+exchange receives straight into those margins; the block itself is never copied, and every size
+in the exchange follows from `row_partition` arithmetic -- no size collective, no host sync.
 """
 import math
 
@@ -22,105 +27,222 @@ import torch.distributed as dist
 
 def row_partition(n, parts):
     """[(r0, r1)] per part, xr_split's chunking without the buffer (nd/utils.py:305-310)."""
-    cs = int(math.ceil(n / parts))
+    cs = int(math.ceil(n / parts)) if parts > 0 else n
     return [(min(i * cs, n), min((i + 1) * cs, n)) for i in range(parts)]
 
 
+def _world_rank(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _peer(group, group_rank):
+    """P2POp wants GLOBAL ranks; `group_rank` is a rank inside `group`."""
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
 def my_rows(n, group=None):
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = _world_rank(group)
     return row_partition(n, world)[rank]
 
 
-def exchange_halo(core, halo, dim, group=None):
-    """Extend this rank's row block by up to `halo` rows of each neighbour.
-
-    core : tensor whose axis `dim` holds this rank's rows (ranks are in row order).
-    Returns (ext, lo, hi): `ext` = [rows from rank-1 | core | rows from rank+1] along `dim`,
-    `lo`/`hi` = how many rows were added in front / behind (0 at the global edges).
-    """
-    if halo <= 0 or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return core, 0, 0
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    n_local = core.shape[dim]
-    # every rank must be able to serve a full halo (the reference's chunks overlap by `buffer`
-    # in the same way); sizes are agreed on with one small all-gather of row counts
-    counts = [torch.zeros(1, dtype=torch.int64, device=core.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=core.device),
-                    group=group)
-    counts = [int(c.item()) for c in counts]
-    lo = min(halo, counts[rank - 1]) if rank > 0 else 0
-    hi = min(halo, counts[rank + 1]) if rank < world - 1 else 0
-    send_up = min(halo, n_local) if rank > 0 else 0            # my first rows go to rank-1
-    send_dn = min(halo, n_local) if rank < world - 1 else 0    # my last rows go to rank+1
-    if (rank > 0 and counts[rank - 1] < halo) or (rank < world - 1 and counts[rank + 1] < halo) \
-            or (n_local < halo and world > 1):
+def check_partition(global_n, world, halo):
+    """Every block must be able to serve a full halo to its neighbours (the reference's chunks
+    overlap by `buffer` in the same way).  Pure arithmetic on (global_n, world, halo): every rank
+    reaches the same verdict, so either all of them raise here or none does -- before any
+    point-to-point operation is posted (a rank raising alone would leave its neighbours waiting)."""
+    if world <= 1 or halo <= 0:
+        return
+    counts = [b - a for a, b in row_partition(global_n, world)]
+    if any(c < halo for c in counts):
         raise ValueError('row blocks (%s rows) are smaller than the halo (%d): use fewer ranks'
                          % (counts, halo))
 
-    def rows(t, a, b):
-        idx = [slice(None)] * t.dim()
-        idx[dim] = slice(a, b)
-        return t[tuple(idx)]
 
-    ops = []
-    recv_lo = recv_hi = None
-    if rank > 0:
-        shape = list(core.shape)
-        shape[dim] = lo
-        recv_lo = torch.empty(shape, dtype=core.dtype, device=core.device)
-        ops.append(dist.P2POp(dist.isend, rows(core, 0, send_up).contiguous(), rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, recv_lo, rank - 1, group))
+def halo_extent(global_n, halo, rank, world):
+    """(r0, r1, lo, hi): this rank's rows and how many halo rows it holds in front / behind
+    (none at the raster's own edges, where the kernels reflect)."""
+    r0, r1 = row_partition(global_n, world)[rank]
+    lo = halo if (rank > 0 and halo > 0) else 0
+    hi = halo if (rank < world - 1 and halo > 0) else 0
+    return r0, r1, lo, hi
+
+
+def _rows(t, dim, a, b):
+    idx = [slice(None)] * t.dim()
+    idx[dim] = slice(a, b)
+    return t[tuple(idx)]
+
+
+class RowShard:
+    """Rows [r0, r1) of a raster whose row axis is `dim` of `ext`, stored with `lo` / `hi` margin
+    rows for the neighbours' halos: `ext` = rows [r0 - lo, r1 + hi) of the whole raster once
+    `exchange_halo_` has run, `core` = the view of the block's own rows."""
+
+    __slots__ = ('ext', 'dim', 'lo', 'hi', 'r0', 'r1', 'global_n', 'halo')
+
+    def __init__(self, ext, dim, lo, hi, r0, r1, global_n, halo):
+        self.ext, self.dim, self.lo, self.hi = ext, dim, lo, hi
+        self.r0, self.r1, self.global_n, self.halo = r0, r1, global_n, halo
+        if ext.shape[dim] != (r1 - r0) + lo + hi:
+            raise ValueError('shard buffer has %d rows, expected %d + %d + %d'
+                             % (ext.shape[dim], lo, r1 - r0, hi))
+
+    @property
+    def core(self):
+        return _rows(self.ext, self.dim, self.lo, self.lo + (self.r1 - self.r0))
+
+    @property
+    def n_local(self):
+        return self.r1 - self.r0
+
+    def like(self, ext):
+        """A shard with the same geometry around another buffer (a filter's output)."""
+        return RowShard(ext, self.dim, self.lo, self.hi, self.r0, self.r1, self.global_n, self.halo)
+
+
+def empty_shard(lead, global_ny, nx, halo, device, dtype=torch.float32, group=None, rank=None,
+                world=None):
+    """Uninitialised shard of a planar raster (*lead, y, x) for this rank (or an explicit
+    rank / world): rows [r0 - lo, r1 + hi), x fastest.  With two leading axes (variable, date) the
+    date planes get nd_amd.synth's padding, which the streaming kernels like."""
+    from . import synth
+    if world is None or rank is None:
+        world, rank = _world_rank(group)
+    check_partition(global_ny, world, halo)
+    r0, r1, lo, hi = halo_extent(global_ny, halo, rank, world)
+    lead = tuple(int(v) for v in lead)
+    rows = (r1 - r0) + lo + hi
+    if len(lead) == 2:
+        ext = synth.empty_stack(lead[0], lead[1], rows, nx, device, dtype)
+    else:
+        ext = torch.empty(lead + (rows, nx), dtype=dtype, device=device)
+    return RowShard(ext, len(lead), lo, hi, r0, r1, global_ny, halo)
+
+
+def shard_of(full, halo, dim, rank, world, device=None):
+    """The shard (margins already filled) a rank would hold of the whole raster `full`: the
+    scatter form, for data that starts in one place -- xr_split with its buffer."""
+    n = full.shape[dim]
+    check_partition(n, world, halo)
+    r0, r1, lo, hi = halo_extent(n, halo, rank, world)
+    ext = _rows(full, dim, r0 - lo, r1 + hi)
+    if device is not None:
+        ext = ext.to(device)
+    return RowShard(ext, dim, lo, hi, r0, r1, n, halo)
+
+
+def exchange_halo_(shard, group=None):
+    """Fill the margins of `shard` with the neighbours' edge rows, in place.  One batched group
+    of point-to-point operations (two sends, two receives at most); only halo-sized pieces are
+    ever packed or unpacked, the block itself stays where it is."""
+    world, rank = _world_rank(group)
+    check_partition(shard.global_n, world, shard.halo)        # identical verdict on every rank
+    if world == 1 or shard.halo <= 0:
+        return shard
+    ext, dim, lo, hi, n = shard.ext, shard.dim, shard.lo, shard.hi, shard.n_local
+    halo = shard.halo
+    ops, landing = [], []
+
+    def recv_into(view, peer):
+        buf = view if view.is_contiguous() else torch.empty(view.shape, dtype=view.dtype,
+                                                            device=view.device)
+        ops.append(dist.P2POp(dist.irecv, buf, _peer(group, peer), group))
+        if buf is not view:
+            landing.append((view, buf))
+
+    if rank > 0:                                   # my first rows go up, rank-1's last rows come in
+        ops.append(dist.P2POp(dist.isend, _rows(ext, dim, lo, lo + halo).contiguous(),
+                              _peer(group, rank - 1), group))
+        recv_into(_rows(ext, dim, 0, lo), rank - 1)
     if rank < world - 1:
-        shape = list(core.shape)
-        shape[dim] = hi
-        recv_hi = torch.empty(shape, dtype=core.dtype, device=core.device)
-        ops.append(dist.P2POp(dist.isend, rows(core, n_local - send_dn, n_local).contiguous(),
-                              rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, recv_hi, rank + 1, group))
+        ops.append(dist.P2POp(dist.isend, _rows(ext, dim, lo + n - halo, lo + n).contiguous(),
+                              _peer(group, rank + 1), group))
+        recv_into(_rows(ext, dim, lo + n, lo + n + hi), rank + 1)
     for req in dist.batch_isend_irecv(ops):
         req.wait()
-    parts = [p for p in (recv_lo, core, recv_hi) if p is not None]
-    return torch.cat(parts, dim=dim), lo, hi
+    for view, buf in landing:
+        view.copy_(buf)
+    return shard
+
+
+def exchange_halo(core, halo, dim, global_n=None, group=None):
+    """Convenience form for a block that was NOT allocated with margins: builds the shard (one
+    copy of the block into it), exchanges, returns (ext, lo, hi).  Pipelines should allocate with
+    `empty_shard` / `shard_of` instead and call `exchange_halo_`.  `global_n` = rows of the whole
+    raster (None: a single process, or the block is the whole raster)."""
+    world, rank = _world_rank(group)
+    if halo <= 0 or world == 1:
+        return core, 0, 0
+    if global_n is None:
+        raise ValueError('exchange_halo needs the global row count to size the neighbours\' blocks')
+    check_partition(global_n, world, halo)
+    r0, r1, lo, hi = halo_extent(global_n, halo, rank, world)
+    if core.shape[dim] != r1 - r0:
+        raise ValueError('this rank holds %d rows, the partition of %d rows over %d ranks gives it %d'
+                         % (core.shape[dim], global_n, world, r1 - r0))
+    shape = list(core.shape)
+    shape[dim] = (r1 - r0) + lo + hi
+    ext = torch.empty(shape, dtype=core.dtype, device=core.device)
+    shard = RowShard(ext, dim, lo, hi, r0, r1, global_n, halo)
+    shard.core.copy_(core)
+    exchange_halo_(shard, group)
+    return ext, lo, hi
 
 
 def trim(ext, lo, hi, dim):
-    idx = [slice(None)] * ext.dim()
-    idx[dim] = slice(lo, ext.shape[dim] - hi)
-    return ext[tuple(idx)]
+    return _rows(ext, dim, lo, ext.shape[dim] - hi)
 
 
-def filter_rows(fn, core, halo, dim, group=None):
+def filter_rows(fn, core, halo, dim, global_n=None, group=None):
     """Apply `fn` (tile -> filtered tile, reflecting at its own edges) to a row-sharded raster:
-    exchange halos, filter tile+halo, drop the halo rows -- xr_split/xr_merge across GPUs."""
-    ext, lo, hi = exchange_halo(core, halo, dim, group)
+    exchange halos, filter tile+halo, drop the halo rows -- xr_split/xr_merge across GPUs.
+    `core` may be a RowShard (no copy) or a plain block (copied into a shard once)."""
+    if isinstance(core, RowShard):
+        exchange_halo_(core, group)
+        return trim(fn(core.ext), core.lo, core.hi, core.dim)
+    ext, lo, hi = exchange_halo(core, halo, dim, global_n, group)
     return trim(fn(ext), lo, hi, dim)
 
 
-def boxcar_rows(stack, w, group=None):
-    """BoxcarFilter(dims=('y','x'), w) on a row-sharded planar stack (..., y_local, x)."""
+def _boxcar_kernel(ndim, w):
     import numpy as np
+    return np.ones((1,) * (ndim - 2) + (w, w)) / float(w * w)
+
+
+def boxcar_rows(stack, w, global_ny=None, group=None):
+    """BoxcarFilter(dims=('y','x'), w) on a row-sharded planar stack (..., y_local, x): a
+    RowShard, or a plain block together with `global_ny`."""
     from . import kernels
-    k = np.ones((1,) * (stack.dim() - 2) + (w, w)) / float(w * w)
-    if stack.dim() > 4:
+    t = stack.ext if isinstance(stack, RowShard) else stack
+    if t.dim() > 4:
         raise NotImplementedError
-    return filter_rows(lambda t: kernels.convolve(t, k), stack, w // 2, stack.dim() - 2, group)
+    k = _boxcar_kernel(t.dim(), w)
+    return filter_rows(lambda e: kernels.convolve(e, k), stack, w // 2, t.dim() - 2, global_ny, group)
 
 
 def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group=None):
     """NLMeansFilter on a row-sharded planar stack (var, time, y_local, x), joint weights over the
     variables.  r, f: (time, y, x) radii like NLMeansFilter(dims=('time', 'y', 'x')).  The halo
     rows (r_y + f_y) are exchanged once for all variables and dates; reflection happens at the
-    global edges.  With r_time = 0 every date is filtered on its own by the LDS-tiled kernels."""
-    from . import kernels
+    global edges.  With r_time = 0 every date is filtered on its own by the LDS-tiled kernels.
+    `stack`: a RowShard whose halo is r_y + f_y (nothing is copied), or a plain block."""
+    from . import kernels, synth
     rt, ry, rx = (int(v) for v in r)
     ft, fy, fx = (int(v) for v in f)
     halo = ry + fy
-    r0, _ = my_rows(global_ny, group)
-    ext, lo, hi = exchange_halo(stack, halo, 2, group)
+    if isinstance(stack, RowShard):
+        if stack.global_n != global_ny or (stack.halo != halo and _world_rank(group)[0] > 1):
+            raise ValueError('the shard was allocated for %d rows / halo %d, the filter needs %d / %d'
+                             % (stack.global_n, stack.halo, global_ny, halo))
+        shard = exchange_halo_(stack, group)
+        ext, lo, hi, r0 = shard.ext, shard.lo, shard.hi, shard.r0
+    else:
+        r0, _ = my_rows(global_ny, group)
+        ext, lo, hi = exchange_halo(stack, halo, 2, global_ny, group)
     nvar, k, ny_ext, nx = ext.shape
-    out = torch.empty_like(ext)
+    out = synth.empty_stack(nvar, k, ny_ext, nx, ext.device, ext.dtype)
     if rt == 0 and ft == 0:
         # (y, x, time, var) view of planar memory: x contiguous
         kernels.pixelwise_nlmeans_3d(
@@ -139,8 +261,19 @@ def omnibus_rows(stack, alpha, n, stats=False):
     """OmnibusTest on this rank's rows of a planar stack (4, time, y_local, x): per pixel, no
     exchange."""
     from . import kernels
+    if isinstance(stack, RowShard):
+        stack = stack.core
     return kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha, n=n,
                                     dims=('time', 'y', 'x'), stats=stats)
+
+
+def omnibus_c3_rows(stack, alpha, n, stats=False):
+    """Full-pol omnibus on this rank's rows of a planar stack (9, time, y_local, x)."""
+    from . import kernels
+    if isinstance(stack, RowShard):
+        stack = stack.core
+    return kernels.change_detection_c3([stack[c] for c in range(9)], alpha=alpha, n=n,
+                                       dims=('time', 'y', 'x'), stats=stats)
 
 
 def nlmeans_then_omnibus(stack, global_ny, r, f, sigma, h, alpha, n, n_eff=-1, patch_mode=0,

@@ -1,0 +1,162 @@
+"""Two-GPU checks of the tile layer with the REAL HIP kernels and RCCL (skipped on a one-GPU box):
+
+  * torch.distributed over `nccl`, one fresh process per GPU: halo exchange into the shard margins,
+    then boxcar_rows / nlmeans_rows / nlmeans_then_omnibus on tile+halo, against the unsharded
+    result computed by rank 0 on its own GPU -- bit for bit
+    (nd/tests/test_filters_common.py:54-60: njobs=2 == serial, with the real filter);
+  * one process driving two devices: `Filter.apply(ds, devices=[0, 1])` and
+    `OmnibusTest(devices=[0, 1])` == the single-device result (the multi-worker hook of
+    nd/algorithm.py:57-68).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()          # does not initialise the GPU on this image
+
+
+needs2 = pytest.mark.skipif(_ngpu() < 2, reason='needs at least two GPUs')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _nccl_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        from nd_amd import kernels, tiles
+        k, ny, nx = 6, 301, 517                       # odd sizes: unequal blocks, ragged tiles
+        g = torch.Generator().manual_seed(12)
+        full = (torch.rand((4, k, ny, nx), generator=g) + 0.25)
+        full[1] -= 0.75
+        full[2] -= 0.75
+        full[1] *= 0.3
+        full[2] *= 0.3
+        r, f = (1, 3, 3), (1, 1, 1)
+        halo = r[1] + f[1]
+        sh = tiles.empty_shard((4, k), ny, nx, halo, dev)
+        sh.ext.fill_(float('nan'))
+        sh.core.copy_(full[:, :, sh.r0:sh.r1])
+        tiles.exchange_halo_(sh)
+        torch.cuda.synchronize()
+        assert torch.equal(sh.ext.cpu(), full[:, :, sh.r0 - sh.lo:sh.r1 + sh.hi])
+        got_nlm = tiles.nlmeans_rows(sh, ny, r, f, 0.7, 0.9, n_eff=20.0, patch_mode=0)
+        got_nlm1 = tiles.nlmeans_rows(sh, ny, (0, 3, 3), (0, 1, 1), 0.7, 0.9, patch_mode=1)
+        got_ch = tiles.nlmeans_then_omnibus(sh, ny, r, f, 0.7, 0.9, 0.5, 20, n_eff=20.0)
+        shb = tiles.empty_shard((4, k), ny, nx, 2, dev)
+        shb.core.copy_(full[:, :, shb.r0:shb.r1])
+        got_box = tiles.boxcar_rows(shb, 5)
+        torch.cuda.synchronize()
+        # every rank computes the unsharded result on its own GPU and compares its rows
+        whole = full.to(dev)
+        out = torch.empty_like(whole)
+        kernels.pixelwise_nlmeans_3d(whole.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, 0.7, 0.9,
+                                     20.0, patch_mode=0)
+        assert torch.equal(got_nlm, out[:, :, sh.r0:sh.r1])
+        want_ch = kernels.change_detection(out[0], out[1], out[2], out[3], alpha=0.5, n=20)
+        assert torch.equal(got_ch, want_ch[sh.r0:sh.r1])
+        assert int(want_ch.sum()) > 0
+        out1 = torch.empty_like(whole)
+        kernels.pixelwise_nlmeans_3d(whole.permute(2, 3, 1, 0), out1.permute(2, 3, 1, 0), (3, 3, 0),
+                                     (1, 1, 0), 0.7, 0.9, -1, patch_mode=1)
+        assert torch.equal(got_nlm1, out1[:, :, sh.r0:sh.r1])
+        want_box = kernels.convolve(whole, np.ones((1, 1, 5, 5)) / 25.0)
+        assert torch.equal(got_box, want_box[:, :, shb.r0:shb.r1])
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@needs2
+def test_nccl_row_sharded_kernels_equal_unsharded():
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(ret.keys()) == list(range(world))
+
+
+@needs2
+def test_apply_over_two_devices_equals_one(oracle):
+    import torch
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    from nd_amd.filters import BoxcarFilter, NLMeansFilter
+    from tests import synth
+    planes = synth.omnibus_stack(seed=21, k=10, ny=90, nx=130, dtype=np.float32, change_frac=0.2)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    host = xr_lite.Dataset()
+    for v, a in zip(('C11', 'C12__re', 'C12__im', 'C22'), yxt):
+        host[v] = (('y', 'x', 'time'), a)
+    devs = [0, 1]
+    # host dataset
+    one = BoxcarFilter(w=5).apply(host)
+    two = BoxcarFilter(w=5).apply(host, devices=devs)
+    for v in one.data_vars:
+        np.testing.assert_array_equal(one[v].values, two[v].values)
+    nl1 = NLMeansFilter(dims=('y', 'x'), r=3, f=1, sigma=0.5, h=0.7).apply(host)
+    nl2 = NLMeansFilter(dims=('y', 'x'), r=3, f=1, sigma=0.5, h=0.7).apply(host, njobs=2)
+    for v in nl1.data_vars:
+        np.testing.assert_array_equal(nl1[v].values, nl2[v].values)
+    want = oracle.change_detection_planes(yxt, 0.9, 9).astype(bool)
+    np.testing.assert_array_equal(OmnibusTest(n=9, alpha=0.9, devices=devs).apply(host).values, want)
+    ml1 = OmnibusTest(ml=3, alpha=0.9).apply(host).values
+    ml2 = OmnibusTest(ml=3, alpha=0.9, njobs=2).apply(host).values
+    np.testing.assert_array_equal(ml1, ml2)
+    # device-resident dataset on GPU 0: chunks travel peer-to-peer, the result comes back to GPU 0
+    dev_ds = xr_lite.Dataset()
+    for v in host.data_vars:
+        dev_ds[v] = (('y', 'x', 'time'), torch.from_numpy(host[v].values).to('cuda:0'))
+    two_d = BoxcarFilter(w=5).apply(dev_ds, devices=devs)
+    for v in one.data_vars:
+        assert two_d[v].values.device == torch.device('cuda:0')
+        np.testing.assert_array_equal(two_d[v].values.cpu().numpy(), one[v].values)
+    ch = OmnibusTest(n=9, alpha=0.9, devices=devs).apply(dev_ds)
+    np.testing.assert_array_equal(ch.values.cpu().numpy(), want)
+
+
+def test_devices_argument_with_one_device_is_todays_path(oracle, device):
+    """devices=[0] (and njobs=2 on a one-GPU box) degrade to the single-device result."""
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    from nd_amd.filters import BoxcarFilter
+    from tests import synth
+    planes = synth.omnibus_stack(seed=22, k=8, ny=40, nx=70, dtype=np.float32, change_frac=0.2)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    host = xr_lite.Dataset()
+    for v, a in zip(('C11', 'C12__re', 'C12__im', 'C22'), yxt):
+        host[v] = (('y', 'x', 'time'), a)
+    one = BoxcarFilter(w=3).apply(host)
+    for kw in (dict(devices=[0]), dict(njobs=2), dict(njobs=3, devices=[0])):
+        two = BoxcarFilter(w=3).apply(host, **kw)
+        for v in one.data_vars:
+            np.testing.assert_array_equal(one[v].values, two[v].values)
+    want = oracle.change_detection_planes(yxt, 0.9, 9).astype(bool)
+    np.testing.assert_array_equal(OmnibusTest(n=9, alpha=0.9, devices=[0]).apply(host).values, want)
+    np.testing.assert_array_equal(OmnibusTest(n=9, alpha=0.9, njobs=4).apply(host).values, want)

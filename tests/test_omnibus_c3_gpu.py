@@ -47,9 +47,10 @@ def test_c3_layouts_and_tails(oracle, device):
         np.testing.assert_array_equal(ch, want)
 
 
-def test_omnibus_test_class_detects_full_pol(oracle, device):
-    """OmnibusTest.apply on a dataset with C33 / C13 / C23 runs the 3 x 3 test (host and device
-    datasets, complex cross terms)."""
+def test_omnibus_test_class_full_pol_is_opt_in(oracle, device):
+    """OmnibusTest(pol='full').apply on a dataset with C33 / C13 / C23 runs the 3 x 3 test (host and
+    device datasets, complex cross terms); without `pol` the same dataset gets the reference's
+    dual-pol test on C11 / C12 / C22 (nd/change.py:66), C33 ignored."""
     import torch
     from nd_amd import xr_lite
     from nd_amd.change import OmnibusTest
@@ -70,11 +71,21 @@ def test_omnibus_test_class_detects_full_pol(oracle, device):
         planes += [np.ascontiguousarray(host[name].values.real), np.ascontiguousarray(host[name].values.imag)]
     want = oracle.change_detection_pol(planes, 3, 0.9, looks, njobs=4).astype(bool)
     assert want.any()
-    got = OmnibusTest(n=looks, alpha=0.9).apply(host)
+    got = OmnibusTest(n=looks, alpha=0.9, pol='full').apply(host)
     assert isinstance(got.values, np.ndarray) and got.dims == ('y', 'x', 'time')
     np.testing.assert_array_equal(got.values, want)
     dev_ds = xr_lite.Dataset()
     for name in host.data_vars:
         dev_ds[name] = (('y', 'x', 'time'), torch.from_numpy(host[name].values).to(device))
-    got_dev = OmnibusTest(n=looks, alpha=0.9).apply(dev_ds)
+    got_dev = OmnibusTest(n=looks, alpha=0.9, pol='full').apply(dev_ds)
     np.testing.assert_array_equal(got_dev.values.cpu().numpy(), want)
+    # default: dual-pol on C11 / C12 / C22, as upstream; also when C13 / C23 are absent
+    c12 = host['C12'].values
+    dual = [host['C11'].values, np.ascontiguousarray(c12.real), np.ascontiguousarray(c12.imag),
+            host['C22'].values]
+    want2 = oracle.change_detection_planes(dual, 0.9, looks, njobs=4).astype(bool)
+    np.testing.assert_array_equal(OmnibusTest(n=looks, alpha=0.9).apply(host).values, want2)
+    del host['C13'], host['C23']
+    np.testing.assert_array_equal(OmnibusTest(n=looks, alpha=0.9).apply(host).values, want2)
+    with pytest.raises(KeyError):
+        OmnibusTest(n=looks, alpha=0.9, pol='full').apply(host)
