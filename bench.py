@@ -370,12 +370,12 @@ def extras(main, barrier, dev):
         dom = max(km, key=km.get)
         e = dict(sample=res)
         if wdt == 5:
-            crop = np.ascontiguousarray(x[:, :1024, :1024].cpu().numpy())
+            crop = np.ascontiguousarray(x[:, :2048, :2048].cpu().numpy())
             t0 = time.perf_counter()
             O.convolve_reflect_mt(crop, kern, njobs=cores)
             dtc = time.perf_counter() - t0
             e['cpu_baseline'] = {'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
-                                 'kind': 'port', 'sample': '24 x 1024 x 1024 crop, %.2f s' % dtc}
+                                 'kind': 'port', 'sample': '24 x 2048 x 2048 crop, %.2f s' % dtc}
         entry('BoxcarFilter %dx%d on 24t x 4096 x 4096 f32 (scipy.ndimage.convolve arithmetic)'
               % (wdt, wdt), dt, 5, x.numel(), km, roofline(dom, km[dom], 8 * x.numel()),
               res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
@@ -401,13 +401,13 @@ def extras(main, barrier, dev):
         flop = x.numel() * nq * (49 * 3 + 8) if pm else x.numel() * nq * 2
         e = dict(sample=res, TFLOPs_naive_formula=flop / (dt / steps) / 1e12)
         if pm == 1:
-            crop = np.ascontiguousarray(x[:, :1, :160, :160].permute(2, 3, 1, 0).cpu().numpy())
+            crop = np.ascontiguousarray(x[:, :1, :640, :640].permute(2, 3, 1, 0).cpu().numpy())
             o = np.empty_like(crop)
             t0 = time.perf_counter()
             O.pixelwise_nlmeans_3d(crop, o, (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, njobs=cores, patch_mode=1)
             dtc = time.perf_counter() - t0
-            e['cpu_baseline'] = {'value': 160 * 160 / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
-                                 'kind': 'port', 'sample': '160 x 160 crop of one date, %.2f s' % dtc}
+            e['cpu_baseline'] = {'value': 640 * 640 / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
+                                 'kind': 'port', 'sample': '640 x 640 crop of one date, %.2f s' % dtc}
         entry('NLMeansFilter 7x7 patch / 21x21 search on 12t x 4096 x 4096 f32, patch distances %s'
               % ('as compiled (reference: window mean)' if pm == 0 else 'signed (true patch distances)'),
               dt, steps, x.numel(), km,

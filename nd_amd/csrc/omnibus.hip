@@ -672,101 +672,265 @@ struct OmniDenseArgs {
     uint32_t dump_cap;
 };
 
-template <typename T, int KMAX>
-__global__ void __launch_bounds__(64) omnibus_c2_dense_kernel(const OmniDenseArgs<T> s)
+// ---- the search itself, on a series held in registers ------------------------------------
+// log2 of a positive finite x as (exponent, log2 of the mantissa in [0.5, 1)): the mantissa's
+// log2 comes from the hardware v_log_f32 (<= 1 ulp of a value in [-1, 0], i.e. <= 6e-8 absolute).
+__device__ __forceinline__ void log2_parts(float x, int &e, float &m)
 {
-    extern __shared__ __align__(16) unsigned char nd_smem_d[];
-    double *scr = reinterpret_cast<double *>(nd_smem_d);      // screen constants, as in pass B
+    m = __log2f(__builtin_frexpf(x, &e));
+}
+__device__ __forceinline__ void log2_parts(double x, int &e, float &m)
+{
+    m = __log2f((float)__builtin_frexp(x, &e));
+    // (float) of a mantissa just below 1 may round to 1: log2 = 0, error < 1e-7 as budgeted
+}
+
+constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the mantissa logs
+
+// nd/_change.pyx:224-257 for one pixel per lane, on a series held in registers (static indices
+// only).  Per segment start l the reference evaluates the global test over ts[l:] and then the
+// marginal tests over ts[l:l+j], j = 2, 3, ... up to the first one that fires.
+//
+// Phase 1 (one backward pass over the dates) decides the global test of EVERY l from suffix sums
+//   kept in double.  The reference forms the same sums forward in `floating`; the two differ by
+//   rounding only, and that difference is bounded per pixel:
+//       |det_ref - det| <= 5 n u s11 s22      (n = k - l terms, u = 2^-24 (T = float) / 2^-53;
+//                                              forward-summation bound gamma_(n-1) on s11, s22 and,
+//                                              through Cauchy-Schwarz, on s12; plus the five roundings
+//                                              of the determinant itself)
+//   which widens the screen's band by m2 = 1.46 j 5 n u (s11 s22 / det) in log2 units.  Outside
+//   the widened band the decision is certain; inside, the pixel is handed to pass B.
+// Phase 2 walks the segments forward (static unroll over l; a lane takes part in row l when its
+//   segment starts there).  The marginal sums are the reference's own additions in the
+//   reference's order (0 + a_l + a_l+1 + ...), so their determinant is bit-identical to the
+//   reference's and only the logarithms are approximate (tight band).  Rows stop accumulating as
+//   soon as every participating lane has found its first firing marginal -- at low thresholds
+//   that is after the first step.
+// The double product of determinants is replaced by exact integer sums of per-date logarithms.
+// A test is decided from x = log2(prod) - j log2(det of sum) - R(j) against the host's bounds
+// (DenseScreenEntry, read from LDS); a lane whose x falls between them -- or whose data leaves the
+// domain in which x is meaningful -- stops and is reported in `handoff` (pass B redoes the pixel
+// exactly).
+//   mask: bit t set <=> change detected at date t (valid for lanes with !handoff)
+template <typename T>
+__device__ __forceinline__ float dense_x(const T dets, const bool ok, const int Le, const int Lm,
+                                         const int jj, const DenseScreenEntry &c)
+{
+    int es;
+    float ms;
+    log2_parts(ok ? dets : (T)1, es, ms);
+    const int E = (Le - __mul24(jj, es)) - c.re;
+    const float F = (float)Lm * (1.0f / kLogFix);
+    return (float)E + ((F - c.rf) - (float)jj * ms);
+}
+
+template <typename T, int KMAX>
+__device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k, const bool active,
+                                             const DenseScreenEntry *scr, unsigned &mask_out,
+                                             bool &handoff_out)
+{
+    static_assert(KMAX <= kDenseMax, "screen table too small");
+    int le[KMAX], lm[KMAX];
+    bool bad = false;
+    int eabs = 0;
+    unsigned gF = 0, gI = 0;           // bit l: global test of ts[l:] fires / is undecided
+    {
+        double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0;
+        int Le = 0, Lm = 0;
+        const float cu = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 7.5f;   // 1.46 * 5 u, rounded up
+#pragma unroll
+        for (int t = KMAX - 1; t >= 0; --t) {
+            // branch-free: elements beyond k hold a copy of a valid date and are masked out.  The
+            // instantiation for KMAX serves KMAX - 8 < k <= KMAX (2 <= k for KMAX = 8), so the
+            // early dates are known to be inside the series.
+            constexpr int kmin = KMAX == 8 ? 2 : KMAX - 7;
+            const bool in = (t < kmin) || (t < k);
+            const T det = (v[t][0] * v[t][3]) - ((v[t][1] * v[t][1]) + (v[t][2] * v[t][2]));
+            const bool ok = (det > (T)0) && (det < (T)INFINITY) && (v[t][0] > (T)0);
+            bad = bad || (in && !ok);
+            int e;
+            float m;
+            log2_parts(ok ? det : (T)1, e, m);
+            le[t] = in ? e : 0;
+            lm[t] = in ? (int)rintf(m * kLogFix) : 0;
+            eabs += le[t] < 0 ? -le[t] : le[t];
+            S11 += in ? (double)v[t][0] : 0.0;
+            S12r += in ? (double)v[t][1] : 0.0;
+            S12i += in ? (double)v[t][2] : 0.0;
+            S22 += in ? (double)v[t][3] : 0.0;
+            Le += le[t];
+            Lm += lm[t];
+            if (t < KMAX - 1 && t < k - 1) {                 // global test of ts[t:], j = k - t >= 2
+                const int jj = k - t;
+                const double pp = S11 * S22;
+                const double dets = pp - ((S12r * S12r) + (S12i * S12i));
+                const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
+                int ci = jj;
+                asm volatile("" : "+v"(ci));                  // keep the LDS read at its use
+                const DenseScreenEntry c = scr[ci];
+                const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
+                // rounding of the reference's float sums: relative bound on its determinant
+                const float q = (float)pp * __builtin_amdgcn_rcpf((float)dets);
+                const float rel = cu * (float)jj * q;          // 1.46 * 5 n u * s11 s22 / det
+                const float m2 = (float)jj * rel * 1.01f;
+                const bool sane = okd && (rel < 0.01f);
+                const bool fires = sane && (x + m2 < c.a);
+                const bool cant = sane && (x - m2 > c.b);
+                gF |= fires ? (1u << t) : 0u;
+                gI |= (fires || cant) ? 0u : (1u << t);
+            }
+            // one date at a time: interleaving the evaluations of all dates for instruction-level
+            // parallelism costs more than 100 registers, i.e. half the waves
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // |log2| of every partial product stays below 900: the reference's double product neither
+    // overflows nor loses precision to subnormals, so its logarithm is what the sums here model
+    bad = bad || (eabs > 900);
+    bool handoff = active && bad;
+    bool done = !active || bad;
+    int cur = 0;
+    unsigned mask = 0;
+#pragma unroll
+    for (int l = 0; l < KMAX - 1; ++l) {
+        if (l < k - 1) {
+            bool act = !done && (cur == l);
+            if (__any(act)) {
+                if (act && ((gI >> l) & 1u)) {           // global test undecided: pass B's pixel
+                    handoff = true;
+                    done = true;
+                    act = false;
+                }
+                if (act && !((gF >> l) & 1u)) {          // :241-242
+                    done = true;
+                    act = false;
+                }
+                T s11 = (T)0 + v[l][0], s12r = (T)0 + v[l][1], s12i = (T)0 + v[l][2],
+                  s22 = (T)0 + v[l][3];
+                int Le = le[l], Lm = lm[l];
+                int fire_at = -1;
+                bool open = __any(act);
+#pragma unroll
+                for (int t = l + 1; t < KMAX; ++t) {
+                    if (open && t < k) {
+                        s11 = s11 + v[t][0];
+                        s12r = s12r + v[t][1];
+                        s12i = s12i + v[t][2];
+                        s22 = s22 + v[t][3];
+                        Le += le[t];
+                        Lm += lm[t];
+                        const bool need = act && fire_at < 0;
+                        if (t == k - 1) {
+                            // the marginal test over all of ts[l:] IS the global test, which fires
+                            if (need) fire_at = t;
+                        } else {
+                            const int jj = t - l + 1;
+                            const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                            const bool ok = (dets > (T)0) && (dets < (T)INFINITY);
+                            // (opaque index: keeps the 16-byte LDS read at its use)
+                            int ci = jj;
+                            asm volatile("" : "+v"(ci));
+                            const DenseScreenEntry c = scr[ci];
+                            const float x = dense_x<T>(dets, ok, Le, Lm, jj, c);
+                            const bool fires = ok && (x < c.a);
+                            const bool cant = ok && (x > c.b);
+                            if (need && !(fires || cant)) {       // undecided: pass B's pixel
+                                handoff = true;
+                                done = true;
+                                act = false;
+                            }
+                            if (act && need && fires) fire_at = t;
+                        }
+                        open = __any(act && fire_at < 0);
+                    }
+                }
+                if (act) {                             // fire_at >= l + 1
+                    mask |= 1u << fire_at;             // :252, l + r with r = j - 1
+                    cur = fire_at;                     // :255
+                    if (cur >= k - 1) done = true;     // :256
+                }
+            }
+        }
+    }
+    mask_out = mask;
+    handoff_out = handoff;
+}
+
+// One lane's row of the change map from its mask (the map was zero-filled by pass A).
+__device__ __forceinline__ void store_change_row(uint8_t *res, const int k, const unsigned mask)
+{
+    if ((k & 3) == 0) {                    // rows start on 4-byte boundaries: whole words
+        uint32_t *w = reinterpret_cast<uint32_t *>(res);
+        for (int q = 0; q < (k >> 2); ++q) {
+            const unsigned nib = (mask >> (4 * q)) & 0xFu;
+            w[q] = (nib * 0x00204081u) & 0x01010101u;       // bit i -> byte i
+        }
+    } else {
+        for (int t = 1; t < k; ++t)
+            if ((mask >> t) & 1u) res[t] = 1;
+    }
+}
+
+template <typename T, int KMAX>
+__global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDenseArgs<T> s,
+                                                              const DenseScreen scr_arg)
+{
+    __shared__ DenseScreenEntry scr[kDenseMax + 1];
     const int lane = threadIdx.x;
-    const int k = s.k, kp = k + 1;
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards, nlblock = gridDim.x / kShards;
     const uint32_t n = s.flag_count[shard * kCounterStride + 1];
     if (lblock >= n) return;                  // the usual case in the sparse regime: nothing listed
     const uint32_t *list = s.dense_idx + (size_t)shard * s.segd;
-    for (int j = lane; j <= k; j += 64) {
-        const OmniTabEntry e = s.tab[j];
-        scr[j] = e.m2rho;
-        scr[kp + j] = e.pklogk;
-        scr[2 * kp + j] = e.zlo_a;
-        scr[3 * kp + j] = e.zhi_a;
+    // static indices only: a lane-indexed read of the argument struct would pull all of it into
+    // scalar registers at once
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) scr[j] = scr_arg.e[j];
     }
     __syncthreads();
 
     for (uint32_t w = lblock; w < n; w += nlblock) {
-        const int64_t pix0 = (int64_t)list[w];
+        // (opaque copy of k per wave of pixels: everything derived from k alone -- per-date
+        // predicates, (float)j, bound coefficients -- would otherwise be hoisted out of this loop
+        // and held in ~100 vector and scalar registers for the whole kernel)
+        int k = s.k;
+        asm volatile("" : "+s"(k));
+        const int64_t pix0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)list[w]);   // wave-uniform
         const int64_t pix = pix0 + lane;
         const int64_t row0 = pix0 / s.nx;
-        int64_t row = pix / s.nx, col = pix - row * s.nx;
-        // a wave of pass A never leaves its row unless the rows are contiguous
-        bool active = s.flat ? (pix < s.npix) : (row == row0);
-        if (!active) {
-            row = row0;
-            col = s.nx - 1;
+        const int64_t col0 = pix0 - row0 * s.nx;
+        // a wave of pass A never leaves its row unless the rows are contiguous (flat: sx = 1,
+        // sy = nx); idle lanes re-read the last pixel of the row / raster
+        int64_t ub;           // uniform element offset of lane 0's pixel
+        unsigned delta;       // this lane's element distance from it (>= 0)
+        bool active;
+        if (s.flat) {
+            active = pix < s.npix;
+            ub = pix0;
+            delta = (unsigned)((active ? pix : s.npix - 1) - pix0);
+        } else {
+            active = col0 + lane < s.nx;
+            ub = row0 * s.sy + col0 * s.sx;
+            delta = (unsigned)(((active ? col0 + lane : s.nx - 1) - col0) * s.sx);
         }
-        const int64_t off = row * s.sy + col * s.sx;
+        const int64_t off = ub + (int64_t)delta;
+        // every load of the series in flight at once: no per-date branch (dates beyond k re-read
+        // the last one; the search never looks at them), scalar base + 32-bit lane offset
         T v[KMAX][4];
 #pragma unroll
-        for (int t = 0; t < KMAX; ++t)
-            if (t < k) {
-                const int64_t o = off + (int64_t)t * s.st;
-                v[t][0] = s.c11[o];
-                v[t][1] = s.c12r[o];
-                v[t][2] = s.c12i[o];
-                v[t][3] = s.c22[o];
-            }
-        uint8_t *res = s.change + pix * (int64_t)k;
-        int l = 0;
-        bool done = !active, handoff = false;
-        while (__any(!done)) {
-            Accum<T> A;
-            A.reset();
-            int fire_at = -1;
-            bool gfire = false;
-            // no lane of the wave needs the dates before the earliest segment start
-            int lmin = done ? 0x7fffffff : l;
-#pragma unroll
-            for (int m_ = 32; m_ >= 1; m_ >>= 1) {
-                const int other = __shfl_xor(lmin, m_);
-                lmin = other < lmin ? other : lmin;
-            }
-            lmin = __builtin_amdgcn_readfirstlane(lmin);
-#pragma unroll
-            for (int t = 0; t < KMAX; ++t) {
-                if (t < k && t >= lmin) {
-                    const bool on = !done && t >= l;
-                    if (on) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
-                    const int jj = t - l + 1;
-                    const bool last = (t == k - 1);
-                    // a marginal test while none has fired yet (j >= 2); at the last date the
-                    // same evaluation is the global test, needed even if a marginal fired earlier
-                    const bool need = on && jj >= 2 && (fire_at < 0 || last);
-                    if (__any(need)) {
-                        bool fires = false, inband = false;
-                        if (need) {
-                            const double za = z_approx<T>(A, jj, s.nlooks, scr[jj], scr[kp + jj]);
-                            fires = (za > scr[3 * kp + jj]) && (za < INFINITY);
-                            inband = (za >= scr[2 * kp + jj]) && !fires;
-                        }
-                        if (inband) {
-                            handoff = true;            // pass B decides this pixel
-                            done = true;
-                        }
-                        if (fires && fire_at < 0) fire_at = t;
-                        if (last) gfire = fires;
-                    }
-                }
-            }
-            if (!done) {
-                if (gfire) {                           // implies k - l >= 2
-                    res[fire_at] = 1;                  // :252, l + r with r = j - 1
-                    l = fire_at;                       // :255
-                    if (l >= k - 1) done = true;       // :256
-                } else {
-                    done = true;                       // :241-242
-                }
-            }
+        for (int t = 0; t < KMAX; ++t) {
+            const int64_t ot = ub + (int64_t)(t < k ? t : k - 1) * s.st;
+            v[t][0] = (s.c11 + ot)[delta];
+            v[t][1] = (s.c12r + ot)[delta];
+            v[t][2] = (s.c12i + ot)[delta];
+            v[t][3] = (s.c22 + ot)[delta];
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads together, ahead of every use
+        unsigned mask;
+        bool handoff;
+        dense_search<T, KMAX>(v, k, active, scr, mask, handoff);
+        if (active && !handoff && mask != 0u) store_change_row(s.change + pix * (int64_t)k, k, mask);
         if (__any(handoff)) {
             const unsigned long long m = __ballot(handoff);
             unsigned base = 0;
@@ -791,6 +955,150 @@ __global__ void __launch_bounds__(64) omnibus_c2_dense_kernel(const OmniDenseArg
             }
         }
     }
+}
+
+// -----------------------------------------------------------------------------------------
+// pass A with the search fused in (low thresholds: most waves are dense).  Same loads as
+// omnibus_c2_retain_kernel; a wave in which at least `dense_min` pixels pass the global screen
+// searches all its pixels right away from the registers the series already sits in and writes
+// their rows of the change map whole -- the planes are read once and neither the dense list nor a
+// second kernel is involved.  Sparser waves list their candidates for pass B as usual.
+// Two blocks per CU (the search needs ~250 registers), against four for the plain pass A: this
+// form is chosen by the host when the threshold makes dense waves the rule (alpha < 0.75).
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void zero_fill_span(uint8_t *ob, const int nb, const int lane)
+{
+    int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+    if (head > nb) head = nb;
+    if (lane < head) ob[lane] = 0;
+    const int nvec = (nb - head) >> 4;
+    uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
+    for (int i = lane; i < nvec; i += 64) store_zero16_nt(vz + i);
+    const int tail0 = head + (nvec << 4);
+    if (tail0 + lane < nb) ob[tail0 + lane] = 0;
+}
+
+template <typename T, int KMAX, bool EXACT>
+__global__ void __launch_bounds__(kRetainThreads, 2)
+omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg)
+{
+    __shared__ DenseScreenEntry scr[kDenseMax + 1];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kRetainThreads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = EXACT ? KMAX : g.k;
+    const bool in = x0 < g.nx;
+
+    // ---- issue every load of the series (as in omnibus_c2_retain_kernel) ----
+    T v[KMAX][4];
+    if (EXACT) {
+        const int64_t ub = row * g.sy + bpx0;
+        const unsigned lx = in ? (unsigned)tid : (unsigned)(g.nx - 1 - bpx0);   // idle lanes re-read the last pixel
+        const unsigned voff = lx * (unsigned)sizeof(T);
+        const auto r11 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c11 + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r12r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12r + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r12i = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12i + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r22 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c22 + ub), 0, 0x7fffffff, 0x00020000);
+        const unsigned sstep = (unsigned)g.st * (unsigned)sizeof(T);   // host guarantees k * st * sizeof(T) < 2^31
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const unsigned soff = (unsigned)t * sstep;
+            v[t][0] = buffer_load<T>(r11, voff, soff);
+            v[t][1] = buffer_load<T>(r12r, voff, soff);
+            v[t][2] = buffer_load<T>(r12i, voff, soff);
+            v[t][3] = buffer_load<T>(r22, voff, soff);
+        }
+    } else {
+        const int64_t xc = in ? x0 : g.nx - 1;
+        const int64_t off0 = row * g.sy + xc * g.sx;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const int64_t off = off0 + (int64_t)(t < k ? t : k - 1) * g.st;    // no per-date branch
+            v[t][0] = __builtin_nontemporal_load(g.c11 + off);
+            v[t][1] = __builtin_nontemporal_load(g.c12r + off);
+            v[t][2] = __builtin_nontemporal_load(g.c12i + off);
+            v[t][3] = __builtin_nontemporal_load(g.c22 + off);
+        }
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) scr[j] = scr_arg.e[j];      // static indices only
+    }
+    if (g.write_tab && b == 0) {
+        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads together, ahead of every use
+
+    // ---- global screen of the whole series: is this wave dense? ----
+    Accum<T> A;
+    A.reset();
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+    const bool flag = in && (z_approx<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
+    const unsigned long long m = __ballot(flag);
+    const unsigned shard = (unsigned)(b % kShards);
+    const int64_t wpx0 = bpx0 + (tid & ~63);                  // first pixel of this wave in its row
+    const int64_t wleft = g.nx - wpx0;
+    const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
+    uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
+
+    bool listed = flag;                                       // pixels that go to pass B
+    const bool dense = __popcll(m) >= g.dense_min;
+    if (dense) {
+        unsigned mask;
+        bool handoff;
+        // (k as a run-time value even when it is known to equal KMAX: with every guard folded
+        // away the search becomes one straight block whose scheduling spills ~230 registers)
+        int ks = g.k;
+        asm volatile("" : "+s"(ks));
+        dense_search<T, KMAX>(v, ks, in, scr, mask, handoff);
+        if (handoff) mask = 0u;                               // pass B writes that pixel's changes
+        if (in) {
+            uint8_t *res = wob + (int64_t)lane * k;
+            if ((k & 3) == 0) {
+                uint32_t *w = reinterpret_cast<uint32_t *>(res);
+#pragma unroll
+                for (int q = 0; q < KMAX / 4; ++q)
+                    if (q < (k >> 2)) w[q] = (((mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+            } else {
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & 1u);
+            }
+        }
+        listed = handoff;
+    }
+    if (__any(listed)) {
+        const unsigned long long lm_ = __ballot(listed);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(lm_));
+        base = __shfl(base, 0);
+        if (listed) {
+            const unsigned slot = base + (unsigned)__popcll(lm_ & ((1ull << lane) - 1ull));
+            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
+            if (slot < g.dump_cap) {
+                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) {
+                    if (EXACT || t < k) {
+                        Pack<T, 4> q;
+                        q.v[0] = v[t][0];
+                        q.v[1] = v[t][1];
+                        q.v[2] = v[t][2];
+                        q.v[3] = v[t][3];
+                        *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                    }
+                }
+            }
+        }
+    }
+    // ---- a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275)
+    if (!dense && wnp > 0) zero_fill_span(wob, wnp * k, lane);
 }
 
 // =========================================================================================
@@ -1127,6 +1435,37 @@ static void launch_retain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, int6
     }
 }
 
+template <typename T, int KMAX>
+static void launch_fused_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const DenseScreen &scr,
+                           int64_t nblocks, hipStream_t stream)
+{
+    const dim3 grid((unsigned)nblocks), block(kRetainThreads);
+    if (g.k == KMAX && g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0)
+        hipLaunchKernelGGL((omnibus_c2_fused_kernel<T, KMAX, true>), grid, block, 0, stream, g, tab, scr);
+    else
+        hipLaunchKernelGGL((omnibus_c2_fused_kernel<T, KMAX, false>), grid, block, 0, stream, g, tab, scr);
+}
+
+// k <= 32 (float) / 16 (double): the series lengths dense_search is instantiated for
+template <typename T>
+static void launch_fused(const OmniGlobalArgs<T> &g, const OmniTab &tab, const DenseScreen &scr,
+                         int64_t nblocks, hipStream_t stream)
+{
+    const int k = g.k;
+    if (k <= 8)
+        launch_fused_k<T, 8>(g, tab, scr, nblocks, stream);
+    else if (k <= 16)
+        launch_fused_k<T, 16>(g, tab, scr, nblocks, stream);
+    else if (sizeof(T) == 4) {
+        if (k <= 24)
+            launch_fused_k<float, 24>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, scr,
+                                      nblocks, stream);
+        else
+            launch_fused_k<float, 32>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, scr,
+                                      nblocks, stream);
+    }
+}
+
 template <typename T>
 static void launch_retain(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_t nblocks,
                           bool stats, hipStream_t stream)
@@ -1221,6 +1560,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     g.dense_min = dense_ok ? dense_env : 65;
     const bool stats = (z_out != nullptr) || (p_out != nullptr);
     const bool retain = k <= (sizeof(T) == 4 ? kRetainMaxF32 : kRetainMaxF64);
+    // Low thresholds make nearly every wave dense (P > alpha holds for a fraction 1 - alpha of
+    // stationary pixels): the search is then fused into pass A.  Speed only -- every form gives the
+    // same map.  ND_AMD_FUSED_ALPHA overrides the switch-over (0 = never fuse, 2 = always).
+    static const double fused_alpha = [] {
+        const char *e = getenv("ND_AMD_FUSED_ALPHA");
+        return e ? atof(e) : 0.75;
+    }();
+    const bool fused = retain && dense_ok && !stats && g.dense_min <= 64 && alpha < fused_alpha;
     {
         const size_t per = (size_t)k * 4 * sizeof(T);
         size_t cap = retain ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
@@ -1287,6 +1634,10 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             return ND_AMD_EUNSUPPORTED;
         }
 #undef ND_LAUNCH_PM
+    } else if (fused) {
+        const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+        launch_fused<T>(g, tab, scr, nblocks, stream);
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (retain)
@@ -1299,7 +1650,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     ND_HIP_CHECK(hipGetLastError());
 
     // ---- dense waves (none in the sparse regime: every block then leaves at once) ----
-    if (retain && g.dense_min <= 64) {
+    if (retain && g.dense_min <= 64 && !fused) {
         OmniDenseArgs<T> d;
         d.c11 = g.c11;
         d.c12r = g.c12r;
@@ -1327,18 +1678,18 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         if (per_shard_d > 128) per_shard_d = 128;
         if (per_shard_d < 1) per_shard_d = 1;
         const dim3 gridd((unsigned)(per_shard_d * kShards)), blockd(64);
-        const size_t ldsd = (size_t)(k + 1) * 4 * sizeof(double);
+        const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_DENSE, stream);
         if (k <= 8)
-            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 8>), gridd, blockd, ldsd, stream, d);
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 8>), gridd, blockd, 0, stream, d, scr);
         else if (k <= 16)
-            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 16>), gridd, blockd, ldsd, stream, d);
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 16>), gridd, blockd, 0, stream, d, scr);
         else if (sizeof(T) == 4 && k <= 24)
-            hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 24>), gridd, blockd, ldsd, stream,
-                               reinterpret_cast<const OmniDenseArgs<float> &>(d));
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 24>), gridd, blockd, 0, stream,
+                               reinterpret_cast<const OmniDenseArgs<float> &>(d), scr);
         else if (sizeof(T) == 4)
-            hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 32>), gridd, blockd, ldsd, stream,
-                               reinterpret_cast<const OmniDenseArgs<float> &>(d));
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 32>), gridd, blockd, 0, stream,
+                               reinterpret_cast<const OmniDenseArgs<float> &>(d), scr);
     }
     ND_HIP_CHECK(hipGetLastError());
 

@@ -282,6 +282,87 @@ static OmniTabEntry make_entry(int j, uint32_t n_looks, double alpha, int pol)
     return e;
 }
 
+// ---- constants of the in-register search's screen (omnibus.hip: dense_search) ----------------
+// The search decides a test from  L2 = log2(prod of determinants) - j * log2(det of sum),
+// z = z0 + c * L2 with z0 = m2rho n pklogk and c = m2rho n ln 2 (< 0 for rho > 0), evaluated as
+//   x = L2 - R  in float, relative to a reference point R = re + rf near the decision:
+//   x < a  =>  the test fires for certain;   x > b  =>  it cannot fire;   otherwise: undecided,
+// the pixel is handed to pass B (exact evaluation).  Error budget of the device's x (see
+// dense_search): j * (6e-8 hardware log2 + 1.5e-8 fixed point) per determinant, j * 6e-8 for the
+// determinant of the sum, < 6e-6 float32 arithmetic  =>  < 9e-6 at j = 24; `mg` below is more than
+// twice that, plus the rounding of z to T that the exact bounds zlo / zhi refer to.
+struct DenseScreenEntry {
+    int re;
+    float rf, a, b;
+};
+constexpr int kDenseMax = 32;
+struct DenseScreen {
+    DenseScreenEntry e[kDenseMax + 1];
+};
+
+template <typename T>
+static DenseScreenEntry make_dense_entry(const OmniTabEntry &t, int j, uint32_t n_looks)
+{
+    DenseScreenEntry d;
+    d.re = 0;
+    d.rf = 0.f;
+    d.a = -INFINITY;    // never "fires for certain"
+    d.b = INFINITY;     // never "cannot fire"  => every test of this j is handed over
+    const double c = t.m2rho * (double)n_looks * 0.6931471805599453;
+    const double z0 = t.m2rho * (double)n_looks * t.pklogk;
+    if (j < 2 || !(c < 0.0) || !(c > -INFINITY) || !(z0 == z0) || !(fabs(z0) < INFINITY)) return d;
+    if (t.zlo == INFINITY) {          // P <= 1 < alpha: nothing can fire
+        d.b = -INFINITY;
+        return d;
+    }
+    const double eps = sizeof(T) == 4 ? 1.1920928955078125e-07 : 2.220446049250313e-16;
+    const bool hi_ok = t.zhi < INFINITY && t.zhi > -INFINITY;
+    const bool lo_ok = t.zlo > -INFINITY && t.zlo < INFINITY;
+    const double mg0 = 2e-5 + 4e-7 * (double)j;
+    double Lhi = 0, Llo = 0;
+    if (hi_ok) {
+        const double zr = 2.0 * eps * fabs(t.zhi);                 // (T) rounding of z
+        Lhi = (t.zhi + zr - z0) / c;                               // z > zhi + zr  <=>  L2 < Lhi
+        Lhi -= mg0 + 1e-12 * fabs(Lhi);
+    }
+    if (lo_ok) {
+        const double zr = 2.0 * eps * fabs(t.zlo);
+        Llo = (t.zlo - zr - z0) / c;                               // z < zlo - zr  <=>  L2 > Llo
+        Llo += mg0 + 1e-12 * fabs(Llo);
+    }
+    if (!hi_ok && !lo_ok) return d;
+    const double R = hi_ok ? Lhi : Llo;
+    if (!(fabs(R) < 5e8)) return d;
+    const double fl = floor(R);
+    d.re = (int)fl;
+    d.rf = (float)(R - fl);
+    if (hi_ok) {
+        d.a = 0.f;
+        d.b = lo_ok ? (float)(Llo - R) + 1e-6f : INFINITY;
+        if (lo_ok && !(Llo >= R)) {      // cannot happen (zlo <= zhi); be safe: exact only
+            d.a = -INFINITY;
+            d.b = INFINITY;
+        }
+    } else {
+        d.a = -INFINITY;
+        d.b = 0.f;
+    }
+    return d;
+}
+
+template <typename T>
+static DenseScreen make_dense_screen(const std::vector<OmniTabEntry> &tab, int k, uint32_t n_looks)
+{
+    DenseScreen s;
+    memset(&s, 0, sizeof(s));
+    for (int j = 0; j <= kDenseMax; ++j) {
+        s.e[j].a = -INFINITY;
+        s.e[j].b = INFINITY;
+        if (j >= 1 && j <= k) s.e[j] = make_dense_entry<T>(tab[(size_t)j], j, n_looks);
+    }
+    return s;
+}
+
 // small cache of per-call tables: they depend only on (k, n_looks, alpha, dtype, p)
 struct TabKey {
     int k, dtype, pol;
