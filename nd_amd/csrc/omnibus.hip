@@ -686,6 +686,11 @@ __device__ __forceinline__ void log2_parts(double x, int &e, float &m)
 }
 
 constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the mantissa logs
+// 1: the per-date logarithms are parked in LDS between the two phases of the search (48 registers
+// less, but every row then waits for an LDS round trip); 0: they stay in registers
+#ifndef ND_LOGS_LDS
+#define ND_LOGS_LDS 0
+#endif
 
 // nd/_change.pyx:224-257 for one pixel per lane, on a series held in registers (static indices
 // only).  Per segment start l the reference evaluates the global test over ts[l:] and then the
@@ -712,6 +717,32 @@ constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the
 // domain in which x is meaningful -- stops and is reported in `handoff` (pass B redoes the pixel
 // exactly).
 //   mask: bit t set <=> change detected at date t (valid for lanes with !handoff)
+// The screen's per-j constants live in four registers of every wave, entry j in lane j, and are
+// fetched with v_readlane (a few cycles, no memory access; the index is wave-uniform).
+struct ScreenRegs {
+    int re;
+    float rf, a, b;
+};
+__device__ __forceinline__ ScreenRegs screen_regs_load(const DenseScreenEntry *scr_lds, const int lane)
+{
+    const DenseScreenEntry e = scr_lds[lane <= kDenseMax ? lane : kDenseMax];
+    ScreenRegs r;
+    r.re = e.re;
+    r.rf = e.rf;
+    r.a = e.a;
+    r.b = e.b;
+    return r;
+}
+__device__ __forceinline__ DenseScreenEntry screen_entry(const ScreenRegs &r, const int j)
+{
+    DenseScreenEntry c;
+    c.re = __builtin_amdgcn_readlane(r.re, j);
+    c.rf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.rf), j));
+    c.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.a), j));
+    c.b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.b), j));
+    return c;
+}
+
 template <typename T>
 __device__ __forceinline__ float dense_x(const T dets, const bool ok, const int Le, const int Lm,
                                          const int jj, const DenseScreenEntry &c)
@@ -724,13 +755,18 @@ __device__ __forceinline__ float dense_x(const T dets, const bool ok, const int 
     return (float)E + ((F - c.rf) - (float)jj * ms);
 }
 
+// `logs`: this lane's column of an LDS array int2[KMAX][64] (per-date exponent and fixed-point
+// mantissa logarithm; written in phase 1, read back by the rows of phase 2 -- 48 registers less).
 template <typename T, int KMAX>
 __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k, const bool active,
-                                             const DenseScreenEntry *scr, unsigned &mask_out,
+                                             const ScreenRegs &scr, int2 *logs, unsigned &mask_out,
                                              bool &handoff_out)
 {
     static_assert(KMAX <= kDenseMax, "screen table too small");
+#if !ND_LOGS_LDS
     int le[KMAX], lm[KMAX];
+    (void)logs;
+#endif
     bool bad = false;
     int eabs = 0;
     unsigned gF = 0, gI = 0;           // bit l: global test of ts[l:] fires / is undecided
@@ -751,23 +787,31 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
             int e;
             float m;
             log2_parts(ok ? det : (T)1, e, m);
-            le[t] = in ? e : 0;
-            lm[t] = in ? (int)rintf(m * kLogFix) : 0;
-            eabs += le[t] < 0 ? -le[t] : le[t];
+            const int le_t = in ? e : 0;
+            const int lm_t = in ? (int)rintf(m * kLogFix) : 0;
+#if ND_LOGS_LDS
+            logs[t * 64] = make_int2(le_t, lm_t);
+#else
+            le[t] = le_t;
+            lm[t] = lm_t;
+#endif
+            eabs += le_t < 0 ? -le_t : le_t;
             S11 += in ? (double)v[t][0] : 0.0;
             S12r += in ? (double)v[t][1] : 0.0;
             S12i += in ? (double)v[t][2] : 0.0;
             S22 += in ? (double)v[t][3] : 0.0;
-            Le += le[t];
-            Lm += lm[t];
+            Le += le_t;
+            Lm += lm_t;
+#ifdef ND_DBG_NOP1EVAL
+            if (false) {
+#else
             if (t < KMAX - 1 && t < k - 1) {                 // global test of ts[t:], j = k - t >= 2
+#endif
                 const int jj = k - t;
                 const double pp = S11 * S22;
                 const double dets = pp - ((S12r * S12r) + (S12i * S12i));
                 const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
-                int ci = jj;
-                asm volatile("" : "+v"(ci));                  // keep the LDS read at its use
-                const DenseScreenEntry c = scr[ci];
+                const DenseScreenEntry c = screen_entry(scr, jj);
                 const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
                 // rounding of the reference's float sums: relative bound on its determinant
                 const float q = (float)pp * __builtin_amdgcn_rcpf((float)dets);
@@ -791,6 +835,9 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
     bool done = !active || bad;
     int cur = 0;
     unsigned mask = 0;
+#ifdef ND_DBG_NOP2
+    gF = gF ? 1u : 0u;
+#endif
 #pragma unroll
     for (int l = 0; l < KMAX - 1; ++l) {
         if (l < k - 1) {
@@ -805,20 +852,31 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
                     done = true;
                     act = false;
                 }
-                T s11 = (T)0 + v[l][0], s12r = (T)0 + v[l][1], s12i = (T)0 + v[l][2],
-                  s22 = (T)0 + v[l][3];
-                int Le = le[l], Lm = lm[l];
+                // (the reference's sums start from 0: 0 + a_l = a_l exactly, up to the sign of a zero
+                // cross term, which no product below can see)
+                T s11 = v[l][0], s12r = v[l][1], s12i = v[l][2], s22 = v[l][3];
+#if ND_LOGS_LDS
+                const int2 lg0 = logs[l * 64];
+#else
+                const int2 lg0 = make_int2(le[l], lm[l]);
+#endif
+                int Le = lg0.x, Lm = lg0.y;
                 int fire_at = -1;
                 bool open = __any(act);
 #pragma unroll
                 for (int t = l + 1; t < KMAX; ++t) {
                     if (open && t < k) {
+#if ND_LOGS_LDS
+                        const int2 lg = logs[t * 64];
+#else
+                        const int2 lg = make_int2(le[t], lm[t]);
+#endif
                         s11 = s11 + v[t][0];
                         s12r = s12r + v[t][1];
                         s12i = s12i + v[t][2];
                         s22 = s22 + v[t][3];
-                        Le += le[t];
-                        Lm += lm[t];
+                        Le += lg.x;
+                        Lm += lg.y;
                         const bool need = act && fire_at < 0;
                         if (t == k - 1) {
                             // the marginal test over all of ts[l:] IS the global test, which fires
@@ -827,10 +885,7 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
                             const int jj = t - l + 1;
                             const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
                             const bool ok = (dets > (T)0) && (dets < (T)INFINITY);
-                            // (opaque index: keeps the 16-byte LDS read at its use)
-                            int ci = jj;
-                            asm volatile("" : "+v"(ci));
-                            const DenseScreenEntry c = scr[ci];
+                            const DenseScreenEntry c = screen_entry(scr, jj);
                             const float x = dense_x<T>(dets, ok, Le, Lm, jj, c);
                             const bool fires = ok && (x < c.a);
                             const bool cant = ok && (x > c.b);
@@ -859,7 +914,7 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
 // One lane's row of the change map from its mask (the map was zero-filled by pass A).
 __device__ __forceinline__ void store_change_row(uint8_t *res, const int k, const unsigned mask)
 {
-    if ((k & 3) == 0) {                    // rows start on 4-byte boundaries: whole words
+    if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {   // rows start on 4-byte boundaries: whole words
         uint32_t *w = reinterpret_cast<uint32_t *>(res);
         for (int q = 0; q < (k >> 2); ++q) {
             const unsigned nib = (mask >> (4 * q)) & 0xFu;
@@ -875,7 +930,8 @@ template <typename T, int KMAX>
 __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDenseArgs<T> s,
                                                               const DenseScreen scr_arg)
 {
-    __shared__ DenseScreenEntry scr[kDenseMax + 1];
+    __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    __shared__ int2 logs_lds[ND_LOGS_LDS ? KMAX * 64 : 1];
     const int lane = threadIdx.x;
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards, nlblock = gridDim.x / kShards;
@@ -886,9 +942,10 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
     // scalar registers at once
     if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j <= KMAX; ++j) scr[j] = scr_arg.e[j];
+        for (int j = 0; j <= KMAX; ++j) scr_lds[j] = scr_arg.e[j];
     }
     __syncthreads();
+    const ScreenRegs scr = screen_regs_load(scr_lds, lane);
 
     for (uint32_t w = lblock; w < n; w += nlblock) {
         // (opaque copy of k per wave of pixels: everything derived from k alone -- per-date
@@ -914,7 +971,6 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
             ub = row0 * s.sy + col0 * s.sx;
             delta = (unsigned)(((active ? col0 + lane : s.nx - 1) - col0) * s.sx);
         }
-        const int64_t off = ub + (int64_t)delta;
         // every load of the series in flight at once: no per-date branch (dates beyond k re-read
         // the last one; the search never looks at them), scalar base + 32-bit lane offset
         T v[KMAX][4];
@@ -929,7 +985,7 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
         __builtin_amdgcn_sched_barrier(0);      // keep the loads together, ahead of every use
         unsigned mask;
         bool handoff;
-        dense_search<T, KMAX>(v, k, active, scr, mask, handoff);
+        dense_search<T, KMAX>(v, k, active, scr, logs_lds + (ND_LOGS_LDS ? lane : 0), mask, handoff);
         if (active && !handoff && mask != 0u) store_change_row(s.change + pix * (int64_t)k, k, mask);
         if (__any(handoff)) {
             const unsigned long long m = __ballot(handoff);
@@ -978,11 +1034,15 @@ __device__ __forceinline__ void zero_fill_span(uint8_t *ob, const int nb, const 
     if (tail0 + lane < nb) ob[tail0 + lane] = 0;
 }
 
+#ifndef ND_FUSED_OCC
+#define ND_FUSED_OCC 2
+#endif
 template <typename T, int KMAX, bool EXACT>
-__global__ void __launch_bounds__(kRetainThreads, 2)
+__global__ void __launch_bounds__(kRetainThreads, ND_FUSED_OCC)
 omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg)
 {
-    __shared__ DenseScreenEntry scr[kDenseMax + 1];
+    __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    __shared__ int2 logs_lds[ND_LOGS_LDS ? KMAX * kRetainThreads : 1];        // [wave][date][lane]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t b = blockIdx.x;
@@ -1026,7 +1086,7 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
     }
     if (tid == 0) {
 #pragma unroll
-        for (int j = 0; j <= KMAX; ++j) scr[j] = scr_arg.e[j];      // static indices only
+        for (int j = 0; j <= KMAX; ++j) scr_lds[j] = scr_arg.e[j];      // static indices only
     }
     if (g.write_tab && b == 0) {
         for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
@@ -1057,11 +1117,12 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
         // away the search becomes one straight block whose scheduling spills ~230 registers)
         int ks = g.k;
         asm volatile("" : "+s"(ks));
-        dense_search<T, KMAX>(v, ks, in, scr, mask, handoff);
+        const ScreenRegs scr = screen_regs_load(scr_lds, lane);
+        dense_search<T, KMAX>(v, ks, in, scr, logs_lds + (ND_LOGS_LDS ? (tid >> 6) * (KMAX * 64) + lane : 0), mask, handoff);
         if (handoff) mask = 0u;                               // pass B writes that pixel's changes
         if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
-            if ((k & 3) == 0) {
+            if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
                 uint32_t *w = reinterpret_cast<uint32_t *>(res);
 #pragma unroll
                 for (int q = 0; q < KMAX / 4; ++q)
@@ -1093,6 +1154,329 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
                         q.v[3] = v[t][3];
                         *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
                     }
+                }
+            }
+        }
+    }
+    // ---- a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275)
+    if (!dense && wnp > 0) zero_fill_span(wob, wnp * k, lane);
+}
+
+// -----------------------------------------------------------------------------------------
+// pass A with the search fused in, streaming form (low thresholds).  The series is NOT kept in
+// registers: the dates are consumed as they arrive, last date first, PF dates in flight.
+//
+//   phase 1 (per date t, branch-free): logarithm of the date's determinant; suffix sums over
+//           ts[t:] in double -> the global test G(t) as in dense_search; the 2- and 3-date sums
+//           a_t + a_t+1 (+ a_t+2) in the reference's `floating` and order from a rolling window of
+//           three dates -> the marginal tests M2(t), M3(t) with the tight band.  Each test leaves
+//           two bits per lane (fires / undecided) at position t of six 32-bit masks.
+//   walk    (per segment start l, a handful of bit operations): G(l) undecided -> pass B; does not
+//           fire -> finished; else the first firing marginal: M2(l), M3(l), and only if neither
+//           fires (about 1e-3 of the rows at alpha = 0.01) the deeper marginals j = 4, 5, ... with
+//           the dates read again from memory (L2-resident) in a rolled loop.
+// About 100 registers -> 4 to 5 waves per SIMD instead of 2, and any k <= 32.
+// Same decisions as dense_search (same sums, same bounds), hence the same map.
+// -----------------------------------------------------------------------------------------
+template <typename T>
+struct DateVal {
+    T a, b, c, d;
+};
+
+template <typename T, bool BUF>
+struct PlaneReader {
+    // BUF: x-contiguous planes, buffer descriptors + 32-bit lane offset + scalar date offset
+    __amdgpu_buffer_rsrc_t r11, r12r, r12i, r22;
+    unsigned voff, sstep;
+    const T *p11, *p12r, *p12i, *p22;
+    int64_t st;
+    __device__ __forceinline__ DateVal<T> load(const int t) const
+    {
+        DateVal<T> q;
+        if (BUF) {
+            const unsigned soff = (unsigned)t * sstep;
+            q.a = buffer_load<T>(r11, voff, soff);
+            q.b = buffer_load<T>(r12r, voff, soff);
+            q.c = buffer_load<T>(r12i, voff, soff);
+            q.d = buffer_load<T>(r22, voff, soff);
+        } else {
+            const int64_t o = (int64_t)t * st;
+            q.a = __builtin_nontemporal_load(p11 + o);
+            q.b = __builtin_nontemporal_load(p12r + o);
+            q.c = __builtin_nontemporal_load(p12i + o);
+            q.d = __builtin_nontemporal_load(p22 + o);
+        }
+        return q;
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void screen_decide(const float x, const float m2, const bool sane,
+                                              const DenseScreenEntry &c, const int t,
+                                              unsigned &fbits, unsigned &ibits)
+{
+    const bool fires = sane && (x + m2 < c.a);
+    const bool cant = sane && (x - m2 > c.b);
+    fbits |= fires ? (1u << t) : 0u;
+    ibits |= (fires || cant) ? 0u : (1u << t);
+}
+
+template <typename T, int PF, bool BUF>
+__global__ void __launch_bounds__(kRetainThreads)
+omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg)
+{
+    __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kRetainThreads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+
+    PlaneReader<T, BUF> rd;
+    {
+        const int64_t xc = in ? x0 : g.nx - 1;                  // idle lanes re-read the last pixel
+        if (BUF) {
+            const int64_t ub = row * g.sy + bpx0;
+            rd.voff = (unsigned)(xc - bpx0) * (unsigned)sizeof(T);
+            rd.r11 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c11 + ub), 0, 0x7fffffff, 0x00020000);
+            rd.r12r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12r + ub), 0, 0x7fffffff, 0x00020000);
+            rd.r12i = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12i + ub), 0, 0x7fffffff, 0x00020000);
+            rd.r22 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c22 + ub), 0, 0x7fffffff, 0x00020000);
+            rd.sstep = (unsigned)g.st * (unsigned)sizeof(T);   // host guarantees k * st * sizeof(T) < 2^31
+        } else {
+            const int64_t off0 = row * g.sy + xc * g.sx;
+            rd.p11 = g.c11 + off0;
+            rd.p12r = g.c12r + off0;
+            rd.p12i = g.c12i + off0;
+            rd.p22 = g.c22 + off0;
+            rd.st = g.st;
+        }
+    }
+    // ---- first PF dates in flight (last date first) ----
+    DateVal<T> ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int t = k - 1 - u;
+        ring[u] = rd.load(t > 0 ? t : 0);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j <= kDenseMax; ++j) scr_lds[j] = scr_arg.e[j];      // static indices only
+    }
+    if (g.write_tab && b == 0) {
+        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
+    }
+    __syncthreads();
+    const ScreenRegs scr = screen_regs_load(scr_lds, lane);
+
+    // ---- phase 1 ----
+    unsigned gF = 0, gI = 0, m2F = 0, m2I = 0, m3F = 0, m3I = 0;
+    bool bad = false;
+    int eabs = 0;
+    double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0;
+    int Le = 0, Lm = 0;
+    DateVal<T> d1, d2;                         // dates t + 1, t + 2
+    d1.a = d1.d = d2.a = d2.d = (T)1;
+    d1.b = d1.c = d2.b = d2.c = (T)0;
+    int e1 = 0, m1 = 0, e2 = 0, m2q = 0;       // their logarithms
+    const float cu = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 7.5f;   // 1.46 * 5 u, rounded up
+
+    for (int tb = k - 1; tb >= 0; tb -= PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb - u;
+            if (t >= 0) {
+                const DateVal<T> q = ring[u];
+                if (t - PF >= 0) ring[u] = rd.load(t - PF);          // keep PF dates in flight
+                const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+                const bool ok = (det > (T)0) && (det < (T)INFINITY) && (q.a > (T)0);
+                bad = bad || !ok;
+                int e0;
+                float mf;
+                log2_parts(ok ? det : (T)1, e0, mf);
+                const int m0 = (int)rintf(mf * kLogFix);
+                eabs += e0 < 0 ? -e0 : e0;
+                S11 += (double)q.a;
+                S12r += (double)q.b;
+                S12i += (double)q.c;
+                S22 += (double)q.d;
+                Le += e0;
+                Lm += m0;
+                if (t <= k - 2) {                                   // global test of ts[t:], j = k - t
+                    const int jj = k - t;
+                    const double pp = S11 * S22;
+                    const double dets = pp - ((S12r * S12r) + (S12i * S12i));
+                    const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
+                    const DenseScreenEntry c = screen_entry(scr, jj);
+                    const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
+                    const float qq = (float)pp * __builtin_amdgcn_rcpf((float)dets);
+                    const float rel = cu * (float)jj * qq;          // 1.46 * 5 n u * s11 s22 / det
+                    screen_decide<T>(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t, gF, gI);
+                }
+                if (t <= k - 3) {                                   // marginal tests over 2 and 3 dates
+                    // the reference's sums, in its type and order: (0 + a_t) + a_t+1 (+ a_t+2)
+                    T s11 = q.a + d1.a, s12r = q.b + d1.b, s12i = q.c + d1.c, s22 = q.d + d1.d;
+                    {
+                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                        const DenseScreenEntry c = screen_entry(scr, 2);
+                        const float x = dense_x<T>(dets, oks, e0 + e1, m0 + m1, 2, c);
+                        screen_decide<T>(x, 0.f, oks, c, t, m2F, m2I);
+                    }
+                    if (t <= k - 4) {
+                        s11 = s11 + d2.a;
+                        s12r = s12r + d2.b;
+                        s12i = s12i + d2.c;
+                        s22 = s22 + d2.d;
+                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                        const DenseScreenEntry c = screen_entry(scr, 3);
+                        const float x = dense_x<T>(dets, oks, (e0 + e1) + e2, (m0 + m1) + m2q, 3, c);
+                        screen_decide<T>(x, 0.f, oks, c, t, m3F, m3I);
+                    }
+                }
+                d2 = d1;
+                e2 = e1;
+                m2q = m1;
+                d1 = q;
+                e1 = e0;
+                m1 = m0;
+            }
+        }
+    }
+    // |log2| of every partial product stays below 900: the reference's double product neither
+    // overflows nor loses precision to subnormals, so its logarithm is what the sums here model
+    bad = bad || (eabs > 900);
+
+    const unsigned shard = (unsigned)(b % kShards);
+    const int64_t wpx0 = bpx0 + (tid & ~63);                  // first pixel of this wave in its row
+    const int64_t wleft = g.nx - wpx0;
+    const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
+    uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
+
+    // ---- is this wave dense?  candidates = pixels whose global test over the whole series can fire
+    const bool cand = in && (bad || (((gF | gI) & 1u) != 0u));
+    const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
+    bool listed = cand;                                       // a sparse wave lists its candidates
+    unsigned mask = 0;
+    if (dense) {
+        bool handoff = in && bad;
+        bool done = !in || bad;
+        int cur = 0;
+        for (int l = 0; l < k - 1; ++l) {
+            bool act = !done && (cur == l);
+            if (!__any(act)) continue;
+            const bool gi = (gI >> l) & 1u, gf = (gF >> l) & 1u;
+            const bool i2 = (m2I >> l) & 1u, f2 = (m2F >> l) & 1u;
+            const bool i3 = (m3I >> l) & 1u, f3 = (m3F >> l) & 1u;
+            int fire = -1;
+            bool deep = false;
+            if (act) {
+                if (gi) {                                     // global test undecided
+                    handoff = true;
+                    done = true;
+                } else if (!gf) {                             // :241-242
+                    done = true;
+                } else if (l + 1 == k - 1) {
+                    fire = l + 1;                             // the 2-date marginal IS the global test
+                } else if (i2) {
+                    handoff = true;
+                    done = true;
+                } else if (f2) {
+                    fire = l + 1;
+                } else if (l + 2 == k - 1) {
+                    fire = l + 2;
+                } else if (i3) {
+                    handoff = true;
+                    done = true;
+                } else if (f3) {
+                    fire = l + 2;
+                } else {
+                    deep = true;
+                }
+            }
+            if (__any(deep)) {
+                // marginal tests over 4 and more dates: the dates of ts[l:] once more, from memory
+                if (deep) {
+                    T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
+                    int Ld = 0, Lmd = 0;
+                    for (int t = l; t < k; ++t) {
+                        const DateVal<T> q = rd.load(t);
+                        s11 = s11 + q.a;
+                        s12r = s12r + q.b;
+                        s12i = s12i + q.c;
+                        s22 = s22 + q.d;
+                        const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+                        int e0;
+                        float mf;
+                        log2_parts(det, e0, mf);              // the pixel is not `bad`: det > 0
+                        Ld += e0;
+                        Lmd += (int)rintf(mf * kLogFix);
+                        if (t < l + 3) continue;              // j = 2, 3 are decided: they do not fire
+                        if (t == k - 1) {
+                            fire = t;                         // the marginal over ts[l:] IS the global test
+                            break;
+                        }
+                        const int jj = t - l + 1;
+                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                        const DenseScreenEntry c = scr_lds[jj];
+                        const float x = dense_x<T>(dets, oks, Ld, Lmd, jj, c);
+                        if (oks && (x < c.a)) {
+                            fire = t;
+                            break;
+                        }
+                        if (!(oks && (x > c.b))) {            // undecided
+                            handoff = true;
+                            done = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (fire >= 0) {
+                mask |= 1u << fire;                           // :252, l + r with r = j - 1
+                cur = fire;                                   // :255
+                if (cur >= k - 1) done = true;                // :256
+            }
+        }
+        if (handoff) mask = 0u;                               // pass B writes that pixel's changes
+        if (in) {
+            uint8_t *res = wob + (int64_t)lane * k;
+            if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
+                uint32_t *w = reinterpret_cast<uint32_t *>(res);
+                for (int q = 0; q < (k >> 2); ++q)
+                    w[q] = (((mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+            } else {
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & 1u);
+            }
+        }
+        listed = handoff;
+    }
+    if (__any(listed)) {
+        const unsigned long long lm_ = __ballot(listed);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(lm_));
+        base = __shfl(base, 0);
+        if (listed) {
+            const unsigned slot = base + (unsigned)__popcll(lm_ & ((1ull << lane) - 1ull));
+            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
+            if (slot < g.dump_cap) {
+                // the series was streamed, not kept: the (rare) listed pixel is read once more
+                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+                for (int t = 0; t < k; ++t) {
+                    const DateVal<T> q = rd.load(t);
+                    Pack<T, 4> o;
+                    o.v[0] = q.a;
+                    o.v[1] = q.b;
+                    o.v[2] = q.c;
+                    o.v[3] = q.d;
+                    *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = o;
                 }
             }
         }
@@ -1637,7 +2021,20 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     } else if (fused) {
         const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-        launch_fused<T>(g, tab, scr, nblocks, stream);
+        static const int fused_form = [] {
+            const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming (default), 1 = registers
+            return e ? atoi(e) : 0;
+        }();
+        if (fused_form == 1) {
+            launch_fused<T>(g, tab, scr, nblocks, stream);
+        } else {
+            const dim3 grid((unsigned)nblocks), block(kRetainThreads);
+            constexpr int PF = sizeof(T) == 4 ? 6 : 4;
+            if (g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0)
+                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, true>), grid, block, 0, stream, g, tab, scr);
+            else
+                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, false>), grid, block, 0, stream, g, tab, scr);
+        }
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (retain)
