@@ -638,6 +638,173 @@ omnibus_c2_retain_pm_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const 
 }
 
 
+__device__ __forceinline__ void zero_fill_span(uint8_t *ob, const int nb, const int lane)
+{
+    int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+    if (head > nb) head = nb;
+    if (lane < head) ob[lane] = 0;
+    const int nvec = (nb - head) >> 4;
+    uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
+    for (int i = lane; i < nvec; i += 64) store_zero16_nt(vz + i);
+    const int tail0 = head + (nvec << 4);
+    if (tail0 + lane < nb) ob[tail0 + lane] = 0;
+}
+
+// -----------------------------------------------------------------------------------------
+// pass A for the reference's layout, LDS-DMA form.  One wave per 64 pixels: the wave's span of
+// every variable (64 pixels x k dates, contiguous in memory) goes straight from memory into a
+// wave-private LDS image with `global_load_lds_dwordx4` -- 16 bytes per lane, 1 KiB per instruction,
+// no register staging, every transfer of the wave (24 KiB at k = 24) in flight at once, and no
+// workgroup barrier: a wave reads only what it loaded itself, after its own s_waitcnt vmcnt(0).
+// Each lane then picks its pixel's series out of the image with 16-byte LDS reads and the kernel
+// continues like the register-retaining form (same fold, screen, list, dump, zero-fill).
+// Needs 16-byte aligned variables and k a multiple of 16 / sizeof(T); the staged form above serves
+// the rest.  (omnibus_c2_retain_pm_kernel: two dependent load -> LDS -> register rounds, 0.41 of
+// the HBM peak at k = 24; this form: see DESIGN.md.)
+// -----------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+typedef __attribute__((address_space(1))) const unsigned char glb_u8_t;
+
+template <typename T>
+struct OmniPmDmaArgs {
+    int ids[4];               // element distance between consecutive dates, per variable (1 or 2)
+    int c12_joint;            // C12 re / im are the halves of one interleaved array: one image
+    int img_off[4];           // element offset of each variable's image in the wave's LDS region
+};
+
+// one variable of this lane's series out of its LDS image (16-byte reads; all register indices
+// static).  BOTH: the image is interleaved complex and both halves are wanted (components COMP,
+// COMP + 1); otherwise a stride-2 image carries the wanted half at the even offsets.
+template <typename T, int KMAX, int COMP, bool BOTH>
+__device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int k, const int ids)
+{
+    constexpr int VE = 16 / (int)sizeof(T);
+    if (ids == 1) {
+#pragma unroll
+        for (int u = 0; u < KMAX / VE; ++u) {
+            if (u * VE < k) {
+                const Pack<T, VE> q = *reinterpret_cast<const Pack<T, VE> *>(im + u * VE);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[u * VE + i][COMP] = q.v[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2 * KMAX / VE; ++u) {
+            if (u * VE < 2 * k) {
+                const Pack<T, VE> q = *reinterpret_cast<const Pack<T, VE> *>(im + u * VE);
+#pragma unroll
+                for (int i = 0; i < VE; i += 2) {
+                    v[(u * VE + i) / 2][COMP] = q.v[i];
+                    if (BOTH) v[(u * VE + i) / 2][COMP + (BOTH ? 1 : 0)] = q.v[i + 1];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int KMAX, bool STATS>
+__global__ void __launch_bounds__(64)
+omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const OmniPmDmaArgs<T> pm)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_dma[];
+    T *img = reinterpret_cast<T *>(nd_smem_dma);
+    constexpr int VE = 16 / (int)sizeof(T);                // elements per 16-byte transfer
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t px0 = b * 64;
+    const int64_t x0 = px0 + lane;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+    const int64_t left = g.nx - px0;
+    const int np = left > 64 ? 64 : (int)left;
+
+    // ---- every transfer of the wave in flight ----
+    auto stage = [&](const T *base, int vi) {
+        const int wpp = k * pm.ids[vi];                     // elements per pixel in memory
+        const int bytes = np * wpp * (int)sizeof(T);        // multiple of 16 (host checks k)
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(base + px0 * wpp);
+        unsigned char *dst = reinterpret_cast<unsigned char *>(img + pm.img_off[vi]);
+        for (int c0 = 0; c0 < bytes; c0 += 1024) {
+            const int eb = c0 + lane * 16;
+            if (eb < bytes)
+                __builtin_amdgcn_global_load_lds((glb_u8_t *)(src + eb), (lds_u8_t *)(dst + c0), 16, 0, kNtAux);
+        }
+    };
+    stage(g.c11, 0);
+    stage(g.c22, 3);
+    stage(g.c12r, 1);
+    if (!pm.c12_joint) stage(g.c12i, 2);
+
+    if (g.write_tab && b == 0) {
+        for (int j = lane; j <= k; j += 64) g.tab_dev[j] = tab.e[j];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- this lane's series out of the images (idle lanes copy the last pixel) ----
+    T v[KMAX][4];
+    const int own = in ? lane : np - 1;
+    pm_pick<T, KMAX, 0, false>(v, img + pm.img_off[0] + own * k * pm.ids[0], k, pm.ids[0]);
+    pm_pick<T, KMAX, 3, false>(v, img + pm.img_off[3] + own * k * pm.ids[3], k, pm.ids[3]);
+    if (pm.c12_joint) {
+        pm_pick<T, KMAX, 1, true>(v, img + pm.img_off[1] + own * k * 2, k, 2);
+    } else {
+        pm_pick<T, KMAX, 1, false>(v, img + pm.img_off[1] + own * k * pm.ids[1], k, pm.ids[1]);
+        pm_pick<T, KMAX, 2, false>(v, img + pm.img_off[2] + own * k * pm.ids[2], k, pm.ids[2]);
+    }
+
+    // ---- fold in time order ----
+    Accum<T> A;
+    A.reset();
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t)
+        if (t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+
+    bool flag;
+    if (STATS) {
+        const T z = z_stat<T>(A, k, g.nlooks, g.e);
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        flag = in && ((double)P > g.alpha);
+        if (in) {
+            if (g.z_out) g.z_out[x0] = z;
+            if (g.p_out) g.p_out[x0] = P;
+        }
+    } else {
+        flag = in && (z_approx<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
+    }
+
+    // ---- list + dump ----
+    if (__any(flag)) {
+        const unsigned long long m = __ballot(flag);
+        const unsigned shard = (unsigned)(b % kShards);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag) {
+            const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)x0;
+            if (slot < g.dump_cap) {
+                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) {
+                    if (t < k) {
+                        Pack<T, 4> q;
+                        q.v[0] = v[t][0];
+                        q.v[1] = v[t][1];
+                        q.v[2] = v[t][2];
+                        q.v[3] = v[t][3];
+                        *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                    }
+                }
+            }
+        }
+    }
+    // ---- zero-fill this wave's slice of the change map (np.zeros at nd/_change.pyx:275) ----
+    zero_fill_span(g.change + px0 * (int64_t)k, np * k, lane);
+}
+
 // =========================================================================================
 // dense waves: the change-point search from registers
 // =========================================================================================
@@ -686,11 +853,7 @@ __device__ __forceinline__ void log2_parts(double x, int &e, float &m)
 }
 
 constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the mantissa logs
-// 1: the per-date logarithms are parked in LDS between the two phases of the search (48 registers
-// less, but every row then waits for an LDS round trip); 0: they stay in registers
-#ifndef ND_LOGS_LDS
-#define ND_LOGS_LDS 0
-#endif
+
 
 // nd/_change.pyx:224-257 for one pixel per lane, on a series held in registers (static indices
 // only).  Per segment start l the reference evaluates the global test over ts[l:] and then the
@@ -755,18 +918,15 @@ __device__ __forceinline__ float dense_x(const T dets, const bool ok, const int 
     return (float)E + ((F - c.rf) - (float)jj * ms);
 }
 
-// `logs`: this lane's column of an LDS array int2[KMAX][64] (per-date exponent and fixed-point
-// mantissa logarithm; written in phase 1, read back by the rows of phase 2 -- 48 registers less).
+// (Parking the per-date logarithms in LDS between the two phases saves 48 registers but puts an
+// LDS round trip into every row of phase 2: measured slower.)
 template <typename T, int KMAX>
 __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k, const bool active,
-                                             const ScreenRegs &scr, int2 *logs, unsigned &mask_out,
+                                             const ScreenRegs &scr, unsigned &mask_out,
                                              bool &handoff_out)
 {
     static_assert(KMAX <= kDenseMax, "screen table too small");
-#if !ND_LOGS_LDS
     int le[KMAX], lm[KMAX];
-    (void)logs;
-#endif
     bool bad = false;
     int eabs = 0;
     unsigned gF = 0, gI = 0;           // bit l: global test of ts[l:] fires / is undecided
@@ -789,12 +949,8 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
             log2_parts(ok ? det : (T)1, e, m);
             const int le_t = in ? e : 0;
             const int lm_t = in ? (int)rintf(m * kLogFix) : 0;
-#if ND_LOGS_LDS
-            logs[t * 64] = make_int2(le_t, lm_t);
-#else
             le[t] = le_t;
             lm[t] = lm_t;
-#endif
             eabs += le_t < 0 ? -le_t : le_t;
             S11 += in ? (double)v[t][0] : 0.0;
             S12r += in ? (double)v[t][1] : 0.0;
@@ -802,11 +958,7 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
             S22 += in ? (double)v[t][3] : 0.0;
             Le += le_t;
             Lm += lm_t;
-#ifdef ND_DBG_NOP1EVAL
-            if (false) {
-#else
             if (t < KMAX - 1 && t < k - 1) {                 // global test of ts[t:], j = k - t >= 2
-#endif
                 const int jj = k - t;
                 const double pp = S11 * S22;
                 const double dets = pp - ((S12r * S12r) + (S12i * S12i));
@@ -835,9 +987,6 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
     bool done = !active || bad;
     int cur = 0;
     unsigned mask = 0;
-#ifdef ND_DBG_NOP2
-    gF = gF ? 1u : 0u;
-#endif
 #pragma unroll
     for (int l = 0; l < KMAX - 1; ++l) {
         if (l < k - 1) {
@@ -855,22 +1004,13 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
                 // (the reference's sums start from 0: 0 + a_l = a_l exactly, up to the sign of a zero
                 // cross term, which no product below can see)
                 T s11 = v[l][0], s12r = v[l][1], s12i = v[l][2], s22 = v[l][3];
-#if ND_LOGS_LDS
-                const int2 lg0 = logs[l * 64];
-#else
-                const int2 lg0 = make_int2(le[l], lm[l]);
-#endif
-                int Le = lg0.x, Lm = lg0.y;
+                int Le = le[l], Lm = lm[l];
                 int fire_at = -1;
                 bool open = __any(act);
 #pragma unroll
                 for (int t = l + 1; t < KMAX; ++t) {
                     if (open && t < k) {
-#if ND_LOGS_LDS
-                        const int2 lg = logs[t * 64];
-#else
                         const int2 lg = make_int2(le[t], lm[t]);
-#endif
                         s11 = s11 + v[t][0];
                         s12r = s12r + v[t][1];
                         s12i = s12i + v[t][2];
@@ -931,7 +1071,6 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
                                                               const DenseScreen scr_arg)
 {
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
-    __shared__ int2 logs_lds[ND_LOGS_LDS ? KMAX * 64 : 1];
     const int lane = threadIdx.x;
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards, nlblock = gridDim.x / kShards;
@@ -985,7 +1124,7 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
         __builtin_amdgcn_sched_barrier(0);      // keep the loads together, ahead of every use
         unsigned mask;
         bool handoff;
-        dense_search<T, KMAX>(v, k, active, scr, logs_lds + (ND_LOGS_LDS ? lane : 0), mask, handoff);
+        dense_search<T, KMAX>(v, k, active, scr, mask, handoff);
         if (active && !handoff && mask != 0u) store_change_row(s.change + pix * (int64_t)k, k, mask);
         if (__any(handoff)) {
             const unsigned long long m = __ballot(handoff);
@@ -1022,27 +1161,11 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
 // Two blocks per CU (the search needs ~250 registers), against four for the plain pass A: this
 // form is chosen by the host when the threshold makes dense waves the rule (alpha < 0.75).
 // -----------------------------------------------------------------------------------------
-__device__ __forceinline__ void zero_fill_span(uint8_t *ob, const int nb, const int lane)
-{
-    int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
-    if (head > nb) head = nb;
-    if (lane < head) ob[lane] = 0;
-    const int nvec = (nb - head) >> 4;
-    uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
-    for (int i = lane; i < nvec; i += 64) store_zero16_nt(vz + i);
-    const int tail0 = head + (nvec << 4);
-    if (tail0 + lane < nb) ob[tail0 + lane] = 0;
-}
-
-#ifndef ND_FUSED_OCC
-#define ND_FUSED_OCC 2
-#endif
 template <typename T, int KMAX, bool EXACT>
-__global__ void __launch_bounds__(kRetainThreads, ND_FUSED_OCC)
+__global__ void __launch_bounds__(kRetainThreads, 2)
 omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg)
 {
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
-    __shared__ int2 logs_lds[ND_LOGS_LDS ? KMAX * kRetainThreads : 1];        // [wave][date][lane]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t b = blockIdx.x;
@@ -1118,7 +1241,7 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
         int ks = g.k;
         asm volatile("" : "+s"(ks));
         const ScreenRegs scr = screen_regs_load(scr_lds, lane);
-        dense_search<T, KMAX>(v, ks, in, scr, logs_lds + (ND_LOGS_LDS ? (tid >> 6) * (KMAX * 64) + lane : 0), mask, handoff);
+        dense_search<T, KMAX>(v, ks, in, scr, mask, handoff);
         if (handoff) mask = 0u;                               // pass B writes that pixel's changes
         if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
@@ -1404,36 +1527,48 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 if (deep) {
                     T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
                     int Ld = 0, Lmd = 0;
-                    for (int t = l; t < k; ++t) {
-                        const DateVal<T> q = rd.load(t);
-                        s11 = s11 + q.a;
-                        s12r = s12r + q.b;
-                        s12i = s12i + q.c;
-                        s22 = s22 + q.d;
-                        const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
-                        int e0;
-                        float mf;
-                        log2_parts(det, e0, mf);              // the pixel is not `bad`: det > 0
-                        Ld += e0;
-                        Lmd += (int)rintf(mf * kLogFix);
-                        if (t < l + 3) continue;              // j = 2, 3 are decided: they do not fire
-                        if (t == k - 1) {
-                            fire = t;                         // the marginal over ts[l:] IS the global test
-                            break;
-                        }
-                        const int jj = t - l + 1;
-                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
-                        const DenseScreenEntry c = scr_lds[jj];
-                        const float x = dense_x<T>(dets, oks, Ld, Lmd, jj, c);
-                        if (oks && (x < c.a)) {
-                            fire = t;
-                            break;
-                        }
-                        if (!(oks && (x > c.b))) {            // undecided
-                            handoff = true;
-                            done = true;
-                            break;
+                    bool searching = true;
+                    // four dates in flight per round trip (most searches end at j = 4 or 5)
+                    for (int t0 = l; t0 < k && searching; t0 += 4) {
+                        DateVal<T> qb[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) qb[u] = rd.load(t0 + u < k ? t0 + u : k - 1);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int t = t0 + u;
+                            if (searching && t < k) {
+                                const DateVal<T> q = qb[u];
+                                s11 = s11 + q.a;
+                                s12r = s12r + q.b;
+                                s12i = s12i + q.c;
+                                s22 = s22 + q.d;
+                                const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+                                int e0;
+                                float mf;
+                                log2_parts(det, e0, mf);          // the pixel is not `bad`: det > 0
+                                Ld += e0;
+                                Lmd += (int)rintf(mf * kLogFix);
+                                if (t >= l + 3) {                 // j = 2, 3 are decided: they do not fire
+                                    if (t == k - 1) {
+                                        fire = t;                 // the marginal over ts[l:] IS the global test
+                                        searching = false;
+                                    } else {
+                                        const int jj = t - l + 1;
+                                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                                        const DenseScreenEntry c = scr_lds[jj];
+                                        const float x = dense_x<T>(dets, oks, Ld, Lmd, jj, c);
+                                        if (oks && (x < c.a)) {
+                                            fire = t;
+                                            searching = false;
+                                        } else if (!(oks && (x > c.b))) {      // undecided
+                                            handoff = true;
+                                            done = true;
+                                            searching = false;
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                 }
@@ -1992,6 +2127,45 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }
         pm.c12_joint = (pm_ids[1] == 2 && pm_ids[2] == 2 &&
                         static_cast<const T *>(c12im) == static_cast<const T *>(c12re) + 1) ? 1 : 0;
+        // LDS-DMA form: 16-byte aligned variables, k a multiple of the 16-byte vector, k <= 24
+        constexpr int VE = 16 / (int)sizeof(T);
+        static const int pm_form = [] {
+            const char *e = getenv("ND_AMD_PM_FORM");        // 1 = always the register-staged form
+            return e ? atoi(e) : 0;
+        }();
+        const bool dma_ok = pm_form != 1 && (k % VE) == 0 &&
+                            (((uintptr_t)c11 | (uintptr_t)c22 | (uintptr_t)c12re) & 15) == 0 &&
+                            (pm.c12_joint || ((uintptr_t)c12im & 15) == 0);
+        if (dma_ok) {
+            OmniPmDmaArgs<T> dm;
+            int off = 0;
+            for (int vi = 0; vi < 4; ++vi) dm.ids[vi] = (int)pm_ids[vi];
+            dm.c12_joint = pm.c12_joint;
+            const int order[4] = {0, 3, 1, 2};
+            for (int oi = 0; oi < 4; ++oi) {
+                const int vi = order[oi];
+                dm.img_off[vi] = off;
+                if (vi == 2 && dm.c12_joint) continue;      // shares the image of C12 re
+                off += 64 * (int)k * dm.ids[vi];
+            }
+            const size_t lds_dma = (size_t)off * sizeof(T);
+            const dim3 gridw((unsigned)ceil_div(npix, 64)), blockw(64);
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+#define ND_LAUNCH_DMA(KM)                                                                              \
+    do {                                                                                              \
+        if (stats)                                                                                    \
+            hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, true>), gridw, blockw, lds_dma, stream, g, tab, dm);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, false>), gridw, blockw, lds_dma, stream, g, tab, dm); \
+    } while (0)
+            if (k <= 8)
+                ND_LAUNCH_DMA(8);
+            else if (k <= 16)
+                ND_LAUNCH_DMA(16);
+            else
+                ND_LAUNCH_DMA(24);
+#undef ND_LAUNCH_DMA
+        } else {
         const size_t lds = 2 * (size_t)kRetainThreads * (size_t)(k | 1) * sizeof(T);
         if (lds > 64 * 1024) {
             set_error("nd_amd_omnibus_c2_pixel_major: %lld dates of this type do not fit the staging image",
@@ -2018,14 +2192,19 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             return ND_AMD_EUNSUPPORTED;
         }
 #undef ND_LAUNCH_PM
+        }
     } else if (fused) {
         const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+        // Two forms of the fused kernel, same map: the streaming one wins while searches beyond
+        // three dates are rare (a row needs one with probability ~ alpha per pixel): measured
+        // 2.3 vs 3.1 ms at alpha = 0.01, break-even at 0.05, 6.3 vs 5.1 ms at 0.2 (24 x 4096^2).
         static const int fused_form = [] {
-            const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming (default), 1 = registers
-            return e ? atoi(e) : 0;
+            const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 1 = registers, else by alpha
+            return e ? atoi(e) : -1;
         }();
-        if (fused_form == 1) {
+        const bool regs_form = fused_form == 1 || (fused_form != 0 && alpha > 0.05);
+        if (regs_form) {
             launch_fused<T>(g, tab, scr, nblocks, stream);
         } else {
             const dim3 grid((unsigned)nblocks), block(kRetainThreads);
