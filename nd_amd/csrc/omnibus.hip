@@ -1306,22 +1306,35 @@ struct DateVal {
     T a, b, c, d;
 };
 
-template <typename T, bool BUF>
+// MODE 0: plain pointers (any strides); 1: x-contiguous planes through buffer descriptors + 32-bit
+// lane offset + scalar date offset; 2: the wave's LDS images of pixel-major variables (LDS-DMA)
+template <typename T, int MODE>
 struct PlaneReader {
-    // BUF: x-contiguous planes, buffer descriptors + 32-bit lane offset + scalar date offset
     __amdgpu_buffer_rsrc_t r11, r12r, r12i, r22;
     unsigned voff, sstep;
-    const T *p11, *p12r, *p12i, *p22;
+    const T *p11, *p12r, *p12i, *p22;      // MODE 2: this lane's series inside each image
     int64_t st;
+    int i11, i12, i22, joint;              // MODE 2: date strides inside the images
     __device__ __forceinline__ DateVal<T> load(const int t) const
     {
         DateVal<T> q;
-        if (BUF) {
+        if (MODE == 1) {
             const unsigned soff = (unsigned)t * sstep;
             q.a = buffer_load<T>(r11, voff, soff);
             q.b = buffer_load<T>(r12r, voff, soff);
             q.c = buffer_load<T>(r12i, voff, soff);
             q.d = buffer_load<T>(r22, voff, soff);
+        } else if (MODE == 2) {
+            q.a = p11[t * i11];
+            q.d = p22[t * i22];
+            if (joint) {
+                const Pack<T, 2> bc = *reinterpret_cast<const Pack<T, 2> *>(p12r + 2 * t);
+                q.b = bc.v[0];
+                q.c = bc.v[1];
+            } else {
+                q.b = p12r[t * i12];
+                q.c = p12i[t * i12];
+            }
         } else {
             const int64_t o = (int64_t)t * st;
             q.a = __builtin_nontemporal_load(p11 + o);
@@ -1330,6 +1343,43 @@ struct PlaneReader {
             q.d = __builtin_nontemporal_load(p22 + o);
         }
         return q;
+    }
+    // MODE 2: the VE = 16 / sizeof(T) dates t0 .. t0 + VE - 1 (t0 a multiple of VE) with 16-byte LDS
+    // reads where the variable's dates are adjacent (a lane's series is k * ids elements from the
+    // next lane's: single-element reads of one date collide 8-way on the 32 banks, 16-byte reads 2-way)
+    template <int VE>
+    __device__ __forceinline__ void load_group(const int t0, DateVal<T> (&q)[VE]) const
+    {
+        auto var = [&](const T *p, int ids, auto put) {
+            if (ids == 1) {
+                const Pack<T, VE> w = *reinterpret_cast<const Pack<T, VE> *>(p + t0);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) put(i, w.v[i]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const Pack<T, VE> w = *reinterpret_cast<const Pack<T, VE> *>(p + 2 * t0 + h * VE);
+#pragma unroll
+                    for (int i = 0; i < VE; i += 2) put(h * (VE / 2) + i / 2, w.v[i]);
+                }
+            }
+        };
+        var(p11, i11, [&](int i, T x) { q[i].a = x; });
+        var(p22, i22, [&](int i, T x) { q[i].d = x; });
+        if (joint) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const Pack<T, VE> w = *reinterpret_cast<const Pack<T, VE> *>(p12r + 2 * t0 + h * VE);
+#pragma unroll
+                for (int i = 0; i < VE; i += 2) {
+                    q[h * (VE / 2) + i / 2].b = w.v[i];
+                    q[h * (VE / 2) + i / 2].c = w.v[i + 1];
+                }
+            }
+        } else {
+            var(p12r, i12, [&](int i, T x) { q[i].b = x; });
+            var(p12i, i12, [&](int i, T x) { q[i].c = x; });
+        }
     }
 };
 
@@ -1344,25 +1394,58 @@ __device__ __forceinline__ void screen_decide(const float x, const float m2, con
     ibits |= (fires || cant) ? 0u : (1u << t);
 }
 
-template <typename T, int PF, bool BUF>
-__global__ void __launch_bounds__(kRetainThreads)
-omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg)
+template <typename T, int PF, int MODE>
+__global__ void __launch_bounds__(MODE == 2 ? 64 : kRetainThreads)
+omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg,
+                         const OmniPmDmaArgs<T> pm)
 {
+    constexpr int kThreads = MODE == 2 ? 64 : kRetainThreads;
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    extern __shared__ __align__(16) unsigned char nd_smem_stream[];    // MODE 2: the wave's images
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t b = blockIdx.x;
-    const int64_t row = b / g.blocks_per_row;
-    const int64_t bx = b - row * g.blocks_per_row;
-    const int64_t bpx0 = bx * (int64_t)kRetainThreads;
+    const int64_t row = MODE == 2 ? 0 : b / g.blocks_per_row;           // pixel-major: one flat row
+    const int64_t bx = MODE == 2 ? b : b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kThreads;
     const int64_t x0 = bpx0 + tid;
     const int k = g.k;
     const bool in = x0 < g.nx;
 
-    PlaneReader<T, BUF> rd;
-    {
+    PlaneReader<T, MODE> rd;
+    if (MODE == 2) {
+        // the wave's span of every variable into its LDS image (as in omnibus_c2_pm_dma_kernel)
+        T *img = reinterpret_cast<T *>(nd_smem_stream);
+        const int64_t left = g.nx - bpx0;
+        const int np = left > 64 ? 64 : (int)left;
+        auto stage = [&](const T *base, int vi) {
+            const int wpp = k * pm.ids[vi];
+            const int bytes = np * wpp * (int)sizeof(T);
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(base + bpx0 * wpp);
+            unsigned char *dst = reinterpret_cast<unsigned char *>(img + pm.img_off[vi]);
+            for (int c0 = 0; c0 < bytes; c0 += 1024) {
+                const int eb = c0 + lane * 16;
+                if (eb < bytes)
+                    __builtin_amdgcn_global_load_lds((glb_u8_t *)(src + eb), (lds_u8_t *)(dst + c0), 16, 0, kNtAux);
+            }
+        };
+        stage(g.c11, 0);
+        stage(g.c22, 3);
+        stage(g.c12r, 1);
+        if (!pm.c12_joint) stage(g.c12i, 2);
+        const int own = in ? lane : np - 1;
+        rd.i11 = pm.ids[0];
+        rd.i12 = pm.ids[1];
+        rd.i22 = pm.ids[3];
+        rd.joint = pm.c12_joint;
+        rd.p11 = img + pm.img_off[0] + own * k * pm.ids[0];
+        rd.p22 = img + pm.img_off[3] + own * k * pm.ids[3];
+        rd.p12r = img + pm.img_off[1] + own * k * pm.ids[1];
+        rd.p12i = pm.c12_joint ? rd.p12r + 1 : img + pm.img_off[2] + own * k * pm.ids[2];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         const int64_t xc = in ? x0 : g.nx - 1;                  // idle lanes re-read the last pixel
-        if (BUF) {
+        if (MODE == 1) {
             const int64_t ub = row * g.sy + bpx0;
             rd.voff = (unsigned)(xc - bpx0) * (unsigned)sizeof(T);
             rd.r11 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c11 + ub), 0, 0x7fffffff, 0x00020000);
@@ -1379,19 +1462,21 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
             rd.st = g.st;
         }
     }
-    // ---- first PF dates in flight (last date first) ----
+    // ---- first dates in flight (last date first) ----
     DateVal<T> ring[PF];
+    if (MODE != 2) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int t = k - 1 - u;
-        ring[u] = rd.load(t > 0 ? t : 0);
+        for (int u = 0; u < PF; ++u) {
+            const int t = k - 1 - u;
+            ring[u] = rd.load(t > 0 ? t : 0);
+        }
     }
     if (tid == 0) {
 #pragma unroll
         for (int j = 0; j <= kDenseMax; ++j) scr_lds[j] = scr_arg.e[j];      // static indices only
     }
     if (g.write_tab && b == 0) {
-        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
+        for (int j = tid; j <= k; j += kThreads) g.tab_dev[j] = tab.e[j];
     }
     __syncthreads();
     const ScreenRegs scr = screen_regs_load(scr_lds, lane);
@@ -1408,66 +1493,83 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     int e1 = 0, m1 = 0, e2 = 0, m2q = 0;       // their logarithms
     const float cu = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 7.5f;   // 1.46 * 5 u, rounded up
 
-    for (int tb = k - 1; tb >= 0; tb -= PF) {
+    auto process = [&](const DateVal<T> &q, const int t) {
+        const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+        const bool ok = (det > (T)0) && (det < (T)INFINITY) && (q.a > (T)0);
+        bad = bad || !ok;
+        int e0;
+        float mf;
+        log2_parts(ok ? det : (T)1, e0, mf);
+        const int m0 = (int)rintf(mf * kLogFix);
+        eabs += e0 < 0 ? -e0 : e0;
+        S11 += (double)q.a;
+        S12r += (double)q.b;
+        S12i += (double)q.c;
+        S22 += (double)q.d;
+        Le += e0;
+        Lm += m0;
+        if (t <= k - 2) {                                   // global test of ts[t:], j = k - t
+            const int jj = k - t;
+            const double pp = S11 * S22;
+            const double dets = pp - ((S12r * S12r) + (S12i * S12i));
+            const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
+            const DenseScreenEntry c = screen_entry(scr, jj);
+            const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
+            const float qq = (float)pp * __builtin_amdgcn_rcpf((float)dets);
+            const float rel = cu * (float)jj * qq;          // 1.46 * 5 n u * s11 s22 / det
+            screen_decide<T>(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t, gF, gI);
+        }
+        if (t <= k - 3) {                                   // marginal tests over 2 and 3 dates
+            // the reference's sums, in its type and order: (0 + a_t) + a_t+1 (+ a_t+2)
+            T s11 = q.a + d1.a, s12r = q.b + d1.b, s12i = q.c + d1.c, s22 = q.d + d1.d;
+            {
+                const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                const DenseScreenEntry c = screen_entry(scr, 2);
+                const float x = dense_x<T>(dets, oks, e0 + e1, m0 + m1, 2, c);
+                screen_decide<T>(x, 0.f, oks, c, t, m2F, m2I);
+            }
+            if (t <= k - 4) {
+                s11 = s11 + d2.a;
+                s12r = s12r + d2.b;
+                s12i = s12i + d2.c;
+                s22 = s22 + d2.d;
+                const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                const DenseScreenEntry c = screen_entry(scr, 3);
+                const float x = dense_x<T>(dets, oks, (e0 + e1) + e2, (m0 + m1) + m2q, 3, c);
+                screen_decide<T>(x, 0.f, oks, c, t, m3F, m3I);
+            }
+        }
+        d2 = d1;
+        e2 = e1;
+        m2q = m1;
+        d1 = q;
+        e1 = e0;
+        m1 = m0;
+    };
+    if (MODE == 2) {
+        // LDS-resident series: groups of VE dates, one group of 16-byte reads ahead
+        constexpr int VE = 16 / (int)sizeof(T);
+        DateVal<T> cur[VE], nxt[VE];
+        rd.template load_group<VE>(k - VE, nxt);
+        for (int t0 = k - VE; t0 >= 0; t0 -= VE) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int t = tb - u;
-            if (t >= 0) {
-                const DateVal<T> q = ring[u];
-                if (t - PF >= 0) ring[u] = rd.load(t - PF);          // keep PF dates in flight
-                const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
-                const bool ok = (det > (T)0) && (det < (T)INFINITY) && (q.a > (T)0);
-                bad = bad || !ok;
-                int e0;
-                float mf;
-                log2_parts(ok ? det : (T)1, e0, mf);
-                const int m0 = (int)rintf(mf * kLogFix);
-                eabs += e0 < 0 ? -e0 : e0;
-                S11 += (double)q.a;
-                S12r += (double)q.b;
-                S12i += (double)q.c;
-                S22 += (double)q.d;
-                Le += e0;
-                Lm += m0;
-                if (t <= k - 2) {                                   // global test of ts[t:], j = k - t
-                    const int jj = k - t;
-                    const double pp = S11 * S22;
-                    const double dets = pp - ((S12r * S12r) + (S12i * S12i));
-                    const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
-                    const DenseScreenEntry c = screen_entry(scr, jj);
-                    const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
-                    const float qq = (float)pp * __builtin_amdgcn_rcpf((float)dets);
-                    const float rel = cu * (float)jj * qq;          // 1.46 * 5 n u * s11 s22 / det
-                    screen_decide<T>(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t, gF, gI);
+            for (int i = 0; i < VE; ++i) cur[i] = nxt[i];
+            if (t0 >= VE) rd.template load_group<VE>(t0 - VE, nxt);
+#pragma unroll
+            for (int i = VE - 1; i >= 0; --i) process(cur[i], t0 + i);
+        }
+    } else {
+        for (int tb = k - 1; tb >= 0; tb -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = tb - u;
+                if (t >= 0) {
+                    const DateVal<T> q = ring[u];
+                    if (t - PF >= 0) ring[u] = rd.load(t - PF);          // keep PF dates in flight
+                    process(q, t);
                 }
-                if (t <= k - 3) {                                   // marginal tests over 2 and 3 dates
-                    // the reference's sums, in its type and order: (0 + a_t) + a_t+1 (+ a_t+2)
-                    T s11 = q.a + d1.a, s12r = q.b + d1.b, s12i = q.c + d1.c, s22 = q.d + d1.d;
-                    {
-                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
-                        const DenseScreenEntry c = screen_entry(scr, 2);
-                        const float x = dense_x<T>(dets, oks, e0 + e1, m0 + m1, 2, c);
-                        screen_decide<T>(x, 0.f, oks, c, t, m2F, m2I);
-                    }
-                    if (t <= k - 4) {
-                        s11 = s11 + d2.a;
-                        s12r = s12r + d2.b;
-                        s12i = s12i + d2.c;
-                        s22 = s22 + d2.d;
-                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
-                        const DenseScreenEntry c = screen_entry(scr, 3);
-                        const float x = dense_x<T>(dets, oks, (e0 + e1) + e2, (m0 + m1) + m2q, 3, c);
-                        screen_decide<T>(x, 0.f, oks, c, t, m3F, m3I);
-                    }
-                }
-                d2 = d1;
-                e2 = e1;
-                m2q = m1;
-                d1 = q;
-                e1 = e0;
-                m1 = m0;
             }
         }
     }
@@ -2136,6 +2238,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const bool dma_ok = pm_form != 1 && (k % VE) == 0 &&
                             (((uintptr_t)c11 | (uintptr_t)c22 | (uintptr_t)c12re) & 15) == 0 &&
                             (pm.c12_joint || ((uintptr_t)c12im & 15) == 0);
+        const bool fused_pm = dma_ok && !stats && k <= 32 && dense_env <= 64 && alpha < fused_alpha;
+        if (fused_pm) g.dense_min = dense_env;
         if (dma_ok) {
             OmniPmDmaArgs<T> dm;
             int off = 0;
@@ -2151,6 +2255,11 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             const size_t lds_dma = (size_t)off * sizeof(T);
             const dim3 gridw((unsigned)ceil_div(npix, 64)), blockw(64);
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+            if (fused_pm) {
+                // low threshold: the streaming search, its dates served from the LDS images
+                const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 2>), gridw, blockw, lds_dma, stream, g, tab, scr, dm);
+            } else
 #define ND_LAUNCH_DMA(KM)                                                                              \
     do {                                                                                              \
         if (stats)                                                                                    \
@@ -2209,10 +2318,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         } else {
             const dim3 grid((unsigned)nblocks), block(kRetainThreads);
             constexpr int PF = sizeof(T) == 4 ? 6 : 4;
+            OmniPmDmaArgs<T> nopm;
+            memset(&nopm, 0, sizeof(nopm));
             if (g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0)
-                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, true>), grid, block, 0, stream, g, tab, scr);
+                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1>), grid, block, 0, stream, g, tab, scr, nopm);
             else
-                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, false>), grid, block, 0, stream, g, tab, scr);
+                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0>), grid, block, 0, stream, g, tab, scr, nopm);
         }
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
