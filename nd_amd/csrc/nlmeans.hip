@@ -785,6 +785,327 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
     }
 }
 
+// ---- patch_mode 1, cross-lane form: two columns per lane ------------------------------------
+// nlmeans_patch_kernel gives every lane its own copy of each patch-row sum: 2 (2F+1) single-word
+// LDS reads and as many subtract / multiply-add per row, although seven adjacent lanes share six
+// of the seven squared differences.  Here a lane owns TWO adjacent columns and computes the
+// squared difference of each exactly once (packed float32 arithmetic: one instruction for both
+// columns); the 2F+1-wide row sums are then assembled across lanes with wave shifts (DPP
+// wave_shr / wave_shl, no LDS):  with e(2l), e(2l+1) the lane's squares and P(l) their sum,
+//   F = 1:  hs(2l) = e(2l-1) + P(l)                  hs(2l+1) = P(l) + e(2l+2)
+//   F = 2:  hs(2l) = P(l-1) + P(l) + e(2l+2)         hs(2l+1) = e(2l-1) + P(l) + P(l+1)
+//   F = 3:  hs(2l) = e(2l-3) + P(l-1) + P(l) + P(l+1)   hs(2l+1) = P(l-1) + P(l) + P(l+1) + e(2l+4)
+// i.e. 2 to 6 shifted additions per row and lane-pair instead of 2 x 14 LDS reads + 2 x 14
+// operations.  The first / last HL lanes of a wave only feed their neighbours (a wave yields
+// 2 (64 - 2 HL) columns).  Down the column the patch sum is the sum of the last 2F+1 row sums
+// (re-added every step from the ring: no drift), the weight and the weighted sums are packed
+// float32 as well; total weights are summed in float32 per search row and in double across rows.
+// Differences from the reference's double arithmetic stay <= ~1e-6 relative (tests: 1e-5).
+// Pixels whose weights all vanish in float32 are recomputed exactly as in nlmeans_patch_kernel.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dpp_from_prev(float x)      // lane i <- lane i - 1 (lane 0 <- 0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_from_next(float x)      // lane i <- lane i + 1 (lane 63 <- 0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xF, 0xF, true));
+}
+
+#ifndef ND_PATCH2_TYW1
+#define ND_PATCH2_TYW1 8
+#endif
+template <int V>
+struct Patch2Rows {
+    static constexpr int TYW = (V == 1) ? ND_PATCH2_TYW1 : 4;      // rows per thread
+};
+template <int F>
+struct Patch2Geom {
+    static constexpr int HL = (F == 3) ? 2 : (F >= 1 ? 1 : 0);     // feeder lanes on each side
+    static constexpr int TX = 2 * (64 - 2 * HL);                   // columns a wave yields
+};
+
+// max of two float pairs, one v_max_f32 per component (gfx950 has no packed max; fmaxf() costs
+// three: it canonicalises both operands first).  A NaN operand is dropped (IEEE maxNum), which is
+// what the callers want: NaNs are tracked separately (`ssum`).
+__device__ __forceinline__ f2_t pk_max(const f2_t a, const f2_t b)
+{
+    f2_t d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d.x) : "v"(a.x), "v"(b.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(d.y) : "v"(a.y), "v"(b.y));
+    return d;
+}
+
+template <int F>
+__device__ __forceinline__ f2_t patch2_row_sums(const f2_t e)
+{
+    if (F == 0) return e;
+    const float P = e.x + e.y;
+    f2_t hs;
+    if (F == 1) {
+        hs.x = dpp_from_prev(e.y) + P;
+        hs.y = P + dpp_from_next(e.x);
+    } else if (F == 2) {
+        hs.x = (dpp_from_prev(P) + P) + dpp_from_next(e.x);
+        hs.y = (dpp_from_prev(e.y) + P) + dpp_from_next(P);
+    } else {
+        const float C = (dpp_from_prev(P) + P) + dpp_from_next(P);
+        hs.x = C + dpp_from_prev(dpp_from_prev(e.y));
+        hs.y = C + dpp_from_next(dpp_from_next(e.x));
+    }
+    return hs;
+}
+
+template <int F, int V, int TYW, bool NEFF>
+__global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs a)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_n[];
+    constexpr int HL = Patch2Geom<F>::HL, TX = Patch2Geom<F>::TX, TY = 4 * TYW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r0 = a.r0, r1 = a.r1;
+    const int halo0 = r0 + F;
+    const int M = r1 + 2 * HL + (r1 & 1);        // left / right margin: even, >= r1 + F and >= r1 + 2 HL
+    const int cols = TX + 2 * M, rows = TY + 2 * halo0;
+    float *lds = reinterpret_cast<float *>(nd_smem_n);               // [V][rows][cols]
+    int *ymap = reinterpret_cast<int *>(lds + V * rows * cols);
+    int *xmap = ymap + rows;
+
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int ty = (int)(b % a.tiles_y);
+    const int64_t i2 = a.clo2 + b / a.tiles_y;
+    // Lane pairs sit on GLOBAL (even, odd) columns whatever the tile or the written range: the two
+    // columns of a pair add their row sums in different groupings, and a pixel's value must not
+    // depend on how the raster was cut (multi-GPU row blocks, halo tiles).
+    const int64_t xs = a.clo1 - ((a.off1 + a.clo1) & 1);
+    const int64_t y0 = a.clo0 + (int64_t)ty * TY, x0 = xs + (int64_t)tx * TX;
+
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        __syncthreads();
+        nlm_stage(a, lds + v * rows * cols, ymap, xmap, rows, cols, a.off0 + y0 - halo0,
+                  a.off1 + x0 - M, i2, v, tid);
+    }
+
+    // this lane: tile columns 2 (lane - HL), + 1 (feeder lanes: columns outside the tile), rows
+    // wave*TYW .. wave*TYW + TYW - 1; LDS column of the pair's first element is even
+    const int cx = M + 2 * (lane - HL);
+    const int cy0 = halo0 + wave * TYW;
+    double tw[TYW][2], tsq[NEFF ? TYW : 1][2];
+    f2_t wmax[TYW], ws[TYW][V];
+#pragma unroll
+    for (int p = 0; p < TYW; ++p) {
+        tw[p][0] = tw[p][1] = 0.0;
+        if (NEFF) tsq[p][0] = tsq[p][1] = 0.0;
+        wmax[p] = (f2_t){0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < V; ++v) ws[p][v] = (f2_t){0.f, 0.f};
+    }
+    // the reference divides in double; reciprocals in float32 differ by ~1e-7 relative
+    const float inv_norm = (float)(1.0 / (double)a.dsq_norm);
+    const float exp2_scale = (float)(-1.4426950408889634 / a.h2);      // w = 2^(m * exp2_scale)
+    const f2_t inv_norm2 = (f2_t){inv_norm, inv_norm};
+    const f2_t neg_two_sigma2 = (f2_t){-(float)a.two_sigma2, -(float)a.two_sigma2};
+    const f2_t zero2 = (f2_t){0.f, 0.f};
+    f2_t ssum[TYW];
+#pragma unroll
+    for (int p = 0; p < TYW; ++p) ssum[p] = zero2;
+
+    for (int dy = -r0; dy <= r0; ++dy) {
+        f2_t twf[TYW];                    // NEFF = false: float32 partial sums of this search row
+#pragma unroll
+        for (int p = 0; p < TYW; ++p) twf[p] = (f2_t){0.f, 0.f};
+        for (int dx = -r1; dx <= r1; ++dx) {
+            if (dy == 0 && dx == 0) continue;
+            f2_t H[2 * F + 1], Q[2 * F + 1];      // rings: row sums, and sums of two adjacent rows
+#pragma unroll
+            for (int s = 0; s < TYW + 2 * F; ++s) {
+                // squared differences of this lane's two columns at image row (cy0 - F + s)
+                const int rr = cy0 - F + s;
+                f2_t e = (f2_t){0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float *pa = lds + v * rows * cols + rr * cols + cx;
+                    const float *qa = pa + dy * cols + dx;
+                    const f2_t pv = *reinterpret_cast<const f2_t *>(pa);      // 8-byte aligned
+                    const f2_t qv = (f2_t){qa[0], qa[1]};
+                    const f2_t df = pv - qv;
+                    e = __builtin_elementwise_fma(df, df, e);
+                }
+                constexpr int NR = 2 * F + 1;
+                H[s % NR] = patch2_row_sums<F>(e);
+                if (F >= 2 && s >= 1) Q[s % NR] = H[(s - 1) % NR] + H[s % NR];      // rows s-1, s
+                if (s >= 2 * F) {
+                    const int p = s - 2 * F;
+                    // the patch sum: rows p .. p + 2F, always grouped the same way relative to the
+                    // pixel's own row (pairs from the top, last row alone) -- the ring position of a
+                    // row depends on where the tile starts, the order of the additions must not
+                    f2_t S;
+                    if (F == 0) {
+                        S = H[s % NR];
+                    } else if (F == 1) {
+                        S = (H[(s - 2) % NR] + H[(s - 1) % NR]) + H[s % NR];
+                    } else if (F == 2) {
+                        S = (Q[(s - 3) % NR] + Q[(s - 1) % NR]) + H[s % NR];
+                    } else {
+                        S = ((Q[(s - 5) % NR] + Q[(s - 3) % NR]) + Q[(s - 1) % NR]) + H[s % NR];
+                    }
+                    ssum[p] = ssum[p] + S;          // NaN anywhere in the pixel's patch sums sticks here
+                    const f2_t t = __builtin_elementwise_fma(S, inv_norm2, neg_two_sigma2);
+                    // max(t, 0): a NaN would be dropped here, `ssum` remembers it (exact path below)
+                    const f2_t m = pk_max(t, zero2);
+                    const f2_t ma = m * exp2_scale;
+                    f2_t w;
+                    w.x = __builtin_amdgcn_exp2f(ma.x);
+                    w.y = __builtin_amdgcn_exp2f(ma.y);
+                    if (NEFF) {
+                        // the self weight solves a quadratic whose discriminant cancels: the two
+                        // weight sums it is made of are kept in double, like the reference's
+                        tw[p][0] = tw[p][0] + (double)w.x;
+                        tw[p][1] = tw[p][1] + (double)w.y;
+                        tsq[p][0] = tsq[p][0] + (double)w.x * (double)w.x;
+                        tsq[p][1] = tsq[p][1] + (double)w.y * (double)w.y;
+                    } else {
+                        twf[p] = twf[p] + w;
+                    }
+                    wmax[p] = pk_max(wmax[p], w);
+                    const int qr = cy0 + p + dy, qc = cx + dx;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const float *ap = lds + v * rows * cols + qr * cols + qc;
+                        const f2_t av = (f2_t){ap[0], ap[1]};
+                        // (float)((double)ws + (double)w * (double)a): the product of two floats is
+                        // exact in double, so the fused multiply-add rounds to the same value
+                        ws[p][v] = __builtin_elementwise_fma(w, av, ws[p][v]);
+                    }
+                }
+            }
+        }
+        if (!NEFF) {
+#pragma unroll
+            for (int p = 0; p < TYW; ++p) {
+                tw[p][0] = tw[p][0] + (double)twf[p].x;
+                tw[p][1] = tw[p][1] + (double)twf[p].y;
+            }
+        }
+    }
+
+    const bool feeder = (lane < HL) || (lane >= 64 - HL);
+    // Pixels whose largest float32 weight is (nearly) zero: the reference's double weights are
+    // still non-zero there and decide the self weight and the (denormal) sums, so those pixels
+    // are recomputed below exactly as the reference does.
+    unsigned exact_mask = 0;              // bit 2p + c
+#pragma unroll
+    for (int p = 0; p < TYW; ++p) {
+        const int64_t y = y0 + wave * TYW + p;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int64_t x = x0 + 2 * (lane - HL) + c;
+            if (feeder || !(y < a.chi0 && x < a.chi1 && x >= a.clo1)) continue;
+            const float wm = c ? wmax[p].y : wmax[p].x;
+            const float sp = c ? ssum[p].y : ssum[p].x;
+            if (!(wm >= 1e-30f) || !(sp == sp)) {
+                exact_mask |= 1u << (2 * p + c);
+                continue;
+            }
+            bool fail;
+            const double wself = nlm_self_weight(tw[p][c], NEFF ? tsq[p][c] : 0.0, (double)wm,
+                                                 a.n_eff, a.neff_policy, a.status, &fail);
+            if (!fail) {
+                const double total = tw[p][c] + wself;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float cv = lds[v * rows * cols + (cy0 + p) * cols + cx + c];
+                    const float wsv = c ? ws[p][v].y : ws[p][v].x;
+                    const float sfin = (float)((double)wsv + (wself * (double)cv));
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] =
+                        (float)((double)sfin / total);
+                }
+            }
+        }
+    }
+    if (__any(exact_mask != 0u)) {
+        for (int pc = 0; pc < 2 * TYW; ++pc) {
+            if (!((exact_mask >> pc) & 1u)) continue;
+            // nd/_filters.pyx:363-420 for this one pixel, from the staged tile
+            const int p = pc >> 1, c = pc & 1;
+            const int py = cy0 + p, pxc = cx + c;
+            double t_w = 0.0, t_sq = 0.0, m_w = 0.0;
+            float wsum[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) wsum[v] = 0.f;
+            for (int dy = -r0; dy <= r0; ++dy)
+                for (int dx = -r1; dx <= r1; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    double dsq = 0.0;
+                    for (int i = -F; i <= F; ++i)
+                        for (int j = -F; j <= F; ++j)
+#pragma unroll
+                            for (int v = 0; v < V; ++v) {
+                                const float *base = lds + v * rows * cols;
+                                const float df = base[(py + i) * cols + pxc + j] -
+                                                 base[(py + dy + i) * cols + pxc + dx + j];
+                                const float sq = df * df;
+                                dsq = dsq + (double)sq;
+                            }
+                    dsq = dsq / (double)a.dsq_norm;
+                    const double t = dsq - a.two_sigma2;
+                    const double m = (0.0 > t) ? 0.0 : t;
+                    const double w = exp((-m) / a.h2);
+                    t_w = t_w + w;
+                    t_sq = t_sq + (w * w);
+                    if (w > m_w) m_w = w;
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        wsum[v] = (float)((double)wsum[v] +
+                                          (w * (double)lds[v * rows * cols + (py + dy) * cols + pxc + dx]));
+                }
+            bool fail;
+            const double wself = nlm_self_weight(t_w, t_sq, m_w, a.n_eff, a.neff_policy, a.status, &fail);
+            if (!fail) {
+                const double total = t_w + wself;
+                const int64_t y = y0 + wave * TYW + p;
+                const int64_t x = x0 + 2 * (lane - HL) + c;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float cv = lds[v * rows * cols + py * cols + pxc];
+                    const float sfin = (float)((double)wsum[v] + (wself * (double)cv));
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] =
+                        (float)((double)sfin / total);
+                }
+            }
+        }
+    }
+}
+
+template <int F, int V>
+static void launch_patch2(const NlmTiledArgs &a, int64_t nslices, size_t lds, hipStream_t stream)
+{
+    constexpr int TYW = Patch2Rows<V>::TYW;
+    const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nslices;
+    if (a.n_eff >= 0)
+        hipLaunchKernelGGL((nlmeans_patch2_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256),
+                           lds, stream, a);
+    else
+        hipLaunchKernelGGL((nlmeans_patch2_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256),
+                           lds, stream, a);
+}
+
+template <int F>
+static bool launch_patch2_v(const NlmTiledArgs &a, int64_t nslices, size_t lds, hipStream_t stream)
+{
+    switch (a.nvars) {
+    case 1: launch_patch2<F, 1>(a, nslices, lds, stream); return true;
+    case 2: launch_patch2<F, 2>(a, nslices, lds, stream); return true;
+    case 3: launch_patch2<F, 3>(a, nslices, lds, stream); return true;
+    case 4: launch_patch2<F, 4>(a, nslices, lds, stream); return true;
+    }
+    return false;
+}
+
 template <int F, int V>
 static void launch_patch(const NlmTiledArgs &a, int64_t nslices, size_t lds, hipStream_t stream)
 {
@@ -897,6 +1218,26 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
     const uint32_t F0 = (patch_mode == 1) ? f[A0] : 0u, F1 = (patch_mode == 1) ? f[A1] : 0u;
     if (patch_mode == 0 && (f[A0] != 0 || f[A1] != 0)) return 0;
     if (F0 != F1 || F0 > 3 || nvars > 4) return 0;
+    static const bool no_patch2 = getenv("ND_AMD_NLM_PATCH1") != nullptr;
+    if (!no_patch2 && F0 >= 1) {
+        // cross-lane form: two columns per lane
+        const int hl = (F0 == 3) ? 2 : 1, tx2 = 2 * (64 - 2 * hl), tyw2 = (nvars == 1) ? Patch2Rows<1>::TYW : Patch2Rows<2>::TYW;
+        const int m = a.r1 + 2 * hl + (a.r1 & 1);
+        const size_t cols2 = (size_t)tx2 + 2 * (size_t)m, rows2 = 4 * (size_t)tyw2 + 2 * (size_t)(a.r0 + F0);
+        const size_t lds2 = (size_t)nvars * rows2 * cols2 * sizeof(float) + (rows2 + cols2) * sizeof(int);
+        a.tiles_x = (int)ceil_div(ex + 1, tx2);        // + 1: the tiles start on an even global column
+        a.tiles_y = (int)ceil_div(ey, 4 * tyw2);
+        if (lds2 <= 64 * 1024 && (int64_t)a.tiles_x * a.tiles_y * nsl <= 0x7fffffffLL) {
+            KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
+            bool ok2 = false;
+            switch (F0) {
+            case 1: ok2 = launch_patch2_v<1>(a, nsl, lds2, stream); break;
+            case 2: ok2 = launch_patch2_v<2>(a, nsl, lds2, stream); break;
+            default: ok2 = launch_patch2_v<3>(a, nsl, lds2, stream); break;
+            }
+            if (ok2) return 1;
+        }
+    }
     const int tyw = (nvars == 1) ? 16 : 8;
     a.tiles_x = (int)ceil_div(ex, 64);
     a.tiles_y = (int)ceil_div(ey, 4 * tyw);

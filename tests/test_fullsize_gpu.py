@@ -172,3 +172,45 @@ def test_filters_config_size_bands_match_scipy(device):
         check(kernel2d=kern)
     kernels.gaussian_filter(x, (0.0, 1.0, 1.0), out=out)
     check(sigma=1.0)
+
+
+@pytest.mark.parametrize('alpha', [1e-4, 0.01, 0.5])
+def test_dense_thresholds_whole_raster_equals_oracle(oracle, stack, alpha):
+    """The thresholds users pass (the reference's default alpha = 0.01, the tutorial's 1e-4) make
+    nearly every pixel change at nearly every date: the fused search kernels (streaming form up to
+    alpha = 0.05, register form above) against the oracle on the WHOLE 24 x 4096 x 4096 raster."""
+    import torch
+    from nd_amd import kernels
+    ch = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha, n=9)
+    torch.cuda.synchronize()
+    host = stack.cpu().numpy()
+    planes = [np.moveaxis(host[v], 0, -1) for v in range(4)]
+    want = oracle.change_detection_planes(planes, alpha, 9, njobs=16)
+    got = ch.cpu().numpy()
+    nbad = int((got != want).sum())
+    assert nbad == 0, '%d change-map bytes differ at alpha=%g' % (nbad, alpha)
+    assert (want.sum(axis=2) > 0).mean() > 0.4
+
+
+@pytest.mark.parametrize('env', [{'ND_AMD_FUSED_FORM': '0'}, {'ND_AMD_FUSED_FORM': '1'},
+                                 {'ND_AMD_FUSED_ALPHA': '0'}, {'ND_AMD_PM_FORM': '1'}])
+def test_every_kernel_form_gives_the_same_map(env):
+    """The host picks among several forms of the low-threshold search by alpha (streaming fused,
+    register fused, separate dense kernel; LDS-DMA or register-staged pixel-major pass A).  The
+    choice is about speed only: force each form in a fresh process and compare with the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py'), '--ny', '512',
+                          '--nx', '2048', '--alphas', '1e-4,0.01,0.2,0.6,0.99', '--steps', '1',
+                          '--cpu-rows', '512', '--layouts', 'planar,pm'],
+                         env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 10, out.stdout[-2000:]
+    for r in lines:
+        assert r['bytes_differing'] == 0, r

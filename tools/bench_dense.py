@@ -10,13 +10,22 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--k', type=int, default=24); ap.add_argument('--ny', type=int, default=4096); ap.add_argument('--nx', type=int, default=4096)
 ap.add_argument('--alphas', default='1e-4,0.01,0.5,0.9,0.99'); ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--cpu-rows', type=int, default=4096); ap.add_argument('--dtype', default='f32')
+ap.add_argument('--layouts', default='planar', help="planar and/or pm (the reference's (y, x, time) layout, C12 complex)")
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 dt_ = torch.float32 if a.dtype == 'f32' else torch.float64
 st = synth.wishart_c2_stack(a.k, a.ny, a.nx, looks=9, seed=1234, device=dev, change_frac=0.01, dtype=dt_)
 host = None
-for alpha in [float(x) for x in a.alphas.split(',')]:
-    fn = lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
+pm = None
+for layout, alpha in [(l, float(x)) for l in a.layouts.split(',') for x in a.alphas.split(',')]:
+    if layout == 'pm':
+        if pm is None:
+            yxt = [st[v].permute(1, 2, 0).contiguous() for v in range(4)]
+            c12 = torch.complex(yxt[1], yxt[2])
+            pm = (yxt[0], c12.real, c12.imag, yxt[3])
+        fn = lambda: kernels.change_detection_pixel_major(*pm, alpha=alpha, n=9)
+    else:
+        fn = lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
     for _ in range(2): out = fn()
     torch.cuda.synchronize()
     _lib.timing_enable(8 * a.steps + 8)
@@ -26,7 +35,7 @@ for alpha in [float(x) for x in a.alphas.split(',')]:
     kt = _lib.timing_collect(); _lib.timing_enable(0)
     by = {}
     for n_, ms in kt: by.setdefault(n_, []).append(ms)
-    res = {'alpha': alpha, 'ms': dt * 1e3, 'Mpx_per_s': a.ny * a.nx / dt / 1e6,
+    res = {'layout': layout, 'alpha': alpha, 'ms': dt * 1e3, 'Mpx_per_s': a.ny * a.nx / dt / 1e6,
            'kernels_ms': {n_: round(sum(v) / len(v), 4) for n_, v in by.items()},
            'flagged': float((out.sum(dim=2) > 0).float().mean().item()),
            'changes_per_px': float(out.sum().item()) / (a.ny * a.nx)}
