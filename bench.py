@@ -340,10 +340,33 @@ def extras(main, barrier, dev):
         dom = max(km, key=km.get)
         entry('OmnibusTest C2 %dt x %d x %d f32, alpha=%g (dense regime: %.3f of pixels change)'
               % (main.k, main.rows, main.nx, alpha, res['flagged_fraction']), dt, 5, main.npix, km,
-              roofline(dom, km[dom], main.read_bytes,
-                       note='FP64-issue bound search kernels; bytes = one read of the stack'),
+              roofline(dom, km[dom], main.alg_bytes,
+                       note='search fused into the streaming pass over the planes (VALU-issue bound: '
+                            '~4.1 k vector instructions per 64 pixels); bytes = planes read once + '
+                            'change map written once'),
               res['bad'] == 0, sample=res)
     del ch
+
+    # -- the same test on data in the reference's own layout ((y, x, time), C12 interleaved complex):
+    #    what OmnibusTest.apply(ds) receives from a reference-layout dataset
+    yxt = [main.stack[v].permute(1, 2, 0).contiguous() for v in range(4)]
+    c12 = torch.complex(yxt[1], yxt[2])
+    pmv = (yxt[0], c12.real, c12.imag, yxt[3])
+    del yxt
+    for alpha in (0.99, 0.01):
+        fn = lambda: kernels.change_detection_pixel_major(*pmv, alpha=alpha, n=a.looks)      # noqa: E731
+        dt, km, ch = timed(fn, 5, 2, barrier)
+        ref = kernels.change_detection(*main.stack, alpha=alpha, n=a.looks)
+        same = bool(torch.equal(ch, ref))
+        res = checks.omnibus_sample(main.stack, ch, alpha, a.looks, nsample=20000, seed=9)
+        dom = max(km, key=km.get)
+        entry('OmnibusTest C2 %dt x %d x %d f32 in the reference layout (y, x, time), C12 complex64, '
+              'alpha=%g' % (main.k, main.rows, main.nx, alpha), dt, 5, main.npix, km,
+              roofline(dom, km[dom], main.alg_bytes,
+                       note='LDS-DMA staging of pixel-major spans (global_load_lds_dwordx4)'),
+              res['bad'] == 0 and same, sample=res, equal_to_planar_map=same)
+    del ch, ref, c12, pmv
+    _free()
 
     # -- full-pol C3, config 4's single-GPU share
     class A:

@@ -149,7 +149,25 @@ struct OmniGlobalArgs {
     uint32_t *dense_idx;      // [kShards][segd]
     uint32_t segd;
     int dense_min;            // 65 = never
+    // Data-driven choice between the sparse design (this pass + pass B) and the fused search, made
+    // on the device: omnibus_c2_sample_kernel counts the candidates among `gate_n` sampled pixels
+    // into *gate; both variants are launched and the one the count does not favour returns at
+    // once.  gate_mode 0: no gate; 1: run only if the sample is dense; 2: only if it is sparse.
+    const uint32_t *gate;
+    uint32_t gate_n;
+    int gate_mode;
 };
+
+// dense <=> at least 1/8 of the sampled pixels pass the global screen (measured break-even of
+// pass A + pass B against the fused kernel: ~10 % candidates)
+template <typename T>
+__device__ __forceinline__ bool omni_gate_skip(const OmniGlobalArgs<T> &g)
+{
+    if (g.gate_mode == 0) return false;
+    const uint32_t hits = __builtin_nontemporal_load(g.gate);
+    const bool dense = hits * 8u >= g.gate_n;
+    return (g.gate_mode == 1) != dense;
+}
 
 constexpr int kGlobalThreads = 256;
 #ifndef ND_RETAIN_THREADS
@@ -327,6 +345,7 @@ template <typename T, int KMAX, bool EXACT, bool STATS>
 __global__ void __launch_bounds__(kRetainThreads)
 omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 {
+    if (omni_gate_skip(g)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t b = blockIdx.x;
@@ -455,6 +474,53 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
         const int tail0 = head + (nvec << 4);
         if (tail0 + tid < nb) ob[tail0 + tid] = 0;
     }
+}
+
+// -----------------------------------------------------------------------------------------
+// How dense is the raster?  A few hundred pixel blocks spread over it, one pixel per thread,
+// streaming fold of the whole series and the same global screen as pass A; the number of
+// candidates goes to *gate_out.  ~1 % of the data: microseconds.
+// -----------------------------------------------------------------------------------------
+template <typename T>
+struct OmniSampleArgs {
+    const T *c11, *c12r, *c12i, *c22;
+    int64_t nx, blocks_per_row, block_stride;   // sampled pixel block = blockIdx.x * block_stride
+    int64_t sy, sx, st;
+    int m11, m12, m22;                          // element multipliers (pixel-major inputs: 1 or 2)
+    int k;
+    double nlooks;
+    OmniTabEntry e;
+    uint32_t *gate_out;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kRetainThreads) omnibus_c2_sample_kernel(const OmniSampleArgs<T> a)
+{
+    const int tid = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * a.block_stride;
+    const int64_t row = b / a.blocks_per_row;
+    const int64_t x0 = (b - row * a.blocks_per_row) * (int64_t)kRetainThreads + tid;
+    const bool in = x0 < a.nx;
+    const int64_t off0 = row * a.sy + (in ? x0 : a.nx - 1) * a.sx;
+    Accum<T> A;
+    A.reset();
+    for (int t0 = 0; t0 < a.k; t0 += 4) {
+        T q[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t o = off0 + (int64_t)(t0 + u < a.k ? t0 + u : a.k - 1) * a.st;
+            q[u][0] = a.c11[o * a.m11];
+            q[u][1] = a.c12r[o * a.m12];
+            q[u][2] = a.c12i[o * a.m12];
+            q[u][3] = a.c22[o * a.m22];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 + u < a.k) A.step(q[u][0], q[u][1], q[u][2], q[u][3]);
+    }
+    const bool flag = in && (z_approx<T>(A, a.k, a.nlooks, a.e) >= a.e.zlo_a);
+    const unsigned long long m = __ballot(flag);
+    if ((tid & 63) == 0 && m != 0ull) atomicAdd(a.gate_out, (unsigned)__popcll(m));
 }
 
 // -----------------------------------------------------------------------------------------
@@ -707,9 +773,9 @@ template <typename T, int KMAX, bool STATS>
 __global__ void __launch_bounds__(64)
 omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const OmniPmDmaArgs<T> pm)
 {
+    if (omni_gate_skip(g)) return;
     extern __shared__ __align__(16) unsigned char nd_smem_dma[];
     T *img = reinterpret_cast<T *>(nd_smem_dma);
-    constexpr int VE = 16 / (int)sizeof(T);                // elements per 16-byte transfer
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     const int64_t px0 = b * 64;
@@ -1165,6 +1231,7 @@ template <typename T, int KMAX, bool EXACT>
 __global__ void __launch_bounds__(kRetainThreads, 2)
 omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg)
 {
+    if (omni_gate_skip(g)) return;
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1399,6 +1466,7 @@ __global__ void __launch_bounds__(MODE == 2 ? 64 : kRetainThreads)
 omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg,
                          const OmniPmDmaArgs<T> pm)
 {
+    if (omni_gate_skip(g)) return;
     constexpr int kThreads = MODE == 2 ? 64 : kRetainThreads;
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
     extern __shared__ __align__(16) unsigned char nd_smem_stream[];    // MODE 2: the wave's images
@@ -2189,6 +2257,17 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         return e ? atof(e) : 0.75;
     }();
     const bool fused = retain && dense_ok && !stats && g.dense_min <= 64 && alpha < fused_alpha;
+    // The threshold only says that dense waves are LIKELY; whether they are is a property of the
+    // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
+    // is therefore made on the device from a sample (omnibus_c2_sample_kernel): both variants are
+    // launched, the unfavoured one returns at once.  ND_AMD_GATE=0: decide by alpha alone.
+    static const bool gate_env = [] {
+        const char *e = getenv("ND_AMD_GATE");
+        return e ? atoi(e) != 0 : true;
+    }();
+    g.gate = flag_count + 2;            // word 2 of shard 0's counter line (zeroed with the counters)
+    g.gate_n = 0;
+    g.gate_mode = 0;
     {
         const size_t per = (size_t)k * 4 * sizeof(T);
         size_t cap = retain ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
@@ -2215,6 +2294,37 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                   (long long)nblocks);
         return ND_AMD_EUNSUPPORTED;
     }
+    // returns true when the sample was taken (the kernels launched next may then be gated)
+    auto take_sample = [&]() -> bool {
+        const int64_t sblocks_total = ceil_div(npix, (int64_t)kRetainThreads);
+        if (!gate_env || !retain || sblocks_total < 4096) return false;
+        OmniSampleArgs<T> sa;
+        sa.c11 = g.c11;
+        sa.c12r = g.c12r;
+        sa.c12i = g.c12i;
+        sa.c22 = g.c22;
+        sa.nx = g.nx;
+        sa.blocks_per_row = ceil_div(g.nx, (int64_t)kRetainThreads);
+        const int64_t total = sa.blocks_per_row * g.nrows;
+        const int64_t nsb = 512;
+        sa.block_stride = total / nsb;
+        sa.sy = sy;
+        sa.sx = sx;
+        sa.st = st;
+        sa.m11 = pm_ids ? (int)pm_ids[0] : 1;
+        sa.m12 = pm_ids ? (int)pm_ids[1] : 1;
+        sa.m22 = pm_ids ? (int)pm_ids[3] : 1;
+        sa.k = (int)k;
+        sa.nlooks = g.nlooks;
+        sa.e = g.e;
+        sa.gate_out = flag_count + 2;
+        g.gate_n = (uint32_t)(nsb * kRetainThreads);
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SAMPLE, stream);
+        hipLaunchKernelGGL((omnibus_c2_sample_kernel<T>), dim3((unsigned)nsb), dim3(kRetainThreads), 0,
+                           stream, sa);
+        return true;
+    };
+    bool gated = false;
     if (pm_ids != nullptr) {
         if (!retain || !flat) {
             set_error("nd_amd_omnibus_c2_pixel_major: %lld dates exceed the register-retaining sizes",
@@ -2254,12 +2364,19 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             }
             const size_t lds_dma = (size_t)off * sizeof(T);
             const dim3 gridw((unsigned)ceil_div(npix, 64)), blockw(64);
-            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
             if (fused_pm) {
-                // low threshold: the streaming search, its dates served from the LDS images
+                // low threshold: the streaming search, its dates served from the LDS images --
+                // if the sample confirms that the raster is dense
+                gated = take_sample();
                 const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+                g.gate_mode = gated ? 1 : 0;
+                KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
                 hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 2>), gridw, blockw, lds_dma, stream, g, tab, scr, dm);
-            } else
+                g.gate_mode = gated ? 2 : 0;
+                g.dense_min = 65;                            // the sparse form lists pixel by pixel
+            }
+            if (!fused_pm || gated) {
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
 #define ND_LAUNCH_DMA(KM)                                                                              \
     do {                                                                                              \
         if (stats)                                                                                    \
@@ -2274,6 +2391,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             else
                 ND_LAUNCH_DMA(24);
 #undef ND_LAUNCH_DMA
+            }
+            g.gate_mode = 0;
         } else {
         const size_t lds = 2 * (size_t)kRetainThreads * (size_t)(k | 1) * sizeof(T);
         if (lds > 64 * 1024) {
@@ -2303,8 +2422,11 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
 #undef ND_LAUNCH_PM
         }
     } else if (fused) {
+        gated = take_sample();
         const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
-        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+        g.gate_mode = gated ? 1 : 0;
+        {
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
         // Two forms of the fused kernel, same map: the streaming one wins while searches beyond
         // three dates are rare (a row needs one with probability ~ alpha per pixel): measured
         // 2.3 vs 3.1 ms at alpha = 0.01, break-even at 0.05, 6.3 vs 5.1 ms at 0.2 (24 x 4096^2).
@@ -2325,6 +2447,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             else
                 hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0>), grid, block, 0, stream, g, tab, scr, nopm);
         }
+        }
+        if (gated) {
+            // the sparse design, should the sample say so (dense waves it still meets go to the
+            // separate dense kernel below)
+            g.gate_mode = 2;
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+            launch_retain<T>(g, tab, nblocks, stats, stream);
+        }
+        g.gate_mode = 0;
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (retain)
@@ -2337,7 +2468,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     ND_HIP_CHECK(hipGetLastError());
 
     // ---- dense waves (none in the sparse regime: every block then leaves at once) ----
-    if (retain && g.dense_min <= 64 && !fused) {
+    if (retain && g.dense_min <= 64 && (!fused || gated) && pm_ids == nullptr) {
         OmniDenseArgs<T> d;
         d.c11 = g.c11;
         d.c12r = g.c12r;
