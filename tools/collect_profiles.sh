@@ -20,5 +20,11 @@ python3 $R/tools/summarize_prof.py $OUT/dstats $OUT/dfetch $OUT/dwrite $OUT/omni
 bash $R/tools/pmc_dense.sh $1/dense_pmc 0.01 > /dev/null 2>&1
 bash $R/tools/pmc_nlm.sh $1/nlm_pmc > /dev/null 2>&1
 (cd $R && python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err)
+cp $OUT/stats/p_kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
+cp $OUT/dstats/p_kernel_stats.csv $OUT/dense_kernel_stats.csv 2>/dev/null
+cp $OUT/dense_pmc/summary.txt $OUT/dense_pmc_summary.txt 2>/dev/null
+cp $OUT/nlm_pmc/summary.txt $OUT/nlm_pmc_summary.txt 2>/dev/null
+# the raw traces are large (the merge back is limited to 64 MiB): keep the summaries only
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/dstats $OUT/dfetch $OUT/dwrite $OUT/dense_pmc $OUT/nlm_pmc
 ls $OUT
 cat $OUT/omnibus_rocprof.txt $OUT/omnibus_dense_rocprof.txt

@@ -17,12 +17,12 @@ import sys
 
 
 def kernel_stats(d):
-    f = glob.glob(d + '/*/*_kernel_stats.csv')[0]
+    f = (glob.glob(d + '/*/*_kernel_stats.csv') + glob.glob(d + '/*kernel_stats.csv'))[0]
     return [r for r in csv.DictReader(open(f)) if 'nd_amd' in r['Name']]
 
 
 def pmc(d, counter):
-    f = glob.glob(d + '/*/*_counter_collection.csv')[0]
+    f = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*counter_collection.csv'))[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if 'nd_amd' in r['Kernel_Name'] and r['Counter_Name'] == counter:
