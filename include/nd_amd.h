@@ -86,6 +86,10 @@ const char *nd_amd_last_error(void);
  *              *min_bytes, the smallest size the call accepts; anything in
  *              between trades speed on change-rich rasters for memory.
  * njobs has no equivalent: the whole raster is one launch.
+ * Series length: any k >= 1; parity-tested up to k = 130.  The first call
+ * with a new (k, n_looks, alpha, dtype) tabulates one pair of decision bounds
+ * per sub-series length on the host (O(k^2) work, cached); their safety
+ * margin grows with k (see omni_bounds) so that very long series stay exact.
  * ---------------------------------------------------------------------- */
 size_t nd_amd_omnibus_c2_workspace_bytes(int dtype, int64_t ny, int64_t nx, int64_t k,
                                          size_t *min_bytes);

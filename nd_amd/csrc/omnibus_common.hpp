@@ -215,7 +215,12 @@ static void omni_bounds(int j, int a2, double omega2, double lgam, double alpha,
     if (j < 2) return;
     if (!(omega2 >= 0.0 && omega2 <= 1.0) || !(alpha == alpha)) return;
     const double ulp = sizeof(T) == 4 ? 5.9604644775390625e-08 : 1.1102230246251565e-16;
-    const double margin = 16.0 * ulp * (1.0 + 2.0 * omega2) + 1e-11;
+    // the device's double evaluation: ~1e-13 from the series, plus the prefactor
+    // exp(a ln x - x - lgamma(a + 1)), whose exponent carries ~a (1 + ln a) eps of absolute
+    // rounding error -- negligible at a = 2 (k - 1) <= 100, 2e-10 for series of 10^4 dates
+    const double a_half = 0.5 * (double)a2;
+    const double margin = 16.0 * ulp * (1.0 + 2.0 * omega2) + 1e-11 +
+                          8.0 * a_half * (1.0 + log(a_half + 2.0)) * 1.1102230246251565e-16;
     auto Pz = [&](double z) {
         double p1, p2;
         host_chisq_pair(z, a2, lgam, &p1, &p2);

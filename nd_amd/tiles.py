@@ -144,21 +144,30 @@ def exchange_halo_(shard, group=None):
     ext, dim, lo, hi, n = shard.ext, shard.dim, shard.lo, shard.hi, shard.n_local
     halo = shard.halo
     ops, landing = [], []
+    # RCCL moves device memory itself.  A `gloo` group (CPU tests, or several ranks sharing one
+    # GPU, which RCCL refuses) only moves host memory: halo pieces of device shards are staged
+    # through host buffers there -- halo-sized copies, the block still never moves.
+    via_host = ext.is_cuda and dist.get_backend(group) == 'gloo'
+
+    def send_rows(a, b, peer):
+        piece = _rows(ext, dim, a, b).contiguous()
+        if via_host:
+            piece = piece.cpu()
+        ops.append(dist.P2POp(dist.isend, piece, _peer(group, peer), group))
 
     def recv_into(view, peer):
-        buf = view if view.is_contiguous() else torch.empty(view.shape, dtype=view.dtype,
-                                                            device=view.device)
+        direct = view.is_contiguous() and not via_host
+        buf = view if direct else torch.empty(view.shape, dtype=view.dtype,
+                                              device='cpu' if via_host else view.device)
         ops.append(dist.P2POp(dist.irecv, buf, _peer(group, peer), group))
         if buf is not view:
             landing.append((view, buf))
 
     if rank > 0:                                   # my first rows go up, rank-1's last rows come in
-        ops.append(dist.P2POp(dist.isend, _rows(ext, dim, lo, lo + halo).contiguous(),
-                              _peer(group, rank - 1), group))
+        send_rows(lo, lo + halo, rank - 1)
         recv_into(_rows(ext, dim, 0, lo), rank - 1)
     if rank < world - 1:
-        ops.append(dist.P2POp(dist.isend, _rows(ext, dim, lo + n - halo, lo + n).contiguous(),
-                              _peer(group, rank + 1), group))
+        send_rows(lo + n - halo, lo + n, rank + 1)
         recv_into(_rows(ext, dim, lo + n, lo + n + hi), rank + 1)
     for req in dist.batch_isend_irecv(ops):
         req.wait()

@@ -1,4 +1,12 @@
-"""Two-GPU checks of the tile layer with the REAL HIP kernels and RCCL (skipped on a one-GPU box):
+"""Multi-rank checks of the tile layer with the REAL HIP kernels.
+
+  * `test_shared_gpu_...`: three fresh processes that SHARE the one GPU of a development / driver
+    box, torch.distributed over `gloo` (RCCL refuses two ranks on one device; the halo pieces of
+    the device shards are staged through the host, nd_amd/tiles.py): the same worker as the RCCL
+    test below, so the sharded kernels, the in-place margin exchange on device buffers and the
+    global-edge reflection run across ranks on every box;
+
+Two-GPU checks (skipped on a one-GPU box):
 
   * torch.distributed over `nccl`, one fresh process per GPU: halo exchange into the shard margins,
     then boxcar_rows / nlmeans_rows / nlmeans_then_omnibus on tile+halo, against the unsharded
@@ -33,15 +41,19 @@ def _free_port():
     return p
 
 
-def _nccl_worker(rank, world, port, ret):
+def _rank_worker(rank, world, port, ret, backend='nccl', shared_gpu=False):
     import torch
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(rank)
-    dev = torch.device('cuda', rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    idx = 0 if shared_gpu else rank
+    torch.cuda.set_device(idx)
+    dev = torch.device('cuda', idx)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from nd_amd import kernels, tiles
         k, ny, nx = 6, 301, 517                       # odd sizes: unequal blocks, ragged tiles
@@ -86,20 +98,34 @@ def _nccl_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@needs2
-def test_nccl_row_sharded_kernels_equal_unsharded():
+def _run_ranks(world, backend, shared_gpu):
     import torch.multiprocessing as mp
-    world = 2
     port = _free_port()
     ctx = mp.get_context('spawn')
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, ret, backend, shared_gpu))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
+    for p in procs:
+        if p.is_alive():                       # never leave a rank behind on the GPU box
+            p.kill()
+            p.join()
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert sorted(ret.keys()) == list(range(world))
+
+
+@needs2
+def test_nccl_row_sharded_kernels_equal_unsharded():
+    _run_ranks(2, 'nccl', shared_gpu=False)
+
+
+def test_shared_gpu_row_sharded_kernels_equal_unsharded():
+    """Three ranks on ONE GPU (gloo rendezvous, halos staged through the host): interior rank with
+    two neighbours, unequal blocks (301 rows -> 101 / 101 / 99)."""
+    _run_ranks(3, 'gloo', shared_gpu=True)
 
 
 @needs2
