@@ -363,19 +363,31 @@ typedef float nlm_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRollRowsPerWave = 13;          // (32 + 2 * 10) rows over 4 waves
 constexpr int kRollR0Max = 10;
 
-__device__ __forceinline__ float nlm_div_rounded(float s, double total, double inv_total)
+// res[i] = (float)((double)s[i] / total) for four sums, without the divisions: s * (1/total) is
+// within 3 ulp of the correctly rounded quotient, so both round to the same float unless the
+// product sits within a few ulp of a float rounding boundary or leaves the normal float range --
+// then (any lane of the wave, any of the four: a wave-uniform and very rare branch) divide.  The
+// branch must stay a branch: if-converted, every output pays a double-precision division.
+__device__ __forceinline__ void nlm_div_rounded4(const float s[4], double total, double inv_total,
+                                                 float res[4])
 {
-    // (float)((double)s / total) without the division: s * (1/total) is within 3 ulp of the
-    // correctly rounded quotient, so both round to the same float unless the product sits within a
-    // few ulp of a float rounding boundary or leaves the normal float range -- then divide.
-    const double sd = (double)s;
-    double q = sd * inv_total;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(q);
-    const unsigned lo = (unsigned)bits & 0x1fffffffu;
-    const unsigned e = (unsigned)(bits >> 52) & 0x7ffu;
-    const bool risky = (lo - 0x0ffffff8u) <= 16u || e < 1023u - 125u || e > 1023u + 126u;
-    if (risky) q = sd / total;
-    return (float)q;
+    double q[4];
+    bool risky = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        q[i] = (double)s[i] * inv_total;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(q[i]);
+        const unsigned lo = (unsigned)bits & 0x1fffffffu;
+        const unsigned e = (unsigned)(bits >> 52) & 0x7ffu;
+        risky |= (lo - 0x0ffffff8u) <= 16u || (e - (1023u - 125u)) > 251u;
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(risky) != 0ull, 0)) {
+        asm volatile("" ::: "memory");          // not speculated, not if-converted
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = (double)s[i] / total;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) res[i] = (float)q[i];
 }
 
 // R0T >= 0: the row radius is the compile-time constant R0T (the row loop unrolls and every
@@ -549,14 +561,14 @@ __global__ void __launch_bounds__(256) nlmeans_window_roll_kernel(const NlmTiled
             for (int py = 0; py < 4; ++py) {
                 const int64_t y = y0 + ly + py;
                 if (y < a.chi0) {
-                    float res[4];
+                    float res[4], sv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float ws = (py & 1) ? acc[py >> 1][i].y : acc[py >> 1][i].x;
                         // self term last (nd/_filters.pyx:417-420), weights are exactly 1 / wself
-                        const float sv = (float)((double)ws + (wself * (double)C[py * COLSP + i]));
-                        res[i] = nlm_div_rounded(sv, total, inv_total);
+                        sv[i] = (float)((double)ws + (wself * (double)C[py * COLSP + i]));
                     }
+                    nlm_div_rounded4(sv, total, inv_total, res);
                     float *o = a.out + i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x0 + lx;
                     if (vec_ok && x0 + lx + 3 < a.chi1) {
                         *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
@@ -572,6 +584,262 @@ __global__ void __launch_bounds__(256) nlmeans_window_roll_kernel(const NlmTiled
         if (has_next) store_plane((int)(nxt % nzr));
         __syncthreads();
     }
+}
+
+// ---- patch_mode 0, f > 0, window of THREE planes along the third axis, streaming form ---------
+// The tutorial's filter (NLMeansFilter(dims=('time','y','x'), r=(1,3,3), f=1)) has a window of
+// three dates.  The ring kernel above keeps those three planes in LDS (62 KB per block at R = 3:
+// two blocks per CU) and reads every staged row once per output slice.  Here ONE plane is consumed
+// at a time and serves the three output slices whose windows hold it: the plane of step s is the
+// dz = 0 plane of slice q + 1, the dz = 1 plane of slice q and the dz = 2 plane of slice q - 1
+// (q = first slice - 1 + s; the staged sequence zmap(f - 1), zmap(f), ..., zmap(l + 1) holds for
+// every slice its three planes in the reference's visiting order, whole-sample reflection at the
+// ends of the axis included, because slice i's planes (dz = 1, 2) are slice i + 1's planes
+// (dz = 0, 1)).  A thread keeps three sets of 4 x 4 running sums:
+//   ab[py][i] = (.x: slice q - 1, finishing; .y: slice q) -- the two receive the SAME element at
+//               the same step of their sums (only the window centre of slice q is replaced by
+//               +0.0), so every addition is packed, with no unpaired border rows;
+//   c[pr][i]  = slice q + 1, starting, packed over vertically adjacent outputs as in the ring form.
+// Staging is LDS-DMA (buffer_load_dword ... lds: memory -> LDS without passing through registers,
+// per-lane source offsets carry the reflection) into the second of two plane slots while the first
+// is consumed; one barrier per step.  41 KB of LDS and < 128 VGPRs: three blocks per CU, and a
+// third of the ring form's LDS reads.
+typedef __attribute__((address_space(3))) float nlm_lds_f32;
+
+// OY = output rows per thread (4: 256 threads per 128 x 32 tile; 2: 512 threads, half the running
+// sums per thread and twice the waves per CU), WPE = waves per SIMD the register budget is set for.
+template <int R, int OY, int WPE>
+__global__ void __launch_bounds__(32 * (kWinTY / OY), WPE) nlmeans_window_stream3_kernel(const NlmTiledArgs a)
+{
+    constexpr int NT = 32 * (kWinTY / OY), NWAVES = NT / 64;
+    constexpr int NW = ((2 * R + 4) + 3) / 4 * 4;      // floats a thread reads from one staged row
+    constexpr int COLSP = kWinTX - 4 + NW;             // row pitch (multiple of 4)
+    constexpr int ROWS = kWinTY + 2 * R;
+    constexpr int PSZ = ROWS * COLSP;
+    constexpr int NPRE = (ROWS + NWAVES - 1) / NWAVES; // staged rows per wave
+    extern __shared__ __align__(16) unsigned char nd_smem_s3[];
+    float *slots = reinterpret_cast<float *>(nd_smem_s3);         // [2][PSZ]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int ty = (int)(b % a.tiles_y);
+    const int v = (int)(b / a.tiles_y);
+    const int64_t y0 = a.clo0 + (int64_t)ty * kWinTY, x0 = a.clo1 + (int64_t)tx * kWinTX;
+    const int lx = (tid % 32) * 4, ly = (tid / 32) * OY;
+
+    const double nq = (double)(3 * (2 * R + 1) * (2 * R + 1) - 1);
+    bool fail;
+    const double wself = nlm_self_weight(nq, nq, 1.0, a.n_eff, a.neff_policy, a.status, &fail);
+    const double total = nq + wself;
+    const double inv_total = 1.0 / total;
+
+    // A descriptor per plane, a wave-uniform row offset (scalar) and one 32-bit byte offset per
+    // lane and staged column.  (Row offsets inside a plane fit 31 bits: checked on the host.)
+    int xoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int m = nlm_reflect_i(a.off1 + x0 - R + lane + 64 * j, a.G1) - (int)a.off1;
+        xoff[j] = 4 * (m < 0 ? 0 : (m >= (int)a.N1 ? (int)a.N1 - 1 : m));
+    }
+    int roff[NPRE];
+    {
+        const int64_t gy0 = a.off0 + y0 - R;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            int m = nlm_reflect_i(gy0 + wave + NWAVES * u, a.G0) - (int)a.off0;
+            m = m < 0 ? 0 : (m >= (int)a.N0 ? (int)a.N0 - 1 : m);
+            roff[u] = __builtin_amdgcn_readfirstlane(m * (int)a.si0 * 4);
+        }
+    }
+    const float *base = a.arr + (int64_t)v * a.si3;
+
+    auto stage = [&](int64_t p, int slot) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + p * a.si2), 0,
+                                                            0x7fffffff, 0x00020000);
+        nlm_lds_f32 *dst = (nlm_lds_f32 *)(slots + slot * PSZ + wave * COLSP);
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            if (wave + NWAVES * u < ROWS) {
+                nlm_lds_f32 *rp = dst + NWAVES * u * COLSP;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, rp, 4, xoff[0], roff[u], 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, rp + 64, 4, xoff[1], roff[u], 0, 0);
+                if (lane < 2 * R) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, rp + 128, 4, xoff[2], roff[u], 0, 0);
+            }
+        }
+    };
+    auto zmap = [&](int64_t q) {
+        int64_t zz = (int64_t)nlm_reflect_i(a.offz + q, a.Gz) - a.offz;
+        return zz < 0 ? (int64_t)0 : (zz >= a.N2 ? a.N2 - 1 : zz);
+    };
+
+    const int64_t first = a.clo2, last = a.chi2 - 1;
+    const int nsteps = (int)(last - first) + 3;
+    stage(zmap(first - 1), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const bool vec_ok = ((((uintptr_t)a.out) & 15) == 0) && ((a.so0 | a.so2 | a.so3 | x0) & 3) == 0;
+
+    nlm_f32x2 ab[OY][4], c[OY / 2][4];
+    float cen[OY][4];              // window-centre values of slice q - 1 (read while its plane was staged)
+#pragma unroll
+    for (int py = 0; py < OY; ++py)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ab[py][i] = (nlm_f32x2){0.f, 0.f};
+            cen[py][i] = 0.f;
+        }
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int64_t q = first - 1 + s;
+        const bool has_next = s + 1 < nsteps;
+        if (has_next) stage(zmap(q + 1), (s + 1) & 1);
+        const float *P = slots + (s & 1) * PSZ + ly * COLSP + lx;
+#pragma unroll
+        for (int pr = 0; pr < OY / 2; ++pr)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[pr][i] = (nlm_f32x2){0.f, 0.f};
+
+#pragma unroll
+        for (int ry = 0; ry < OY + 2 * R; ++ry) {
+            float w[NW];
+            const float4 *rp = reinterpret_cast<const float4 *>(P + ry * COLSP);
+#pragma unroll
+            for (int cc = 0; cc < NW / 4; ++cc) {
+                const float4 t = rp[cc];
+                w[4 * cc + 0] = t.x;
+                w[4 * cc + 1] = t.y;
+                w[4 * cc + 2] = t.z;
+                w[4 * cc + 3] = t.w;
+            }
+            // slices q - 1 and q: this row is window row d of output row py
+#pragma unroll
+            for (int py = 0; py < OY; ++py) {
+                const int d = ry - py;
+                if (d >= 0 && d <= 2 * R) {
+#pragma unroll
+                    for (int dx = 0; dx < 2 * R + 1; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float x = w[dx + i];
+                            const nlm_f32x2 t = {x, (d == R && dx == R) ? 0.f : x};
+                            ab[py][i] = ab[py][i] + t;
+                        }
+                }
+            }
+            // slice q + 1 (no centre in its first plane): vertical pairs
+#pragma unroll
+            for (int pr = 0; pr < OY / 2; ++pr) {
+                const int du = ry - 2 * pr, dl = du - 1;
+                const bool vu = du >= 0 && du <= 2 * R, vl = dl >= 0 && dl <= 2 * R;
+                if (vu && vl) {
+#pragma unroll
+                    for (int dx = 0; dx < 2 * R + 1; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float x = w[dx + i];
+                            c[pr][i] = c[pr][i] + (nlm_f32x2){x, x};
+                        }
+                } else if (vu) {
+#pragma unroll
+                    for (int dx = 0; dx < 2 * R + 1; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) c[pr][i].x = c[pr][i].x + w[dx + i];
+                } else if (vl) {
+#pragma unroll
+                    for (int dx = 0; dx < 2 * R + 1; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) c[pr][i].y = c[pr][i].y + w[dx + i];
+                }
+            }
+            // Keep the rows apart.  The sums of slice q + 1 are only needed when the roles move on,
+            // and left alone the optimiser sinks all their additions below the output code -- with
+            // the values of every staged row alive until then (254 VGPRs at R = 3).  The empty asm
+            // statements pin the running sums to this point of the program.
+#pragma unroll
+            for (int pr = 0; pr < OY / 2; ++pr)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(c[pr][i]));
+#pragma unroll
+            for (int py = 0; py < OY; ++py)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ab[py][i]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // slice q - 1 is complete: self term last (nd/_filters.pyx:417-420), then the mean
+        if (s >= 2 && !fail) {
+            const int64_t i2 = q - 1;
+#pragma unroll
+            for (int py = 0; py < OY; ++py) {
+                const int64_t y = y0 + ly + py;
+                if (y < a.chi0) {
+                    float res[4], sv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        sv[i] = (float)((double)ab[py][i].x + (wself * (double)cen[py][i]));
+                    nlm_div_rounded4(sv, total, inv_total, res);
+                    float *o = a.out + i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x0 + lx;
+                    if (vec_ok && x0 + lx + 3 < a.chi1) {
+                        *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (x0 + lx + i < a.chi1) o[i] = res[i];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the centre values of slice q for its last step, then the roles move on (the compiler
+        // barrier keeps the values of the row reads above from being carried down here instead of
+        // being read again: 4 OY registers for most of the step)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int py = 0; py < OY; ++py) {
+            const float *cr = P + (py + R) * COLSP + R;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                cen[py][i] = cr[i];
+                ab[py][i].x = ab[py][i].y;
+                ab[py][i].y = (py & 1) ? c[py >> 1][i].y : c[py >> 1][i].x;
+            }
+        }
+        // the next plane has landed (this wave's transfers) and every wave is done with this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+static bool launch_stream3(const NlmTiledArgs &a, int64_t nb, hipStream_t stream)
+{
+    auto lds = [](int R) {
+        const size_t nw = ((2 * (size_t)R + 4) + 3) / 4 * 4;
+        return 2 * (size_t)(kWinTY + 2 * R) * (kWinTX - 4 + nw) * sizeof(float);
+    };
+    // 512 threads x (2 x 4) outputs by default; the 256-thread form (4 x 4 outputs per thread, half
+    // the waves) measures the same to 1 % -- the kernel is bound by VALU issue, not by latency
+    // (profiles/r02_nlmeans_window_pmc.txt)
+    static const bool oy4 = getenv("ND_AMD_NLM_S3_OY4") != nullptr;
+    const dim3 grid((unsigned)nb);
+#define ND_S3(RR)                                                                                          \
+    if (oy4)                                                                                               \
+        hipLaunchKernelGGL((nlmeans_window_stream3_kernel<RR, 4, 3>), grid, dim3(256), lds(RR), stream, a); \
+    else                                                                                                   \
+        hipLaunchKernelGGL((nlmeans_window_stream3_kernel<RR, 2, 4>), grid, dim3(512), lds(RR), stream, a); \
+    return true
+    switch (a.r1) {
+    case 1: ND_S3(1);
+    case 2: ND_S3(2);
+    case 3: ND_S3(3);
+    case 4: ND_S3(4);
+    case 5: ND_S3(5);
+    default: return false;
+    }
+#undef ND_S3
 }
 
 template <int R1>
@@ -1189,6 +1457,15 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
         a.tiles_x = (int)ceil_div(ex, kWinTX);
         a.tiles_y = (int)ceil_div(ey, kWinTY);
         static const bool no_roll = getenv("ND_AMD_NLM_NOROLL") != nullptr;
+        static const bool no_stream3 = getenv("ND_AMD_NLM_NOSTREAM3") != nullptr;
+        if (!no_roll && !no_stream3 && rz == 1 && a.r0 == a.r1 && a.r1 >= 1 && a.r1 <= 5 &&
+            a.si0 >= 0 && (a.N0 * a.si0 + a.N1) * 4 < 0x7fffffffLL) {
+            const int64_t nbr = (int64_t)a.tiles_x * a.tiles_y * nvars;
+            if (nbr <= 0x7fffffffLL) {
+                KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
+                if (launch_stream3(a, nbr, stream)) return 1;
+            }
+        }
         if (!no_roll && a.r0 <= kRollR0Max && a.r1 <= 10) {
             const size_t nw = ((2 * (size_t)a.r1 + 4) + 3) / 4 * 4;
             const size_t lds_r = (size_t)(2 * rz + 1) * (kWinTY + 2 * a.r0) * (kWinTX - 4 + nw) * sizeof(float);

@@ -63,6 +63,8 @@ def _rank_worker(rank, world, port, ret, backend='nccl', shared_gpu=False):
         full[2] -= 0.75
         full[1] *= 0.3
         full[2] *= 0.3
+        full[0, k // 2:, 100:200, 150:400] *= 6.0     # a step the omnibus test must find
+        full[3, k // 2:, 100:200, 150:400] *= 6.0
         r, f = (1, 3, 3), (1, 1, 1)
         halo = r[1] + f[1]
         sh = tiles.empty_shard((4, k), ny, nx, halo, dev)

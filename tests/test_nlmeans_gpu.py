@@ -182,6 +182,11 @@ def test_tiny_weights_follow_the_reference(oracle, device):
     ((3, 33, 130, 1), (2, 2, 4), (1, 0, 1), 0.5, 0.5, -1),
     ((6, 20, 20, 2), (0, 3, 2), (0, 1, 1), 0.5, 0.5, -1),         # time is a plain slice axis
     ((4, 35, 66, 2), (1, 0, 2), (1, 0, 1), 0.4, 0.6, 20.0),
+    # three-date windows of every size the streaming kernel is instantiated for, series of 2 .. 7 dates
+    ((2, 37, 131, 1), (1, 1, 1), (1, 1, 1), 0.5, 0.5, -1),
+    ((3, 37, 131, 2), (1, 2, 2), (1, 1, 1), 0.5, 0.5, 9.0),
+    ((7, 70, 259, 1), (1, 4, 4), (1, 1, 1), 0.5, 0.5, -1),
+    ((4, 33, 140, 2), (1, 5, 5), (1, 2, 2), 0.5, 0.5, 30.0),
 ])
 def test_time_first_layout_window_kernel(oracle, device, case):
     """(time, y, x, var) views of planar stacks, 3-D search window: the reference-compatible mode
@@ -271,7 +276,13 @@ def test_window_kernel_partial_core_on_every_axis(device):
     from nd_amd import kernels
     rng = np.random.default_rng(53)
     full = torch.from_numpy(rng.gamma(4.0, 0.25, (2, 9, 50, 140)).astype(np.float32)).to(device)  # (var,t,y,x)
-    r, f = (2, 3, 3), (1, 1, 1)
+    _partial_core_case(full, (2, 3, 3), (1, 1, 1))
+    _partial_core_case(full, (1, 3, 3), (1, 1, 1))          # three-date window: the streaming kernel
+
+
+def _partial_core_case(full, r, f):
+    import torch
+    from nd_amd import kernels
     ref = torch.empty_like(full)
     kernels.pixelwise_nlmeans_3d(full.permute(1, 2, 3, 0), ref.permute(1, 2, 3, 0), r, f, 0.5, 0.5, -1,
                                  patch_mode=0)
