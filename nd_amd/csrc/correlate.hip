@@ -343,6 +343,332 @@ static void launch_tiled(const TiledArgs<T> &a, bool box, int64_t nblocks, size_
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// Register-window form for small square windows (3 x 3, 5 x 5, 7 x 7, centred in x) over float32
+// planes: no LDS, no barrier.  A WAVE owns a strip of 256 columns (1 KiB per row, line-aligned) and
+// walks down a chunk of rows of one plane.  A lane owns four adjacent columns: one 16-byte load per
+// input row, converted to double (boxcar: times the weight, once per input element); the KW - 1
+// columns it needs from its neighbours arrive through DPP wave shifts of the converted values; the
+// strip's own outer neighbours (K / 2 columns on either side) come from one more, two-lane load per
+// row.  The KH x (4 + KW - 1) window lives in registers as a ring over the rows (the row loop is
+// unrolled KH times, so every ring index is static), the loads of the next KH rows are in flight
+// while a row is computed, and every output still receives its KH * KW terms in scipy's footprint
+// order with product and sum rounded separately.  Border rule: rows through a scalar index per
+// step, columns outside the row through per-lane mapped single-word loads.
+// (Measured on 24 x 4096^2: strips of 248 written columns whose ends share cache lines with the
+// neighbour strips cost 8 %; non-temporal loads cost 6-10 %, non-temporal stores, deeper read-ahead
+// and the chunk height change nothing; the arithmetic is hidden: the kernel runs at the rate of
+// its own loads and stores.)
+// -----------------------------------------------------------------------------------------
+constexpr int kRollStrip = 256;          // columns per wave: 64 lanes x 4
+
+// extend_index in 32-bit arithmetic (extents below 2^30, checked on the host), clamped into the
+// array: the row loop holds 2 K inlined copies and the 64-bit divisions made most of its code
+__device__ __forceinline__ int extend_index32(int cc, int len, int mode)
+{
+    if (cc >= 0 && cc < len) return cc;
+    int m = 0;
+    if (len > 1) {
+        switch (mode) {
+        case ND_AMD_MODE_REFLECT: {
+            const int sz2 = 2 * len;
+            if (cc < 0) {
+                if (cc < -sz2) cc += sz2 * (-cc / sz2);
+                m = cc < -len ? cc + sz2 : -cc - 1;
+            } else {
+                cc -= sz2 * (cc / sz2);
+                m = cc >= len ? sz2 - cc - 1 : cc;
+            }
+            break;
+        }
+        case ND_AMD_MODE_NEAREST:
+            m = cc < 0 ? 0 : len - 1;
+            break;
+        case ND_AMD_MODE_MIRROR: {
+            const int sz2 = 2 * len - 2;
+            if (cc < 0) {
+                cc = sz2 * (-cc / sz2) + cc;
+                m = cc <= 1 - len ? cc + sz2 : -cc;
+            } else {
+                cc -= sz2 * (cc / sz2);
+                m = cc >= len ? sz2 - cc : cc;
+            }
+            break;
+        }
+        case ND_AMD_MODE_WRAP: {
+            if (cc < 0) {
+                cc += len * (-cc / len);
+                if (cc < 0) cc += len;
+                m = cc;
+            } else {
+                m = cc - len * (cc / len);
+            }
+            break;
+        }
+        }
+    }
+    return m < 0 ? 0 : (m >= len ? len - 1 : m);
+}
+
+struct RollArgs {
+    const float *in;
+    float *out;
+    int64_t ny, nx;
+    int64_t sin_b, sin_y, sout_b, sout_y;
+    int oy0, mode;
+    int nstrips, nchunks, rows_per_chunk;
+    int64_t nbatch;
+    int vec_in, vec_out;        // 16-byte accesses allowed (base and strides aligned)
+    double w[49];               // dense KH x KW weights, row-major
+};
+
+__device__ __forceinline__ double roll_from_prev(double x)      // lane i <- lane i - 1
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double roll_from_next(double x)      // lane i <- lane i + 1
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K, bool BOX>
+__global__ void __launch_bounds__(256, (K == 3 ? 6 : (K == 5 ? 4 : 2))) correlate_roll_kernel(const RollArgs a)
+{
+    constexpr int H = K / 2, WC = 4 + K - 1;
+    const int lane = threadIdx.x & 63;
+    int64_t wid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int strip = (int)(wid % a.nstrips);
+    wid /= a.nstrips;
+    const int chunk = (int)(wid % a.nchunks);
+    const int64_t plane = wid / a.nchunks;
+    if (plane >= a.nbatch) return;
+    const int64_t ys = (int64_t)chunk * a.rows_per_chunk;
+    const int64_t ye = ys + a.rows_per_chunk < a.ny ? ys + a.rows_per_chunk : a.ny;
+    const int xs = strip * kRollStrip, x = xs + 4 * lane;
+    const int nx = (int)a.nx;
+
+    // Column offsets in bytes.  Own columns: a wave whose 256 columns all lie inside the row takes
+    // one 16-byte load per lane, the last strip of a row takes mapped single-word loads.  Outer
+    // columns: the K / 2 columns left of the strip are what lane 0 needs, the K / 2 right of it
+    // what lane 63 needs; every lane of the lower half-wave issues lane 0's loads and every lane
+    // of the upper half lane 63's (two distinct words per instruction, no divergent branch).
+    int xm[4], xe[H];
+    const bool first = lane == 0, lastl = lane == 63;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xm[c] = 4 * extend_index32(x + c, nx, a.mode);
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+        xe[j] = 4 * extend_index32((lane < 32 ? xs - H : xs + kRollStrip) + j, nx, a.mode);
+    const bool wave_vec = a.vec_in && xs + kRollStrip <= nx;
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + plane * a.sin_b), 0,
+                                                       0x7fffffff, 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(a.out + plane * a.sout_b, 0, 0x7fffffff,
+                                                        0x00020000);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct RowRegs {
+        f32x4 v;
+        float e[H];
+    };
+    auto load_row = [&](int64_t r) -> RowRegs {
+        RowRegs rr;
+        f32x4 v;
+        const int m = extend_index32((int)r, (int)a.ny, a.mode);
+        const int soff = __builtin_amdgcn_readfirstlane(m * (int)a.sin_y * 4);
+        if (wave_vec) {
+            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xm[0], soff, 0));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, xm[c], soff, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < H; ++j)
+            rr.e[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, xe[j], soff, 0));
+        rr.v = v;
+        return rr;
+    };
+
+    const double wbox = a.w[0];
+    double win[K][WC];
+    f32x4 raw[K];
+    float rawe[K][H];
+    const int nt = (int)(ye - ys) + K - 1;          // input rows this wave consumes
+#pragma unroll
+    for (int ph = 0; ph < K; ++ph) {
+        if (ph < nt) {
+            const RowRegs rr = load_row(ys + a.oy0 + ph);
+            raw[ph] = rr.v;
+#pragma unroll
+            for (int j = 0; j < H; ++j) rawe[ph][j] = rr.e[j];
+        }
+    }
+
+    const bool writer = x < nx;
+    const bool store_vec = a.vec_out && x + 3 < nx;
+
+    for (int t0 = 0; t0 < nt; t0 += K) {
+#pragma unroll
+        for (int ph = 0; ph < K; ++ph) {
+            const int t = t0 + ph;
+            if (t < nt) {
+                // input row t: own columns, then the neighbours' edge columns
+                double d[4], de[H];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double v = (double)raw[ph][c];
+                    d[c] = BOX ? wbox * v : v;
+                }
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+                    const double ve = (double)rawe[ph][j];
+                    de[j] = BOX ? wbox * ve : ve;
+                }
+                if (t + K < nt) {
+                    const RowRegs rr = load_row(ys + a.oy0 + t + K);
+                    raw[ph] = rr.v;
+#pragma unroll
+                    for (int j = 0; j < H; ++j) rawe[ph][j] = rr.e[j];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) win[ph][H + c] = d[c];
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+                    const double lp = roll_from_prev(d[4 - H + j]), rn = roll_from_next(d[j]);
+                    win[ph][j] = first ? de[j] : lp;
+                    win[ph][H + 4 + j] = lastl ? de[j] : rn;
+                }
+                if (t >= K - 1) {
+                    // output row: window row i sits in ring slot (ph + 1 + i) mod K
+                    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        const int sl = (ph + 1 + i) % K;
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (BOX)
+                                    acc[c] = acc[c] + win[sl][c + j];
+                                else
+                                    acc[c] = acc[c] + a.w[i * K + j] * win[sl][c + j];
+                            }
+                        }
+                    }
+                    const int64_t y = ys + t - (K - 1);
+                    const int ooff = __builtin_amdgcn_readfirstlane((int)(y * a.sout_y) * 4);
+                    if (writer) {
+                        if (store_vec) {
+                            const f32x4 o = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, x * 4, ooff, 0);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (x + c < nx)
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[c]), rout,
+                                                                          (x + c) * 4, ooff, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Try the register-window form; returns 1 if it was launched.
+template <typename T>
+static int try_roll(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
+                    const int64_t so[4], int64_t ntaps, const int64_t *offsets,
+                    const double *weights, int mode, hipStream_t stream)
+{
+    return 0;
+}
+
+template <>
+int try_roll<float>(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
+                    const int64_t so[4], int64_t ntaps, const int64_t *offsets,
+                    const double *weights, int mode, hipStream_t stream)
+{
+    static const bool disabled = getenv("ND_AMD_NO_ROLL") != nullptr || getenv("ND_AMD_NO_TILED") != nullptr;
+    if (disabled || mode == ND_AMD_MODE_CONSTANT) return 0;
+    if (ntaps != 9 && ntaps != 25 && ntaps != 49) return 0;
+    const int K = ntaps == 9 ? 3 : (ntaps == 25 ? 5 : 7);
+    if (si[3] != 1 || so[3] != 1 || si[2] < 0 || so[2] < 0) return 0;
+    // dense K x K window in row-major order, centred in x, every weight non-zero
+    const int64_t oy0 = offsets[2], ox0 = offsets[3];
+    if (ox0 != -(K / 2)) return 0;
+    bool box = true;
+    for (int64_t t = 0; t < ntaps; ++t) {
+        if (offsets[4 * t + 0] != 0 || offsets[4 * t + 1] != 0) return 0;
+        if (offsets[4 * t + 2] != oy0 + t / K || offsets[4 * t + 3] != ox0 + t % K) return 0;
+        if (weights[t] == 0.0 || !(weights[t] == weights[t])) return 0;
+        if (weights[t] != weights[0]) box = false;
+    }
+    if (!box && K == 7) return 0;            // 49 scalar weights: leave to the LDS form
+    const int64_t ny = dims[2], nx = dims[3];
+    if (ny < 1 || nx < 8 || ny > 0x3fffffff || nx > 0x3fffffff) return 0;
+    {   // scipy's offset table is not periodic far outside the array: leave that to the generic kernel
+        const int64_t ry = -oy0 > oy0 + K - 1 ? -oy0 : oy0 + K - 1;
+        if (ry >= 2 * ny || K / 2 >= 2 * nx) return 0;
+    }
+    int64_t nb = dims[0] * dims[1], sbi, sbo;
+    if (dims[0] == 1) {
+        sbi = si[1];
+        sbo = so[1];
+    } else if (dims[1] == 1) {
+        sbi = si[0];
+        sbo = so[0];
+    } else if (si[0] == si[1] * dims[1] && so[0] == so[1] * dims[1]) {
+        sbi = si[1];
+        sbo = so[1];
+    } else {
+        return 0;
+    }
+    // row and column offsets inside a plane travel as 32-bit byte offsets
+    if ((ny * si[2] + nx) * 4 >= 0x7fffffffLL || (ny * so[2] + nx) * 4 >= 0x7fffffffLL) return 0;
+    RollArgs a;
+    a.in = static_cast<const float *>(in);
+    a.out = static_cast<float *>(out);
+    a.ny = ny;
+    a.nx = nx;
+    a.sin_b = sbi;
+    a.sin_y = si[2];
+    a.sout_b = sbo;
+    a.sout_y = so[2];
+    a.oy0 = (int)oy0;
+    a.mode = mode;
+    a.nbatch = nb;
+    a.nstrips = (int)ceil_div(nx, kRollStrip);
+    // rows per wave: long enough to amortise the K - 1 rows read ahead of the first output, short
+    // enough for >= ~16 k waves
+    int64_t rpc = 64;
+    while (rpc > 16 && (int64_t)a.nstrips * ceil_div(ny, rpc) * nb < 16384) rpc /= 2;
+    a.rows_per_chunk = (int)rpc;
+    a.nchunks = (int)ceil_div(ny, rpc);
+    a.vec_in = (((uintptr_t)in & 15) == 0 && (sbi & 3) == 0 && (si[2] & 3) == 0) ? 1 : 0;
+    a.vec_out = (((uintptr_t)out & 15) == 0 && (sbo & 3) == 0 && (so[2] & 3) == 0) ? 1 : 0;
+    for (int i = 0; i < 49; ++i) a.w[i] = i < ntaps ? weights[i] : 0.0;
+    const int64_t nwaves = (int64_t)a.nstrips * a.nchunks * nb;
+    const int64_t nblocks = ceil_div(nwaves, 4);
+    if (nblocks > 0x7fffffffLL) return 0;
+    KernelTimer timer(ND_AMD_KERNEL_BOXCAR_TILED, stream);
+    const dim3 grid((unsigned)nblocks), block(256);
+    if (K == 3) {
+        if (box) hipLaunchKernelGGL((correlate_roll_kernel<3, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((correlate_roll_kernel<3, false>), grid, block, 0, stream, a);
+    } else if (K == 5) {
+        if (box) hipLaunchKernelGGL((correlate_roll_kernel<5, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((correlate_roll_kernel<5, false>), grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((correlate_roll_kernel<7, true>), grid, block, 0, stream, a);
+    }
+    return 1;
+}
+
 // Try the tiled form; returns 1 if it was launched, 0 if the request does not fit it.
 template <typename T>
 static int try_tiled(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
@@ -481,7 +807,8 @@ static int correlate_impl(const void *in, void *out, const int64_t dims[4], cons
     a.cval = cval;
     a.taps_dev = nullptr;
     if (a.total == 0) return ND_AMD_OK;
-    if (try_tiled<T>(in, out, dims, si, so, ntaps, offsets, weights, mode, stream)) {
+    if (try_roll<T>(in, out, dims, si, so, ntaps, offsets, weights, mode, stream) ||
+        try_tiled<T>(in, out, dims, si, so, ntaps, offsets, weights, mode, stream)) {
         ND_HIP_CHECK(hipGetLastError());
         return ND_AMD_OK;
     }

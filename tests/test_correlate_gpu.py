@@ -135,3 +135,35 @@ def test_tiled_edges_and_tiny_planes(device):
             for mode in ('reflect', 'nearest', 'mirror', 'wrap'):
                 np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode),
                                               ndi.convolve(a, k, mode=mode))
+
+
+@pytest.mark.parametrize('mode', ['reflect', 'nearest', 'mirror', 'wrap'])
+def test_register_window_kernel(device, mode):
+    """Square 3 x 3 / 5 x 5 / 7 x 7 windows on float32 planes run in the register-window kernel
+    (one wave per 256-column strip, DPP exchange of the edge columns): strip borders, widths that
+    are not multiples of 4, planes shorter than the window, unaligned row pitches, random and
+    boxcar weights, origins along y -- all bit-equal to scipy."""
+    import scipy.ndimage as ndi
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(31)
+    for shape in [(2, 70, 256), (1, 67, 257), (3, 5, 500), (2, 2, 9), (1, 130, 8), (2, 40, 1003), (1, 3, 767), (1, 9, 260), (2, 6, 252)]:
+        a = rng.normal(size=shape).astype(np.float32)
+        for w in (3, 5, 7):
+            for k in (np.ones((1, w, w)) / float(w * w), rng.normal(size=(1, w, w))):
+                np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode),
+                                              ndi.convolve(a, k, mode=mode))
+    a = rng.normal(size=(2, 45, 300)).astype(np.float32)
+    k = rng.normal(size=(1, 5, 5))
+    for origin in ((0, 1, 0), (0, -2, 0)):
+        np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode, origin=origin),
+                                      ndi.convolve(a, k, mode=mode, origin=origin))
+    # a view with an odd row pitch (no 16-byte accesses) and an output with another pitch
+    base = torch.from_numpy(rng.normal(size=(2, 50, 263)).astype(np.float32)).to(device)
+    view = base[:, 3:47, 1:260]
+    obuf = torch.empty((2, 44, 261), dtype=torch.float32, device=device)
+    out = obuf[:, :, :259]
+    k = np.ones((1, 3, 3)) / 9.0
+    kernels.convolve(view, k, out=out, mode=mode)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), ndi.convolve(view.cpu().numpy(), k, mode=mode))
