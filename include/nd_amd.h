@@ -170,6 +170,24 @@ int nd_amd_correlate1d(const void *in, void *out, int dtype,
                        int mode, double cval, void *hip_stream);
 
 /* ------------------------------------------------------------------------
+ * Two 1-D correlations in one pass over memory: along axis 2 (y), then along
+ * axis 3 (x), the intermediate array rounded to the array dtype exactly as
+ * scipy.ndimage.gaussian_filter does between its per-axis passes (it filters
+ * `output` in place from the second axis on) -- GaussianFilter(dims=('y','x'))
+ * at nd/filters.py:365-378 on x-contiguous planes.
+ * Fused form only: float32, x stride 1, both kernels symmetric (to
+ * DBL_EPSILON, as NI_Correlate1D tests) and of the same odd length
+ * 3, 5, ..., 13 or 17, any border mode except `constant`.  Everything else
+ * returns ND_AMD_EUNSUPPORTED and the caller runs two nd_amd_correlate1d
+ * passes (nd_amd/kernels.py does).  `in` and `out` must not overlap.
+ * ---------------------------------------------------------------------- */
+int nd_amd_correlate1d_yx(const void *in, void *out, int dtype,
+                          const int64_t dims[4],
+                          const int64_t in_strides[4], const int64_t out_strides[4],
+                          int nweights, const double *weights_y, const double *weights_x,
+                          int mode, void *hip_stream);
+
+/* ------------------------------------------------------------------------
  * Non-local means.
  * Replaces  nd._filters._pixelwise_nlmeans_3d(arr, output, r, f, sigma, h, n_eff)
  *           nd/_filters.pyx:320-420, sole caller nd/filters.py:462.

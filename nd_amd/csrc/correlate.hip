@@ -1269,9 +1269,306 @@ static int correlate1d_impl(const void *in, void *out, const int64_t dims[4], co
     return ND_AMD_OK;
 }
 
+// -----------------------------------------------------------------------------------------
+// Two correlate1d passes in one kernel: along y, then along x, over x-contiguous float32 planes --
+// scipy.ndimage.gaussian_filter on dims ('y', 'x') (nd/filters.py:365-378), which filters axis
+// after axis and rounds the intermediate array to the array dtype.  Symmetric kernels of the same
+// radius R in both directions.  Same register-window design as correlate_roll_kernel: a wave owns
+// a strip of columns and walks down a chunk of rows; a lane owns four columns.  The last 2 R + 1
+// input rows (and the rows read ahead) sit in a ring of float32 registers; per output row the lane
+// runs NI_Correlate1D's symmetric form down its four columns in double (outermost pair first),
+// rounds to float32 -- the intermediate array -- and the pass along x takes its R neighbours on
+// either side from the adjacent lanes through DPP wave shifts of those float32 values.  Lanes at
+// the ends of a wave (FEED on either side) only feed their neighbours.  Columns and rows outside
+// the plane are scipy's periodic line extension as index maps: the first pass evaluated at a mapped
+// column IS the extended intermediate line.  One read and one write of the array instead of two.
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ int extend_line32(int cc, int len, int mode)      // clamped into the line
+{
+    if (cc >= 0 && cc < len) return cc;
+    int m = 0;
+    if (len > 1) {
+        switch (mode) {
+        case ND_AMD_MODE_REFLECT: {
+            const int p = 2 * len;
+            m = cc % p;
+            if (m < 0) m += p;
+            m = m < len ? m : p - 1 - m;
+            break;
+        }
+        case ND_AMD_MODE_NEAREST:
+            m = cc < 0 ? 0 : len - 1;
+            break;
+        case ND_AMD_MODE_MIRROR: {
+            const int p = 2 * len - 2;
+            m = cc % p;
+            if (m < 0) m += p;
+            m = m < len ? m : p - m;
+            break;
+        }
+        case ND_AMD_MODE_WRAP: {
+            m = cc % len;
+            if (m < 0) m += len;
+            break;
+        }
+        }
+    }
+    return m < 0 ? 0 : (m >= len ? len - 1 : m);
+}
+
+struct Corr2PassArgs {
+    const float *in;
+    float *out;
+    int64_t ny, nx;
+    int64_t sin_b, sin_y, sout_b, sout_y;
+    int mode;
+    int nstrips, nchunks, rows_per_chunk;
+    int64_t nbatch;
+    int vec_in, vec_out;
+    double wy[9], wx[9];        // w[d] = weight at distance d from the centre
+};
+
+__device__ __forceinline__ float f32_from_prev(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float f32_from_next(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xF, 0xF, true));
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs a)
+{
+    constexpr int FEED = (R + 3) / 4;               // feeder lanes at either end of the wave
+    constexpr int NY = 2 * R + 1, PD = 3, RING = NY + PD;
+    constexpr int SW = (64 - 2 * FEED) * 4;         // columns written per wave
+    const int lane = threadIdx.x & 63;
+    int64_t wid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int strip = (int)(wid % a.nstrips);
+    wid /= a.nstrips;
+    const int chunk = (int)(wid % a.nchunks);
+    const int64_t plane = wid / a.nchunks;
+    if (plane >= a.nbatch) return;
+    const int ys = chunk * a.rows_per_chunk, ny = (int)a.ny, nx = (int)a.nx;
+    const int ye = ys + a.rows_per_chunk < ny ? ys + a.rows_per_chunk : ny;
+    const int x = strip * SW - 4 * FEED + 4 * lane;
+
+    int xm[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xm[c] = 4 * extend_line32(x + c, nx, a.mode);
+    const bool inside = x >= 0 && x + 3 < nx;
+    const bool wave_vec = a.vec_in && __builtin_amdgcn_ballot_w64(!inside) == 0ull;
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + plane * a.sin_b), 0,
+                                                       0x7fffffff, 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(a.out + plane * a.sout_b, 0, 0x7fffffff,
+                                                        0x00020000);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load_row = [&](int t) -> f32x4 {            // input row of step t: ys - R + t
+        const int m = extend_line32(ys - R + t, ny, a.mode);
+        const int soff = __builtin_amdgcn_readfirstlane(m * (int)a.sin_y * 4);
+        f32x4 v;
+        if (wave_vec) {
+            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xm[0], soff, 0));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, xm[c], soff, 0));
+        }
+        return v;
+    };
+
+    f32x4 ring[RING];
+    const int nt = (ye - ys) + 2 * R;               // input rows this wave consumes
+#pragma unroll
+    for (int t = 0; t < PD; ++t)
+        if (t < nt) ring[t] = load_row(t);
+
+    const bool writer = lane >= FEED && lane < 64 - FEED && x < nx;
+    const bool store_vec = a.vec_out && x + 3 < nx;
+
+    for (int t0 = 0; t0 < nt; t0 += RING) {
+#pragma unroll
+        for (int pu = 0; pu < RING; ++pu) {
+            const int t = t0 + pu;
+            if (t < nt) {
+                if (t + PD < nt) ring[(pu + PD) % RING] = load_row(t + PD);
+                if (t >= 2 * R) {
+                    // ---- pass along y on this lane's four columns: rows t - 2R .. t, centre t - R
+                    float ty[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        double o = (double)ring[(pu + RING - R) % RING][c] * a.wy[0];
+#pragma unroll
+                        for (int d = R; d >= 1; --d)
+                            o = o + ((double)ring[(pu + 2 * RING - R - d) % RING][c] +
+                                     (double)ring[(pu + RING - R + d) % RING][c]) * a.wy[d];
+                        ty[c] = (float)o;           // the intermediate array, in the array dtype
+                    }
+                    // ---- pass along x: R values from either side through the neighbouring lanes
+                    double ax[4 + 2 * R];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ax[R + c] = (double)ty[c];
+                    {
+                        float pl[4], nr[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            pl[c] = f32_from_prev(ty[c]);
+                            nr[c] = f32_from_next(ty[c]);
+                        }
+                        constexpr int R1 = R < 4 ? R : 4;
+#pragma unroll
+                        for (int j = 0; j < R1; ++j) {
+                            ax[R - 1 - j] = (double)pl[3 - j];
+                            ax[R + 4 + j] = (double)nr[j];
+                        }
+                        if (R > 4) {
+#pragma unroll
+                            for (int j = 0; j < R - 4; ++j) {
+                                ax[R - 5 - j] = (double)f32_from_prev(pl[3 - j]);
+                                ax[R + 8 + j] = (double)f32_from_next(nr[j]);
+                            }
+                        }
+                    }
+                    float res[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        double o = ax[R + c] * a.wx[0];
+#pragma unroll
+                        for (int d = R; d >= 1; --d) o = o + (ax[R + c - d] + ax[R + c + d]) * a.wx[d];
+                        res[c] = (float)o;
+                    }
+                    const int y = ys + t - 2 * R;
+                    const int ooff = __builtin_amdgcn_readfirstlane(y * (int)a.sout_y * 4);
+                    if (writer) {
+                        if (store_vec) {
+                            const f32x4 o4 = {res[0], res[1], res[2], res[3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rout, x * 4, ooff, 0);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (x + c < nx)
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[c]), rout,
+                                                                          (x + c) * 4, ooff, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+static bool corr1d_symmetric(const double *w, int n)
+{
+    if (!(n & 1)) return false;
+    for (int ii = 1; ii <= n / 2; ++ii)
+        if (fabs(w[ii + n / 2] - w[n / 2 - ii]) > 2.220446049250313e-16) return false;
+    return true;
+}
+
 }  // namespace nd_amd
 
 using namespace nd_amd;
+
+extern "C" int nd_amd_correlate1d_yx(const void *in, void *out, int dtype, const int64_t dims[4],
+                                     const int64_t in_strides[4], const int64_t out_strides[4],
+                                     int nweights, const double *weights_y, const double *weights_x,
+                                     int mode, void *hip_stream)
+{
+    if (!dims || !in_strides || !out_strides || !weights_y || !weights_x || nweights < 1) {
+        set_error("nd_amd_correlate1d_yx: bad argument");
+        return ND_AMD_EINVAL;
+    }
+    if (mode < 0 || mode > 4) {
+        set_error("nd_amd_correlate1d_yx: unknown border mode %d", mode);
+        return ND_AMD_EINVAL;
+    }
+    for (int d = 0; d < 4; ++d)
+        if (dims[d] < 0) {
+            set_error("nd_amd_correlate1d_yx: negative dimension");
+            return ND_AMD_EINVAL;
+        }
+    if (dims[0] * dims[1] * dims[2] * dims[3] == 0) return ND_AMD_OK;
+    if (!in || !out || in == out) {
+        set_error("nd_amd_correlate1d_yx: null or aliased data pointers");
+        return ND_AMD_EINVAL;
+    }
+    static const bool disabled = getenv("ND_AMD_NO_ROLL") != nullptr || getenv("ND_AMD_NO_TILED") != nullptr;
+    const int R = nweights / 2;
+    const int64_t *si = in_strides, *so = out_strides;
+    const int64_t ny = dims[2], nx = dims[3];
+    bool fits = !disabled && dtype == ND_AMD_F32 && mode != ND_AMD_MODE_CONSTANT && (nweights & 1) &&
+                R >= 1 && R <= 8 && R != 7 && corr1d_symmetric(weights_y, nweights) &&
+                corr1d_symmetric(weights_x, nweights) && si[3] == 1 && so[3] == 1 && si[2] >= 0 &&
+                so[2] >= 0 && ny <= 0x3fffffff && nx <= 0x3fffffff && nx >= 8 &&
+                (ny * si[2] + nx) * 4 < 0x7fffffffLL && (ny * so[2] + nx) * 4 < 0x7fffffffLL;
+    int64_t nb = dims[0] * dims[1], sbi = 0, sbo = 0;
+    if (dims[0] == 1) {
+        sbi = si[1];
+        sbo = so[1];
+    } else if (dims[1] == 1) {
+        sbi = si[0];
+        sbo = so[0];
+    } else if (si[0] == si[1] * dims[1] && so[0] == so[1] * dims[1]) {
+        sbi = si[1];
+        sbo = so[1];
+    } else {
+        fits = false;
+    }
+    if (!fits) {
+        set_error("nd_amd_correlate1d_yx: not a case of the fused kernel (float32, x-contiguous planes, "
+                  "symmetric kernels of one radius 1..6 or 8, no constant mode): run two nd_amd_correlate1d passes");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    Corr2PassArgs a;
+    a.in = static_cast<const float *>(in);
+    a.out = static_cast<float *>(out);
+    a.ny = ny;
+    a.nx = nx;
+    a.sin_b = sbi;
+    a.sin_y = si[2];
+    a.sout_b = sbo;
+    a.sout_y = so[2];
+    a.mode = mode;
+    a.nbatch = nb;
+    const int feed = (R + 3) / 4, sw = (64 - 2 * feed) * 4;
+    a.nstrips = (int)ceil_div(nx, sw);
+    // rows per wave: the 2 R rows read ahead of the first output are re-read by the next chunk
+    int64_t rpc = R >= 3 ? 128 : 64;
+    while (rpc > 16 && (int64_t)a.nstrips * ceil_div(ny, rpc) * nb < 12288) rpc /= 2;
+    a.rows_per_chunk = (int)rpc;
+    a.nchunks = (int)ceil_div(ny, rpc);
+    a.vec_in = (((uintptr_t)in & 15) == 0 && (sbi & 3) == 0 && (si[2] & 3) == 0) ? 1 : 0;
+    a.vec_out = (((uintptr_t)out & 15) == 0 && (sbo & 3) == 0 && (so[2] & 3) == 0) ? 1 : 0;
+    for (int d = 0; d < 9; ++d) {
+        // NI_Correlate1D's symmetric form reads the weights left of the centre: fw[j], j < 0
+        a.wy[d] = d <= R ? weights_y[R - d] : 0.0;
+        a.wx[d] = d <= R ? weights_x[R - d] : 0.0;
+    }
+    const int64_t nwaves = (int64_t)a.nstrips * a.nchunks * nb;
+    const int64_t nblocks = ceil_div(nwaves, 4);
+    if (nblocks > 0x7fffffffLL) {
+        set_error("nd_amd_correlate1d_yx: array too large for one launch");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    {
+        KernelTimer timer(ND_AMD_KERNEL_CORRELATE1D, stream);
+        const dim3 grid((unsigned)nblocks), block(256);
+        switch (R) {
+        case 1: hipLaunchKernelGGL((correlate1d_yx_kernel<1>), grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((correlate1d_yx_kernel<2>), grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((correlate1d_yx_kernel<3>), grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((correlate1d_yx_kernel<4>), grid, block, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL((correlate1d_yx_kernel<5>), grid, block, 0, stream, a); break;
+        case 6: hipLaunchKernelGGL((correlate1d_yx_kernel<6>), grid, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL((correlate1d_yx_kernel<8>), grid, block, 0, stream, a); break;
+        }
+    }
+    ND_HIP_CHECK(hipGetLastError());
+    return ND_AMD_OK;
+}
 
 extern "C" int nd_amd_correlate1d(const void *in, void *out, int dtype, const int64_t dims[4],
                                   const int64_t in_strides[4], const int64_t out_strides[4],

@@ -416,6 +416,35 @@ def _gaussian_kernel1d(sigma, radius):
     return phi_x / phi_x.sum()
 
 
+def _gaussian_yx_fused(inp, out, axes, nd, mode, truncate):
+    """The common GaussianFilter(dims=('y', 'x')) case on x-contiguous float32 planes: both passes
+    in one kernel (nd_amd_correlate1d_yx), the intermediate rounded to float32 like scipy's.
+    Returns False when the request is not one the fused kernel takes."""
+    if (len(axes) != 2 or [ax for ax, _ in axes] != [nd - 2, nd - 1] or nd > 4
+            or inp.dtype != torch.float32 or mode not in _lib.MODES or mode == 'constant'
+            or inp.stride(-1) != 1 or out.stride(-1) != 1 or inp.data_ptr() == out.data_ptr()
+            or inp.shape != out.shape or inp.device != out.device):
+        return False
+    lws = [int(truncate * sd + 0.5) for _, sd in axes]
+    if lws[0] != lws[1] or lws[0] < 1:
+        return False
+    wy, wx = (np.ascontiguousarray(_gaussian_kernel1d(sd, lw)[::-1], np.float64)
+              for (_, sd), lw in zip(axes, lws))
+    pad = 4 - nd
+    dev = inp.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().nd_amd_correlate1d_yx(
+            _ptr(inp), _ptr(out), _DT[inp.dtype], _lib.i64_array((1,) * pad + tuple(inp.shape)),
+            _lib.i64_array((0,) * pad + tuple(inp.stride())),
+            _lib.i64_array((0,) * pad + tuple(out.stride())), len(wy),
+            wy.ctypes.data_as(C.POINTER(C.c_double)), wx.ctypes.data_as(C.POINTER(C.c_double)),
+            _lib.MODES[mode], _stream_ptr(dev))
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc)
+    return True
+
+
 def gaussian_filter(inp, sigma, out=None, mode='reflect', cval=0.0, truncate=4.0):
     """scipy.ndimage.gaussian_filter(inp, sigma, output=out, mode, cval, truncate): one
     correlate1d pass per axis with sigma > 1e-15, each pass reading the previous pass's result
@@ -432,6 +461,8 @@ def gaussian_filter(inp, sigma, out=None, mode='reflect', cval=0.0, truncate=4.0
         return out
     src = inp
     bufs = [out, None]
+    if _gaussian_yx_fused(inp, out, axes, nd, mode, truncate):
+        return out
     for n_done, (ax, sd) in enumerate(axes):
         lw = int(truncate * sd + 0.5)
         weights = _gaussian_kernel1d(sd, lw)[::-1]
