@@ -24,7 +24,8 @@ is N times as tall; strong = the stated raster is split over the ranks by tiles.
 
 At N = 1 with the default workload the line also carries `cpu_baseline` (the C oracle on the host's
 cores) and `extra`: the other kernels of the path (dense-threshold omnibus, C3, boxcar, non-local
-means in both patch modes, the pipeline) each with ms, Mpx/s, roofline and a sampled oracle check.
+means in both patch modes, Gaussian, the pipeline) each with ms, Mpx/s, roofline and a sampled
+oracle check.
 
 Prints ONE JSON line on rank 0.
 """
@@ -402,6 +403,23 @@ def extras(main, barrier, dev):
         entry('BoxcarFilter %dx%d on 24t x 4096 x 4096 f32 (scipy.ndimage.convolve arithmetic)'
               % (wdt, wdt), dt, 5, x.numel(), km, roofline(dom, km[dom], 8 * x.numel()),
               res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
+    # -- GaussianFilter(dims=('y', 'x'), sigma=1): both passes in one kernel
+    import scipy.ndimage as ndi
+    dt, km, _ = timed(lambda: kernels.gaussian_filter(x, (0, 1.0, 1.0), out=y), 5, 2, barrier)
+    res = checks.gaussian_bands(x, y, 1.0, [(0, 40), (2030, 2070), (4056, 4096)], [0, 23])
+    dom = max(km, key=km.get)
+    crop = np.ascontiguousarray(x[:4, :2048, :2048].cpu().numpy())
+    t0 = time.perf_counter()
+    ndi.gaussian_filter(crop, (0, 1.0, 1.0))
+    dtc = time.perf_counter() - t0
+    entry('GaussianFilter sigma=1 (9 taps along y, then along x) on 24t x 4096 x 4096 f32 '
+          '(scipy.ndimage.gaussian_filter arithmetic, float32 intermediate)', dt, 5, x.numel(), km,
+          roofline(dom, km[dom], 8 * x.numel(),
+                   note='one read and one write of the array for both passes'),
+          res['bad'] == 0, unit_note='Mpx_per_s counts px.t', sample=res,
+          cpu_baseline={'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': 1,
+                        'kind': 'reference', 'sample': 'scipy.ndimage.gaussian_filter (the reference\'s '
+                        'own arithmetic for this filter) on a 4 x 2048 x 2048 crop, %.2f s' % dtc})
     del x, y
     _free()
 

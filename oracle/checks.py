@@ -120,3 +120,25 @@ def convolve_bands(x, out, kernel2d, bands, dates, halo=12):
             bad += int((got != want[lo:hi]).sum())
             compared += int(got.size)
     return {'bad': bad, 'compared': compared}
+
+
+def gaussian_bands(x, out, sigma, bands, dates, mode='reflect', truncate=4.0):
+    """x / out: (k, ny, nx) device tensors, input and output of GaussianFilter(dims=('y','x'),
+    sigma): bands of rows [r0, r1) of a few dates are filtered by scipy.ndimage.gaussian_filter
+    itself -- the reference's arithmetic for this filter (nd/filters.py:365-378) -- with the
+    kernel's reach of extra rows as context, and compared exactly.  -> dict(bad=, compared=)."""
+    import scipy.ndimage as ndi
+    k, ny, nx = x.shape
+    halo = int(truncate * float(sigma) + 0.5) + 1
+    bad = compared = 0
+    for t in dates:
+        for (r0, r1) in bands:
+            e0, e1 = max(r0 - halo, 0), min(r1 + halo, ny)
+            host = np.ascontiguousarray(x[t, e0:e1].cpu().numpy())
+            want = ndi.gaussian_filter(host, sigma, mode=mode, truncate=truncate)
+            lo = halo if e0 > 0 else 0
+            hi = want.shape[0] - (halo if e1 < ny else 0)
+            got = out[t, e0 + lo:e0 + hi].cpu().numpy()
+            bad += int((got != want[lo:hi]).sum())
+            compared += int(got.size)
+    return {'bad': bad, 'compared': compared}

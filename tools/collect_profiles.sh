@@ -19,6 +19,17 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/dwrite -o p --output-format cs
 python3 $R/tools/summarize_prof.py $OUT/dstats $OUT/dfetch $OUT/dwrite $OUT/omnibus_dense_rocprof.txt "rocprofv3 --kernel-trace --stats -- python3 tools/bench_dense.py --alphas 0.01 --steps 5 --cpu-rows 0 (and --pmc FETCH_SIZE / WRITE_SIZE passes)" > /dev/null
 bash $R/tools/pmc_dense.sh $1/dense_pmc 0.01 > /dev/null 2>&1
 bash $R/tools/pmc_nlm.sh $1/nlm_pmc > /dev/null 2>&1
+# 5. kernel stats of the filters (boxcar 3x3 / 5x5, fused Gaussian) and of the tutorial pipeline
+: > $OUT/filters_kernel_stats.txt
+for args in "--what boxcar --w 3" "--what boxcar --w 5" "--what boxcar --w 7" "--what gaussian --sigma 1.0"; do
+  rm -rf /tmp/fprof; rocprofv3 --kernel-trace --stats -d /tmp/fprof -o p --output-format csv -- python3 $R/tools/bench_filters.py $args --steps 10 > /tmp/fprof.log 2>&1
+  echo "== rocprofv3 --kernel-trace --stats -- python3 tools/bench_filters.py $args --steps 10" >> $OUT/filters_kernel_stats.txt
+  grep "nd_amd" /tmp/fprof/*/p_kernel_stats.csv /tmp/fprof/p_kernel_stats.csv 2>/dev/null | cut -d: -f2- | cut -c1-220 >> $OUT/filters_kernel_stats.txt
+done
+rm -rf /tmp/fprof; rocprofv3 --kernel-trace --stats -d /tmp/fprof -o p --output-format csv -- python3 $R/tools/bench_pipeline.py --nx 16384 --steps 3 --alpha 1e-4 > /tmp/fprof.log 2>&1
+echo "== rocprofv3 --kernel-trace --stats -- python3 tools/bench_pipeline.py --nx 16384 --steps 3 --alpha 1e-4" >> $OUT/filters_kernel_stats.txt
+grep "nd_amd" /tmp/fprof/*/p_kernel_stats.csv /tmp/fprof/p_kernel_stats.csv 2>/dev/null | cut -d: -f2- | cut -c1-220 >> $OUT/filters_kernel_stats.txt
+bash $R/tools/pmc_nlm_window.sh $1/nlmwin > /dev/null 2>&1
 (cd $R && python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err)
 cp $OUT/stats/p_kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
 cp $OUT/dstats/p_kernel_stats.csv $OUT/dense_kernel_stats.csv 2>/dev/null
