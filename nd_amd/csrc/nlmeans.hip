@@ -270,6 +270,19 @@ __device__ __forceinline__ double nlm_self_weight(double total_weight, double to
     return (total_weight + rt) / (n - 1.0);
 }
 
+// find_weight's discriminant n W^2 - n^2 W2 + n W2 relative to its leading term.  Where the
+// neighbours' effective sample size W^2 / W2 is within ~5 % of n_eff - 1 the two large terms
+// cancel, and the float32 weights of the fast kernels (relative error ~2e-7) would come back
+// amplified beyond the 1e-5 budget -- or decide "no solution" differently from the reference.
+// Those pixels take the exact per-pixel path (double weights, the reference's order).  Also true
+// for NaN and for the no-solution side itself.
+__device__ __forceinline__ bool nlm_neff_ill(double tw, double tsq, double n)
+{
+    const double lead = (n * tw) * tw;
+    const double disc = (lead - ((n * n) * tsq)) + (n * tsq);
+    return !(disc >= 0.05 * lead);
+}
+
 // ---- patch_mode 0, f > 0: uniform weights ------------------------------------------------
 constexpr int kWinTX = 128, kWinTY = 32;     // 4 px per thread along x, 32 x 8 threads -> 128 x 8 ... x4 rows
 
@@ -982,7 +995,7 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
     for (int p = 0; p < TYW; ++p) {
         const int64_t y = y0 + wave * TYW + p;
         if (y < a.chi0 && x < a.chi1) {
-            if (!(wmax[p] >= 1e-30f)) {
+            if (!(wmax[p] >= 1e-30f) || (NEFF && nlm_neff_ill(tw[p], NEFF ? tsq[p] : 0.0, a.n_eff))) {
                 exact_mask |= 1u << p;
                 continue;
             }
@@ -1275,7 +1288,7 @@ __global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs 
             if (feeder || !(y < a.chi0 && x < a.chi1 && x >= a.clo1)) continue;
             const float wm = c ? wmax[p].y : wmax[p].x;
             const float sp = c ? ssum[p].y : ssum[p].x;
-            if (!(wm >= 1e-30f) || !(sp == sp)) {
+            if (!(wm >= 1e-30f) || !(sp == sp) || (NEFF && nlm_neff_ill(tw[p][c], NEFF ? tsq[p][c] : 0.0, a.n_eff))) {
                 exact_mask |= 1u << (2 * p + c);
                 continue;
             }

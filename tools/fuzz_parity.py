@@ -126,6 +126,10 @@ def case_nlmeans(rng):
         shape = (int(rng.integers(3, 8)), int(rng.integers(12, 60)), int(rng.integers(12, 200)), nv)
         r = (int(rng.integers(0, 3)), int(rng.integers(0, 5)), int(rng.integers(0, 5)))
         f = tuple(int(v) for v in rng.integers(0, 2, 3))
+        if rng.random() < 0.35:  # three-date square windows: the streaming window kernel (patch_mode 0)
+            R = int(rng.integers(1, 6))
+            shape = (int(rng.integers(2, 9)), int(rng.integers(2 * R + 2, 70)), int(rng.integers(2 * R + 2, 300)), nv)
+            r, f, pm = (1, R, R), (int(rng.integers(0, 2)), 1, int(rng.integers(1, 3))), 0
         perm = (3, 0, 1, 2)
     else:                        # C-contiguous (a, b, c, var): generic kernel
         shape = (int(rng.integers(3, 12)), int(rng.integers(5, 30)), int(rng.integers(5, 40)), nv)
@@ -184,6 +188,15 @@ def case_correlate(rng):
     ksh = tuple(int(v) for v in ([1] * (nd - 2) if rng.random() < 0.7 else rng.integers(1, 4, nd - 2).tolist()) +
                 rng.integers(1, 8, 2).tolist())
     kind = str(rng.choice(['box', 'rand', 'sparse']))
+    origin = 0
+    if rng.random() < 0.35:      # square 3 / 5 / 7 windows on float32 planes: the register-window kernel
+        w = int(rng.choice([3, 5, 7]))
+        dtype = np.float32
+        shape = shape[:-2] + (int(rng.integers(1, 90)), int(rng.integers(8, 900)))
+        ksh = (1,) * (nd - 2) + (w, w)
+        kind = str(rng.choice(['box', 'rand']))
+        if rng.random() < 0.3:
+            origin = (0,) * (nd - 2) + (int(rng.integers(-(w // 2), w // 2 + 1)), 0)
     if kind == 'box':
         kern = np.ones(ksh) / np.prod(ksh)
     else:
@@ -194,9 +207,8 @@ def case_correlate(rng):
                 kern.flat[0] = 1.0
     mode = str(rng.choice(['reflect', 'constant', 'nearest', 'mirror', 'wrap']))
     cval = float(rng.choice([0.0, 1.5]))
-    origin = 0
     a = rng.normal(size=shape).astype(dtype)
-    desc = dict(shape=shape, kernel=ksh, kind=kind, mode=mode, cval=cval, dtype=np.dtype(dtype).name)
+    desc = dict(shape=shape, kernel=ksh, kind=kind, mode=mode, cval=cval, origin=origin, dtype=np.dtype(dtype).name)
     want = O.convolve(a, kern, mode=mode, cval=cval, origin=origin)
     t = torch.from_numpy(a).to(DEV)
     if rng.random() < 0.3 and nd == 3:          # (y, x, time)-style memory: window axes are not the fastest
@@ -213,9 +225,19 @@ def case_gaussian(rng):
     shape = tuple(int(v) for v in rng.integers(1, 60, nd))
     sigma = tuple(float(v) for v in rng.choice([0.0, 0.5, 1.0, 2.5, 7.0], nd))
     mode = str(rng.choice(['reflect', 'constant', 'nearest', 'mirror', 'wrap']))
+    fused = rng.random() < 0.45  # (y, x) passes of one radius on float32 planes: the fused kernel
+    if fused:
+        dtype = np.float32
+        sg = float(rng.choice([0.3, 0.5, 0.75, 1.0, 1.25, 1.5, 2.0]))
+        shape = (int(rng.integers(1, 4)), int(rng.integers(1, 90)), int(rng.integers(8, 800)))
+        sigma = (0.0, sg, sg if rng.random() < 0.8 else sg * 1.05)
+        mode = str(rng.choice(['reflect', 'nearest', 'mirror', 'wrap']))
     a = rng.normal(size=shape).astype(dtype)
+    if fused and rng.random() < 0.3:
+        a[rng.random(shape) < 0.002] = rng.choice([np.inf, -np.inf, np.nan, 0.0])
     desc = dict(shape=shape, sigma=sigma, mode=mode, dtype=np.dtype(dtype).name)
-    want = snf.gaussian_filter(a, sigma=sigma, mode=mode)
+    with np.errstate(all='ignore'):
+        want = snf.gaussian_filter(a, sigma=sigma, mode=mode)
     got = kernels.gaussian_filter(torch.from_numpy(a).to(DEV), sigma, mode=mode).cpu().numpy()
     return np.array_equal(got, want, equal_nan=True), desc
 
