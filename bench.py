@@ -490,6 +490,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # RCCL's version banner goes to stdout at NCCL_DEBUG=VERSION/INFO; this program's stdout is
+        # the one JSON line
+        if os.environ.get('NCCL_DEBUG', '').upper() in ('VERSION', 'INFO', 'TRACE'):
+            os.environ['NCCL_DEBUG'] = 'WARN'
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     def barrier():
