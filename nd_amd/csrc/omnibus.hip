@@ -1374,14 +1374,17 @@ struct DateVal {
 };
 
 // MODE 0: plain pointers (any strides); 1: x-contiguous planes through buffer descriptors + 32-bit
-// lane offset + scalar date offset; 2: the wave's LDS images of pixel-major variables (LDS-DMA)
+// lane offset + scalar date offset; 2: the wave's LDS images of pixel-major variables (LDS-DMA);
+// 3: pixel-major variables read straight from memory, each lane its own series in 16-byte pieces
+// (64 different sectors per load instruction, every sector touched by two to four consecutive
+// groups of dates: the re-reads are L2 hits) -- no LDS, the occupancy of the planar form
 template <typename T, int MODE>
 struct PlaneReader {
     __amdgpu_buffer_rsrc_t r11, r12r, r12i, r22;
     unsigned voff, sstep;
-    const T *p11, *p12r, *p12i, *p22;      // MODE 2: this lane's series inside each image
+    const T *p11, *p12r, *p12i, *p22;      // MODE 2 / 3: this lane's series inside each image / variable
     int64_t st;
-    int i11, i12, i22, joint;              // MODE 2: date strides inside the images
+    int i11, i12, i22, joint;              // MODE 2 / 3: date strides
     __device__ __forceinline__ DateVal<T> load(const int t) const
     {
         DateVal<T> q;
@@ -1391,7 +1394,7 @@ struct PlaneReader {
             q.b = buffer_load<T>(r12r, voff, soff);
             q.c = buffer_load<T>(r12i, voff, soff);
             q.d = buffer_load<T>(r22, voff, soff);
-        } else if (MODE == 2) {
+        } else if (MODE >= 2) {
             q.a = p11[t * i11];
             q.d = p22[t * i22];
             if (joint) {
@@ -1473,8 +1476,8 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t b = blockIdx.x;
-    const int64_t row = MODE == 2 ? 0 : b / g.blocks_per_row;           // pixel-major: one flat row
-    const int64_t bx = MODE == 2 ? b : b - row * g.blocks_per_row;
+    const int64_t row = MODE >= 2 ? 0 : b / g.blocks_per_row;           // pixel-major: one flat row
+    const int64_t bx = MODE >= 2 ? b : b - row * g.blocks_per_row;
     const int64_t bpx0 = bx * (int64_t)kThreads;
     const int64_t x0 = bpx0 + tid;
     const int k = g.k;
@@ -1511,6 +1514,16 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         rd.p12r = img + pm.img_off[1] + own * k * pm.ids[1];
         rd.p12i = pm.c12_joint ? rd.p12r + 1 : img + pm.img_off[2] + own * k * pm.ids[2];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (MODE >= 3) {
+        const int64_t xc = in ? x0 : g.nx - 1;                  // idle lanes re-read the last pixel
+        rd.i11 = pm.ids[0];
+        rd.i12 = pm.ids[1];
+        rd.i22 = pm.ids[3];
+        rd.joint = pm.c12_joint;
+        rd.p11 = g.c11 + xc * k * pm.ids[0];
+        rd.p22 = g.c22 + xc * k * pm.ids[3];
+        rd.p12r = g.c12r + xc * k * pm.ids[1];
+        rd.p12i = pm.c12_joint ? rd.p12r + 1 : g.c12i + xc * k * pm.ids[2];
     } else {
         const int64_t xc = in ? x0 : g.nx - 1;                  // idle lanes re-read the last pixel
         if (MODE == 1) {
@@ -1532,7 +1545,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     }
     // ---- first dates in flight (last date first) ----
     DateVal<T> ring[PF];
-    if (MODE != 2) {
+    if (MODE < 2) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int t = k - 1 - u;
@@ -1616,17 +1629,59 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         e1 = e0;
         m1 = m0;
     };
-    if (MODE == 2) {
-        // LDS-resident series: groups of VE dates, one group of 16-byte reads ahead
+    if (MODE >= 2) {
+        // LDS-resident (or pixel-major) series: groups of VE dates, one group of 16-byte reads ahead
         constexpr int VE = 16 / (int)sizeof(T);
         DateVal<T> cur[VE], nxt[VE];
         rd.template load_group<VE>(k - VE, nxt);
-        for (int t0 = k - VE; t0 >= 0; t0 -= VE) {
+        if (MODE == 4 && (k % (2 * VE)) == 0) {
+            // From memory, two adjacent 16-byte pieces per variable and step: both land in the same
+            // 64-byte sector, so a sector of C11 / C22 is fetched by two steps instead of four and
+            // a sector of an interleaved C12 exactly once (a lane's sectors do not survive in the
+            // caches from one step to the next: 16 waves per CU x 64 lanes x 4 variables).
+            constexpr int V2 = 2 * VE;
+            DateVal<T> cu2[V2], nx2[V2];
+            auto load2 = [&](int t0, DateVal<T> (&q)[V2]) {
+                DateVal<T> lo[VE], hi[VE];
+                rd.template load_group<VE>(t0, lo);
+                rd.template load_group<VE>(t0 + VE, hi);
 #pragma unroll
-            for (int i = 0; i < VE; ++i) cur[i] = nxt[i];
-            if (t0 >= VE) rd.template load_group<VE>(t0 - VE, nxt);
+                for (int i = 0; i < VE; ++i) {
+                    q[i] = lo[i];
+                    q[VE + i] = hi[i];
+                }
+            };
+            load2(k - V2, nx2);
+            for (int t0 = k - V2; t0 >= 0; t0 -= V2) {
 #pragma unroll
-            for (int i = VE - 1; i >= 0; --i) process(cur[i], t0 + i);
+                for (int i = 0; i < V2; ++i) cu2[i] = nx2[i];
+                if (t0 >= V2) load2(t0 - V2, nx2);
+#pragma unroll
+                for (int i = V2 - 1; i >= 0; --i) process(cu2[i], t0 + i);
+            }
+        } else if (MODE >= 3) {
+            // from memory: two groups ahead (the scattered 16-byte reads take longer than a group's
+            // worth of arithmetic)
+            DateVal<T> nx2[VE];
+            if (k >= 2 * VE) rd.template load_group<VE>(k - 2 * VE, nx2);
+            for (int t0 = k - VE; t0 >= 0; t0 -= VE) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    cur[i] = nxt[i];
+                    nxt[i] = nx2[i];
+                }
+                if (t0 >= 2 * VE) rd.template load_group<VE>(t0 - 2 * VE, nx2);
+#pragma unroll
+                for (int i = VE - 1; i >= 0; --i) process(cur[i], t0 + i);
+            }
+        } else {
+            for (int t0 = k - VE; t0 >= 0; t0 -= VE) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) cur[i] = nxt[i];
+                if (t0 >= VE) rd.template load_group<VE>(t0 - VE, nxt);
+#pragma unroll
+                for (int i = VE - 1; i >= 0; --i) process(cur[i], t0 + i);
+            }
         }
     } else {
         for (int tb = k - 1; tb >= 0; tb -= PF) {
@@ -2371,7 +2426,27 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
                 g.gate_mode = gated ? 1 : 0;
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
-                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 2>), gridw, blockw, lds_dma, stream, g, tab, scr, dm);
+                static const bool pm_lds = getenv("ND_AMD_PM_STREAM_LDS") != nullptr;
+                // Two forms of the from-memory search, same map.  Measured on 24 x 4096^2 (alpha = 0.01 /
+                // 1e-4): one 16-byte piece per variable and step, two steps ahead, 104 VGPRs: 3.23 /
+                // 3.77 ms; two adjacent pieces per variable and step (a sector is fetched by two steps
+                // instead of four, interleaved C12 once), 144 VGPRs: 3.52 / 3.12 ms; LDS images:
+                // 4.34 / 3.95 ms.  At very low thresholds every marginal test fires at once, the
+                // waves run in lockstep and the sector form wins; with the ~1 % of deep searches of
+                // alpha = 0.01 the waves drift apart and the lighter form wins.
+                static const int pm_sector_env = [] {
+                    const char *e = getenv("ND_AMD_PM_STREAM_SECTOR");
+                    return e ? atoi(e) : -1;
+                }();
+                const bool pm_direct4 = pm_sector_env >= 0 ? pm_sector_env != 0 : alpha <= 1e-3;
+                if (pm_lds)
+                    hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 2>), gridw, blockw, lds_dma, stream, g, tab, scr, dm);
+                else if (pm_direct4 && (k % (2 * VE)) == 0)
+                    hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 4>), dim3((unsigned)ceil_div(npix, (int64_t)kRetainThreads)),
+                                       dim3(kRetainThreads), 0, stream, g, tab, scr, dm);
+                else
+                    hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 3>), dim3((unsigned)ceil_div(npix, (int64_t)kRetainThreads)),
+                                       dim3(kRetainThreads), 0, stream, g, tab, scr, dm);
                 g.gate_mode = gated ? 2 : 0;
                 g.dense_min = 65;                            // the sparse form lists pixel by pixel
             }
