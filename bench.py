@@ -364,7 +364,9 @@ def extras(main, barrier, dev):
         entry('OmnibusTest C2 %dt x %d x %d f32 in the reference layout (y, x, time), C12 complex64, '
               'alpha=%g' % (main.k, main.rows, main.nx, alpha), dt, 5, main.npix, km,
               roofline(dom, km[dom], main.alg_bytes,
-                       note='LDS-DMA staging of pixel-major spans (global_load_lds_dwordx4)'),
+                       note='LDS-DMA staging of pixel-major spans (global_load_lds_dwordx4)' if alpha > 0.5 else
+                       'streaming search, every lane reading its own pixel-major series from memory '
+                       'in 16-byte pieces (no LDS images)'),
               res['bad'] == 0 and same, sample=res, equal_to_planar_map=same)
     del ch, ref, c12, pmv
     _free()
