@@ -525,6 +525,9 @@ def main():
         traffic, source = PROFILED_TRAFFIC.get(key, (None, None)) if world == 1 else (None, None)
         if args.traffic_bytes is not None:
             traffic, source = args.traffic_bytes, '--traffic-bytes'
+        # the kernel the roofline is quoted on: the workload's pass A, or (low thresholds, where the
+        # search is fused into the one streaming kernel) whichever kernel takes the time
+        dom_k = w.dom if w.dom in avg else max(avg, key=avg.get)
         res = {
             'metric': w.metric(), 'value': value, 'unit': 'Mpixels/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -541,13 +544,13 @@ def main():
                                'one point-to-point halo exchange per step'),
             },
             'kernels_ms': avg,
-            'roofline': roofline(w.dom, avg[w.dom], w.alg_bytes, traffic=traffic,
+            'roofline': roofline(dom_k, avg[dom_k], w.alg_bytes, traffic=traffic,
                                  traffic_source=source,
                                  note='algorithmic bytes = planes read once + change map written once'
                                  if w.name != 'pipeline' else 'algorithmic bytes = filter input + output'),
         }
         if world == 1 and w.name == 'omnibus':
-            res['roofline']['achieved_read_only'] = w.read_bytes / (avg[w.dom] * 1e-3) / 1e9
+            res['roofline']['achieved_read_only'] = w.read_bytes / (avg[dom_k] * 1e-3) / 1e9
             if args.cpu_rows > 0:
                 res['cpu_baseline'] = cpu_baseline_omnibus(w, out)
             if not args.no_extra:

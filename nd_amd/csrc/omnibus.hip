@@ -30,6 +30,8 @@
 // gsl_cdf_chisq_P(z, f) and (z, f+4) (nd/_change.pyx:147-148): f = (j-1) p^2 with p = 2 is a
 // multiple of 4, so a = f/2 = 2(j-1) is an integer and the regularised incomplete gamma
 // function has closed recurrences (chisq_pair in omnibus_common.hpp).
+#include <type_traits>
+
 #include "omnibus_common.hpp"
 
 namespace nd_amd {
@@ -946,7 +948,7 @@ constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the
 // domain in which x is meaningful -- stops and is reported in `handoff` (pass B redoes the pixel
 // exactly).
 //   mask: bit t set <=> change detected at date t (valid for lanes with !handoff)
-// The screen's per-j constants live in four registers of every wave, entry j in lane j, and are
+// The screen's per-j constants live in four registers of every wave, entry j in lane j - 1, and are
 // fetched with v_readlane (a few cycles, no memory access; the index is wave-uniform).
 struct ScreenRegs {
     int re;
@@ -954,7 +956,7 @@ struct ScreenRegs {
 };
 __device__ __forceinline__ ScreenRegs screen_regs_load(const DenseScreenEntry *scr_lds, const int lane)
 {
-    const DenseScreenEntry e = scr_lds[lane <= kDenseMax ? lane : kDenseMax];
+    const DenseScreenEntry e = scr_lds[lane + 1];          // entries 1 .. 64 in lanes 0 .. 63
     ScreenRegs r;
     r.re = e.re;
     r.rf = e.rf;
@@ -965,10 +967,10 @@ __device__ __forceinline__ ScreenRegs screen_regs_load(const DenseScreenEntry *s
 __device__ __forceinline__ DenseScreenEntry screen_entry(const ScreenRegs &r, const int j)
 {
     DenseScreenEntry c;
-    c.re = __builtin_amdgcn_readlane(r.re, j);
-    c.rf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.rf), j));
-    c.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.a), j));
-    c.b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.b), j));
+    c.re = __builtin_amdgcn_readlane(r.re, j - 1);
+    c.rf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.rf), j - 1));
+    c.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.a), j - 1));
+    c.b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.b), j - 1));
     return c;
 }
 
@@ -1453,18 +1455,19 @@ struct PlaneReader {
     }
 };
 
-template <typename T>
+template <typename T, typename MT>
 __device__ __forceinline__ void screen_decide(const float x, const float m2, const bool sane,
                                               const DenseScreenEntry &c, const int t,
-                                              unsigned &fbits, unsigned &ibits)
+                                              MT &fbits, MT &ibits)
 {
     const bool fires = sane && (x + m2 < c.a);
     const bool cant = sane && (x - m2 > c.b);
-    fbits |= fires ? (1u << t) : 0u;
-    ibits |= (fires || cant) ? 0u : (1u << t);
+    fbits |= fires ? ((MT)1 << t) : (MT)0;
+    ibits |= (fires || cant) ? (MT)0 : ((MT)1 << t);
 }
 
-template <typename T, int PF, int MODE>
+// K64: series of 33 .. 64 dates -- the six test masks and the change mask are 64 bits wide
+template <typename T, int PF, int MODE, bool K64 = false>
 __global__ void __launch_bounds__(MODE == 2 ? 64 : kRetainThreads)
 omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg,
                          const OmniPmDmaArgs<T> pm)
@@ -1563,7 +1566,8 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     const ScreenRegs scr = screen_regs_load(scr_lds, lane);
 
     // ---- phase 1 ----
-    unsigned gF = 0, gI = 0, m2F = 0, m2I = 0, m3F = 0, m3I = 0;
+    typedef typename std::conditional<K64, unsigned long long, unsigned>::type MT;
+    MT gF = 0, gI = 0, m2F = 0, m2I = 0, m3F = 0, m3I = 0;
     bool bad = false;
     int eabs = 0;
     double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0;
@@ -1598,7 +1602,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
             const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
             const float qq = (float)pp * __builtin_amdgcn_rcpf((float)dets);
             const float rel = cu * (float)jj * qq;          // 1.46 * 5 n u * s11 s22 / det
-            screen_decide<T>(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t, gF, gI);
+            screen_decide<T, MT>(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t, gF, gI);
         }
         if (t <= k - 3) {                                   // marginal tests over 2 and 3 dates
             // the reference's sums, in its type and order: (0 + a_t) + a_t+1 (+ a_t+2)
@@ -1608,7 +1612,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
                 const DenseScreenEntry c = screen_entry(scr, 2);
                 const float x = dense_x<T>(dets, oks, e0 + e1, m0 + m1, 2, c);
-                screen_decide<T>(x, 0.f, oks, c, t, m2F, m2I);
+                screen_decide<T, MT>(x, 0.f, oks, c, t, m2F, m2I);
             }
             if (t <= k - 4) {
                 s11 = s11 + d2.a;
@@ -1619,7 +1623,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
                 const DenseScreenEntry c = screen_entry(scr, 3);
                 const float x = dense_x<T>(dets, oks, (e0 + e1) + e2, (m0 + m1) + m2q, 3, c);
-                screen_decide<T>(x, 0.f, oks, c, t, m3F, m3I);
+                screen_decide<T, MT>(x, 0.f, oks, c, t, m3F, m3I);
             }
         }
         d2 = d1;
@@ -1707,10 +1711,10 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
 
     // ---- is this wave dense?  candidates = pixels whose global test over the whole series can fire
-    const bool cand = in && (bad || (((gF | gI) & 1u) != 0u));
+    const bool cand = in && (bad || (((gF | gI) & (MT)1) != 0));
     const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
     bool listed = cand;                                       // a sparse wave lists its candidates
-    unsigned mask = 0;
+    MT mask = 0;
     if (dense) {
         bool handoff = in && bad;
         bool done = !in || bad;
@@ -1718,9 +1722,9 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         for (int l = 0; l < k - 1; ++l) {
             bool act = !done && (cur == l);
             if (!__any(act)) continue;
-            const bool gi = (gI >> l) & 1u, gf = (gF >> l) & 1u;
-            const bool i2 = (m2I >> l) & 1u, f2 = (m2F >> l) & 1u;
-            const bool i3 = (m3I >> l) & 1u, f3 = (m3F >> l) & 1u;
+            const bool gi = (gI >> l) & (MT)1, gf = (gF >> l) & (MT)1;
+            const bool i2 = (m2I >> l) & (MT)1, f2 = (m2F >> l) & (MT)1;
+            const bool i3 = (m3I >> l) & (MT)1, f3 = (m3F >> l) & (MT)1;
             int fire = -1;
             bool deep = false;
             if (act) {
@@ -1799,20 +1803,20 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 }
             }
             if (fire >= 0) {
-                mask |= 1u << fire;                           // :252, l + r with r = j - 1
+                mask |= (MT)1 << fire;                        // :252, l + r with r = j - 1
                 cur = fire;                                   // :255
                 if (cur >= k - 1) done = true;                // :256
             }
         }
-        if (handoff) mask = 0u;                               // pass B writes that pixel's changes
+        if (handoff) mask = 0;                                // pass B writes that pixel's changes
         if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
             if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
                 uint32_t *w = reinterpret_cast<uint32_t *>(res);
                 for (int q = 0; q < (k >> 2); ++q)
-                    w[q] = (((mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    w[q] = (((unsigned)(mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
             } else {
-                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & 1u);
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & (MT)1);
             }
         }
         listed = handoff;
@@ -2312,6 +2316,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         return e ? atof(e) : 0.75;
     }();
     const bool fused = retain && dense_ok && !stats && g.dense_min <= 64 && alpha < fused_alpha;
+    // Series beyond the register forms (33 .. 64 dates; float64: 17 .. 64): the streaming search with
+    // 64-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
+    // (k = 48 at alpha = 0.01: 118 ms per 16.7 Mpx).
+    const bool stream_long = !dense_ok && pm_ids == nullptr && !stats && k <= kDenseMax && dense_env <= 64 &&
+                             alpha < fused_alpha;
+    if (stream_long) g.dense_min = dense_env;
     // The threshold only says that dense waves are LIKELY; whether they are is a property of the
     // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
     // is therefore made on the device from a sample (omnibus_c2_sample_kernel): both variants are
@@ -2526,6 +2536,37 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         if (gated) {
             // the sparse design, should the sample say so (dense waves it still meets go to the
             // separate dense kernel below)
+            g.gate_mode = 2;
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+            launch_retain<T>(g, tab, nblocks, stats, stream);
+        }
+        g.gate_mode = 0;
+    } else if (stream_long) {
+        gated = take_sample();                      // only where the sparse form can retain (k <= 48)
+        const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+        g.gate_mode = gated ? 1 : 0;
+        {
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
+            // the streaming kernel walks 256-pixel blocks whatever the sparse form would use
+            const int64_t bpr_keep = g.blocks_per_row;
+            g.blocks_per_row = ceil_div(g.nx, (int64_t)kRetainThreads);
+            const int64_t nbs = g.blocks_per_row * g.nrows;
+            const dim3 grid((unsigned)nbs), block(kRetainThreads);
+            constexpr int PF = sizeof(T) == 4 ? 6 : 4;
+            OmniPmDmaArgs<T> nopm;
+            memset(&nopm, 0, sizeof(nopm));
+            const bool buf = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
+            if (k <= 32) {
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, false>), grid, block, 0, stream, g, tab, scr, nopm);
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, false>), grid, block, 0, stream, g, tab, scr, nopm);
+            } else {
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, true>), grid, block, 0, stream, g, tab, scr, nopm);
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, true>), grid, block, 0, stream, g, tab, scr, nopm);
+            }
+            g.blocks_per_row = bpr_keep;
+        }
+        g.dense_min = 65;                           // no register search at these lengths
+        if (gated) {
             g.gate_mode = 2;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
             launch_retain<T>(g, tab, nblocks, stats, stream);

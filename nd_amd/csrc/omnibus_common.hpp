@@ -300,7 +300,7 @@ struct DenseScreenEntry {
     int re;
     float rf, a, b;
 };
-constexpr int kDenseMax = 32;
+constexpr int kDenseMax = 64;
 struct DenseScreen {
     DenseScreenEntry e[kDenseMax + 1];
 };
@@ -323,7 +323,10 @@ static DenseScreenEntry make_dense_entry(const OmniTabEntry &t, int j, uint32_t 
     const double eps = sizeof(T) == 4 ? 1.1920928955078125e-07 : 2.220446049250313e-16;
     const bool hi_ok = t.zhi < INFINITY && t.zhi > -INFINITY;
     const bool lo_ok = t.zlo > -INFINITY && t.zlo < INFINITY;
-    const double mg0 = 2e-5 + 4e-7 * (double)j;
+    // beyond 32 dates the float32 arithmetic of x works on magnitudes up to j (ulp 7.6e-6 at 64) and
+    // the fixed-point sum of the mantissa logs passes 2^24 before it is converted: the budget grows
+    // to ~2.5e-5 at j = 64, the margin with it
+    const double mg0 = 2e-5 + 4e-7 * (double)j + (j > 32 ? 1e-6 * (double)(j - 32) : 0.0);
     double Lhi = 0, Llo = 0;
     if (hi_ok) {
         const double zr = 2.0 * eps * fabs(t.zhi);                 // (T) rounding of z

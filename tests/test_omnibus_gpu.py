@@ -162,3 +162,24 @@ def test_pixel_major_kernel_equals_planar(oracle, device, dtype, k):
     assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
     t = torch.zeros((6, 4, 5), device=device).permute(1, 2, 0)
     assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
+
+
+@pytest.mark.parametrize('dtype,k', [(np.float32, 33), (np.float32, 40), (np.float32, 48), (np.float32, 57),
+                                     (np.float32, 64), (np.float64, 17), (np.float64, 40), (np.float64, 64)])
+def test_long_series_at_low_thresholds(oracle, device, dtype, k):
+    """33 .. 64 dates (float64: 17 .. 64) at the thresholds users pass: the streaming search with
+    64-bit masks (`stream_long`), planar and strided inputs, against the oracle byte for byte."""
+    import torch
+    from nd_amd import kernels
+    planes = synth.omnibus_stack(seed=300 + k, k=k, ny=24, nx=200, dtype=dtype, change_frac=0.3)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    dev_tyx = [torch.from_numpy(p).to(device) for p in planes]
+    dev_yxt = [torch.from_numpy(p).to(device) for p in yxt]
+    for alpha in (1e-4, 0.01, 0.2):
+        want = oracle.change_detection_planes(yxt, alpha, 9, njobs=8)
+        got = kernels.change_detection(*dev_tyx, alpha=alpha, n=9, dims=('time', 'y', 'x'))
+        got2 = kernels.change_detection(*dev_yxt, alpha=alpha, n=9, dims=('y', 'x', 'time'))
+        torch.cuda.synchronize()
+        assert int((got.cpu().numpy() != want).sum()) == 0, (k, alpha)
+        assert int((got2.cpu().numpy() != want).sum()) == 0, (k, alpha, 'strided')
+        assert want.sum() > 0
