@@ -58,7 +58,9 @@ def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x')
         _require_cuda(t, name)
         if t.dim() != 3:
             raise ValueError('%s must be 3-D, got shape %s' % (name, tuple(t.shape)))
-        if (t.shape != c11.shape or t.stride() != c11.stride() or t.dtype != c11.dtype
+        # strides of length-1 axes address nothing: views of one buffer may carry different ones
+        same_strides = all(a == b for a, b, n_ in zip(t.stride(), c11.stride(), t.shape) if n_ > 1)
+        if (t.shape != c11.shape or not same_strides or t.dtype != c11.dtype
                 or t.device != c11.device):
             raise ValueError('the four covariance planes must share shape, strides, '
                              'dtype and device')
