@@ -2319,9 +2319,11 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // Series beyond the register forms (33 .. 64 dates; float64: 17 .. 64): the streaming search with
     // 64-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
     // (k = 48 at alpha = 0.01: 118 ms per 16.7 Mpx).
-    const bool stream_long = !dense_ok && pm_ids == nullptr && !stats && k <= kDenseMax && dense_env <= 64 &&
+    const bool stream_long = !dense_ok && pm_ids == nullptr && k <= kDenseMax && dense_env <= 64 &&
                              alpha < fused_alpha;
-    if (stream_long) g.dense_min = dense_env;
+    // z / P rasters asked for on top: they come from one launch of the plain pass A (which
+    // evaluates the whole-series test of every pixel anyway), the map from the streaming search
+    const bool stats_split = stream_long && stats;
     // The threshold only says that dense waves are LIKELY; whether they are is a property of the
     // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
     // is therefore made on the device from a sample (omnibus_c2_sample_kernel): both variants are
@@ -2542,6 +2544,24 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }
         g.gate_mode = 0;
     } else if (stream_long) {
+        if (stats_split) {
+            g.dense_min = 65;
+            {
+                KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+                if (retain)
+                    launch_retain<T>(g, tab, nblocks, true, stream);
+                else if (aligned)
+                    launch_global<T, VPPT>(g, tab, nblocks, true, stream);
+                else
+                    launch_global<T, 1>(g, tab, nblocks, true, stream);
+            }
+            ND_HIP_CHECK(hipGetLastError());
+            // its candidate lists are not used: the search below makes its own
+            ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
+            g.z_out = nullptr;
+            g.p_out = nullptr;
+        }
+        g.dense_min = dense_env;
         gated = take_sample();                      // only where the sparse form can retain (k <= 48)
         const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
         g.gate_mode = gated ? 1 : 0;
@@ -2569,7 +2589,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         if (gated) {
             g.gate_mode = 2;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-            launch_retain<T>(g, tab, nblocks, stats, stream);
+            launch_retain<T>(g, tab, nblocks, stats && !stats_split, stream);
         }
         g.gate_mode = 0;
     } else {

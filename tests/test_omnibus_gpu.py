@@ -183,3 +183,8 @@ def test_long_series_at_low_thresholds(oracle, device, dtype, k):
         assert int((got.cpu().numpy() != want).sum()) == 0, (k, alpha)
         assert int((got2.cpu().numpy() != want).sum()) == 0, (k, alpha, 'strided')
         assert want.sum() > 0
+    # with the z / P rasters on top (they come from a separate launch of the plain pass A)
+    want = oracle.change_detection_planes(yxt, 0.01, 9, njobs=8, stats=True)
+    got = kernels.change_detection(*dev_tyx, alpha=0.01, n=9, dims=('time', 'y', 'x'), stats=True)
+    torch.cuda.synchronize()
+    _compare(tuple(g.cpu().numpy() for g in got), want)
