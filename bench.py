@@ -382,6 +382,13 @@ def extras(main, barrier, dev):
     res = w.check(ch)
     entry(w.describe(), dt, 5, w.npix, km, roofline(w.dom, km[w.dom], w.alg_bytes), res['bad'] == 0,
           sample=res)
+    # the same stack at the reference's default threshold: the full-pol streaming search
+    a3.alpha = 0.01
+    dt, km, ch = timed(w.step, 5, 2, barrier)
+    res = w.check(ch)
+    dom = max(km, key=km.get)
+    entry(w.describe(), dt, 5, w.npix, km, roofline(dom, km[dom], w.alg_bytes,
+          note='search fused into the streaming pass (omnibus_c3_stream_kernel)'), res['bad'] == 0, sample=res)
     del w, ch
     _free()
 

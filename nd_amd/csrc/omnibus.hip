@@ -908,19 +908,7 @@ struct OmniDenseArgs {
 };
 
 // ---- the search itself, on a series held in registers ------------------------------------
-// log2 of a positive finite x as (exponent, log2 of the mantissa in [0.5, 1)): the mantissa's
-// log2 comes from the hardware v_log_f32 (<= 1 ulp of a value in [-1, 0], i.e. <= 6e-8 absolute).
-__device__ __forceinline__ void log2_parts(float x, int &e, float &m)
-{
-    m = __log2f(__builtin_frexpf(x, &e));
-}
-__device__ __forceinline__ void log2_parts(double x, int &e, float &m)
-{
-    m = __log2f((float)__builtin_frexp(x, &e));
-    // (float) of a mantissa just below 1 may round to 1: log2 = 0, error < 1e-7 as budgeted
-}
-
-constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the mantissa logs
+// (log2_parts, the screen registers and dense_x live in omnibus_common.hpp: the full-pol kernels use them too)
 
 
 // nd/_change.pyx:224-257 for one pixel per lane, on a series held in registers (static indices
@@ -950,42 +938,6 @@ constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the
 //   mask: bit t set <=> change detected at date t (valid for lanes with !handoff)
 // The screen's per-j constants live in four registers of every wave, entry j in lane j - 1, and are
 // fetched with v_readlane (a few cycles, no memory access; the index is wave-uniform).
-struct ScreenRegs {
-    int re;
-    float rf, a, b;
-};
-__device__ __forceinline__ ScreenRegs screen_regs_load(const DenseScreenEntry *scr_lds, const int lane)
-{
-    const DenseScreenEntry e = scr_lds[lane + 1];          // entries 1 .. 64 in lanes 0 .. 63
-    ScreenRegs r;
-    r.re = e.re;
-    r.rf = e.rf;
-    r.a = e.a;
-    r.b = e.b;
-    return r;
-}
-__device__ __forceinline__ DenseScreenEntry screen_entry(const ScreenRegs &r, const int j)
-{
-    DenseScreenEntry c;
-    c.re = __builtin_amdgcn_readlane(r.re, j - 1);
-    c.rf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.rf), j - 1));
-    c.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.a), j - 1));
-    c.b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.b), j - 1));
-    return c;
-}
-
-template <typename T>
-__device__ __forceinline__ float dense_x(const T dets, const bool ok, const int Le, const int Lm,
-                                         const int jj, const DenseScreenEntry &c)
-{
-    int es;
-    float ms;
-    log2_parts(ok ? dets : (T)1, es, ms);
-    const int E = (Le - __mul24(jj, es)) - c.re;
-    const float F = (float)Lm * (1.0f / kLogFix);
-    return (float)E + ((F - c.rf) - (float)jj * ms);
-}
-
 // (Parking the per-date logarithms in LDS between the two phases saves 48 registers but puts an
 // LDS round trip into every row of phase 2: measured slower.)
 template <typename T, int KMAX>
@@ -1454,17 +1406,6 @@ struct PlaneReader {
         }
     }
 };
-
-template <typename T, typename MT>
-__device__ __forceinline__ void screen_decide(const float x, const float m2, const bool sane,
-                                              const DenseScreenEntry &c, const int t,
-                                              MT &fbits, MT &ibits)
-{
-    const bool fires = sane && (x + m2 < c.a);
-    const bool cant = sane && (x - m2 > c.b);
-    fbits |= fires ? ((MT)1 << t) : (MT)0;
-    ibits |= (fires || cant) ? (MT)0 : ((MT)1 << t);
-}
 
 // K64: series of 33 .. 64 dates -- the six test masks and the change mask are 64 bits wide
 template <typename T, int PF, int MODE, bool K64 = false>

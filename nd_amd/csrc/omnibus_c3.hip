@@ -179,6 +179,295 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3A
     }
 }
 
+// ---- pass A with the search fused in (low thresholds), streaming form ---------------------------
+// The full-pol counterpart of omnibus_c2_stream_kernel (omnibus.hip), for up to 64 dates.  At the
+// thresholds users pass (the reference's default alpha = 0.01) nearly every pixel changes at
+// nearly every date, and listing every pixel for pass B costs ~25 ns per pixel (54 ms per 2 Mpx at
+// k = 48).  Here the dates are consumed as they arrive, last date first, three in flight:
+//   per date t (branch-free): determinant of the date (the reference's `floating` arithmetic) and
+//     its logarithm as (exponent, fixed-point mantissa log); suffix sums of the nine components in
+//     double -> the global test G(t) over ts[t:] from det3 of those sums; the 2- and 3-date sums
+//     a_t + a_t+1 (+ a_t+2) in the reference's type and order from a rolling window -> the marginal
+//     tests M2(t), M3(t), whose determinants are bit-identical to the reference's.  Each test
+//     leaves two bits (fires / undecided) at position t of six 64-bit masks.
+//   walk: per segment start a handful of bit operations; marginals over four and more dates
+//     (neither M2 nor M3 fires: ~alpha of the rows) re-read the dates from memory.
+// Decisions come from the float32 screen of omnibus_common.hpp (p-agnostic: z = z0 + c L2); whatever
+// it cannot decide for certain hands the pixel to pass B, which redoes it exactly.
+//
+// Global tests use suffix sums in double where the reference sums forward in `floating`.  With
+// every date's matrix positive semi-definite (checked per date: positive diagonal, non-negative
+// 2 x 2 minors, positive determinant -- otherwise the pixel goes to pass B), the forward sums carry
+// relative errors gamma = (n - 1) u on the diagonal and absolute errors gamma sqrt(s_ii s_jj) on
+// each off-diagonal part (Cauchy-Schwarz over the dates), and for
+//   D = abc - a|z|^2 - b|y|^2 - c|x|^2 + 2 Re(x z conj y)
+// the partial derivatives are bounded by bc, ac, ab (diagonal) and 4 sqrt(ab) c ... (off-diagonal,
+// |dx| <= sqrt2 gamma sqrt(ab)), which gives |D_ref - D| <= (3 + 3 * 4 sqrt2) gamma abc < 21 gamma abc
+// plus < 40 u abc for the reference's own evaluation of D in `floating`:
+//   |D_ref - D| <= (21 n + 20) u abc      -> band 1.46 j (21 n + 20) u abc / D in log2 units.
+template <typename T>
+__global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3Args<T> g, const OmniTab tab,
+                                                                       const DenseScreen scr_arg,
+                                                                       const int dense_min)
+{
+    constexpr int PF = 3;
+    typedef unsigned long long MT;
+    __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kC3Threads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+    const int64_t xc = in ? x0 : g.nx - 1;                  // idle lanes re-read the last pixel
+    const int64_t off0 = row * g.sy + xc * g.sx;
+    auto load = [&](const int t, T (&v)[9]) {
+        const int64_t o = off0 + (int64_t)t * g.st;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) v[c] = g.pl[c][o];
+    };
+    T ring[PF][9];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load(k - 1 - u > 0 ? k - 1 - u : 0, ring[u]);
+    if (tid == 0) {
+#pragma unroll 1
+        for (int j = 0; j <= kDenseMax; ++j) scr_lds[j] = scr_arg.e[j];
+    }
+    if (g.write_tab && b == 0)
+        for (int j = tid; j <= k; j += kC3Threads) g.tab_dev[j] = tab.e[j];
+    __syncthreads();
+    const ScreenRegs scr = screen_regs_load(scr_lds, lane);
+
+    // ---- phase 1 ----
+    MT gF = 0, gI = 0, m2F = 0, m2I = 0, m3F = 0, m3I = 0;
+    bool bad = false;
+    int eabs = 0;
+    double S[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) S[c] = 0.0;
+    int Le = 0, Lm = 0;
+    T d1[9], d2[9];                            // dates t + 1, t + 2
+#pragma unroll
+    for (int c = 0; c < 9; ++c) d1[c] = d2[c] = (c < 3) ? (T)1 : (T)0;
+    int e1 = 0, m1 = 0, e2 = 0, m2q = 0;       // their logarithms
+    const float cu = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 1.46f;
+
+    auto process = [&](const T (&q)[9], const int t) {
+        const T det = det3<T>(q);
+        const T mn12 = (q[0] * q[1]) - ((q[3] * q[3]) + (q[4] * q[4]));
+        const T mn13 = (q[0] * q[2]) - ((q[5] * q[5]) + (q[6] * q[6]));
+        const T mn23 = (q[1] * q[2]) - ((q[7] * q[7]) + (q[8] * q[8]));
+        const bool ok = (det > (T)0) && (det < (T)INFINITY) && (q[0] > (T)0) && (q[1] > (T)0) &&
+                        (q[2] > (T)0) && (mn12 >= (T)0) && (mn13 >= (T)0) && (mn23 >= (T)0);
+        bad = bad || !ok;
+        int e0;
+        float mf;
+        log2_parts(ok ? det : (T)1, e0, mf);
+        const int m0 = (int)rintf(mf * kLogFix);
+        eabs += e0 < 0 ? -e0 : e0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) S[c] += (double)q[c];
+        Le += e0;
+        Lm += m0;
+        if (t <= k - 2) {                                   // global test of ts[t:], j = k - t
+            const int jj = k - t;
+            const double dets = det3<double>(S);
+            const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
+            const DenseScreenEntry c = screen_entry(scr, jj);
+            const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
+            const float qq = (float)((S[0] * S[1]) * S[2]) * __builtin_amdgcn_rcpf((float)dets);
+            const float rel = (cu * (21.f * (float)jj + 20.f)) * qq;
+            screen_decide<T, MT>(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t, gF, gI);
+        }
+        if (t <= k - 3) {                                   // marginal tests over 2 and 3 dates
+            T s[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) s[c] = q[c] + d1[c];            // (0 + a_t) + a_t+1
+            {
+                const T dets = det3<T>(s);
+                const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                const DenseScreenEntry c = screen_entry(scr, 2);
+                const float x = dense_x<T>(dets, oks, e0 + e1, m0 + m1, 2, c);
+                screen_decide<T, MT>(x, 0.f, oks, c, t, m2F, m2I);
+            }
+            if (t <= k - 4) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) s[c] = s[c] + d2[c];
+                const T dets = det3<T>(s);
+                const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                const DenseScreenEntry c = screen_entry(scr, 3);
+                const float x = dense_x<T>(dets, oks, (e0 + e1) + e2, (m0 + m1) + m2q, 3, c);
+                screen_decide<T, MT>(x, 0.f, oks, c, t, m3F, m3I);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            d2[c] = d1[c];
+            d1[c] = q[c];
+        }
+        e2 = e1;
+        m2q = m1;
+        e1 = e0;
+        m1 = m0;
+    };
+    for (int tb = k - 1; tb >= 0; tb -= PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb - u;
+            if (t >= 0) {
+                T q[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) q[c] = ring[u][c];
+                if (t - PF >= 0) load(t - PF, ring[u]);               // keep PF dates in flight
+                process(q, t);
+            }
+        }
+    }
+    // the reference's double product of determinants stays in the normal range (omnibus.hip)
+    bad = bad || (eabs > 900);
+
+    const unsigned shard = (unsigned)(b % kC3Shards);
+    const int64_t wpx0 = bpx0 + (tid & ~63);
+    const int64_t wleft = g.nx - wpx0;
+    const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
+    uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
+
+    const bool cand = in && (bad || (((gF | gI) & (MT)1) != 0));
+    const bool dense = __popcll(__ballot(cand)) >= dense_min;
+    bool listed = cand;                                       // a sparse wave lists its candidates
+    MT mask = 0;
+    if (dense) {
+        bool handoff = in && bad;
+        bool done = !in || bad;
+        int cur = 0;
+        for (int l = 0; l < k - 1; ++l) {
+            const bool act = !done && (cur == l);
+            if (!__any(act)) continue;
+            const bool gi = (gI >> l) & (MT)1, gf = (gF >> l) & (MT)1;
+            const bool i2 = (m2I >> l) & (MT)1, f2 = (m2F >> l) & (MT)1;
+            const bool i3 = (m3I >> l) & (MT)1, f3 = (m3F >> l) & (MT)1;
+            int fire = -1;
+            bool deep = false;
+            if (act) {
+                if (gi) {                                     // global test undecided
+                    handoff = true;
+                    done = true;
+                } else if (!gf) {                             // nd/_change.pyx:241-242
+                    done = true;
+                } else if (l + 1 == k - 1) {
+                    fire = l + 1;                             // the 2-date marginal IS the global test
+                } else if (i2) {
+                    handoff = true;
+                    done = true;
+                } else if (f2) {
+                    fire = l + 1;
+                } else if (l + 2 == k - 1) {
+                    fire = l + 2;
+                } else if (i3) {
+                    handoff = true;
+                    done = true;
+                } else if (f3) {
+                    fire = l + 2;
+                } else {
+                    deep = true;
+                }
+            }
+            if (__any(deep)) {
+                if (deep) {
+                    // marginal tests over 4 and more dates: the dates of ts[l:] once more
+                    T s[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) s[c] = (T)0;
+                    int Ld = 0, Lmd = 0;
+                    bool searching = true;
+                    for (int t0 = l; t0 < k && searching; t0 += 2) {
+                        T qb[2][9];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) load(t0 + u < k ? t0 + u : k - 1, qb[u]);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int t = t0 + u;
+                            if (searching && t < k) {
+#pragma unroll
+                                for (int c = 0; c < 9; ++c) s[c] = s[c] + qb[u][c];
+                                const T det = det3<T>(qb[u]);
+                                int e0;
+                                float mf;
+                                log2_parts(det, e0, mf);          // the pixel is not `bad`: det > 0
+                                Ld += e0;
+                                Lmd += (int)rintf(mf * kLogFix);
+                                if (t >= l + 3) {                 // j = 2, 3 are decided: they do not fire
+                                    if (t == k - 1) {
+                                        fire = t;                 // the marginal over ts[l:] IS the global test
+                                        searching = false;
+                                    } else {
+                                        const int jj = t - l + 1;
+                                        const T dets = det3<T>(s);
+                                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                                        const DenseScreenEntry c = scr_lds[jj];
+                                        const float x = dense_x<T>(dets, oks, Ld, Lmd, jj, c);
+                                        if (oks && (x < c.a)) {
+                                            fire = t;
+                                            searching = false;
+                                        } else if (!(oks && (x > c.b))) {      // undecided
+                                            handoff = true;
+                                            done = true;
+                                            searching = false;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (fire >= 0) {
+                mask |= (MT)1 << fire;                        // nd/_change.pyx:252
+                cur = fire;                                   // :255
+                if (cur >= k - 1) done = true;                // :256
+            }
+        }
+        if (handoff) mask = 0;                                // pass B writes that pixel's changes
+        if (in) {
+            uint8_t *res = wob + (int64_t)lane * k;
+            if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
+                uint32_t *w = reinterpret_cast<uint32_t *>(res);
+                for (int q = 0; q < (k >> 2); ++q)
+                    w[q] = (((unsigned)(mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+            } else {
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & (MT)1);
+            }
+        }
+        listed = handoff;
+    }
+    if (__any(listed)) {
+        const unsigned long long lm_ = __ballot(listed);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kC3CounterStride, (unsigned)__popcll(lm_));
+        base = __shfl(base, 0);
+        if (listed)
+            g.flag_idx[(size_t)shard * g.seg + base + (unsigned)__popcll(lm_ & ((1ull << lane) - 1ull))] =
+                (uint32_t)(row * g.nx + x0);
+    }
+    // a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275)
+    if (!dense && wnp > 0) {
+        const int nb = wnp * k;
+        int head = (int)((16 - ((uintptr_t)wob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (lane < head) wob[lane] = 0;
+        const int nvec = (nb - head) >> 4;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        u4 *vz = reinterpret_cast<u4 *>(wob + head);
+        const u4 zero = {0u, 0u, 0u, 0u};
+        for (int i = lane; i < nvec; i += 64) vz[i] = zero;
+        const int tail0 = head + (nvec << 4);
+        if (tail0 + lane < nb) wob[tail0 + lane] = 0;
+    }
+}
+
 // ---- pass B ---------------------------------------------------------------------------------
 template <typename T, bool USE_LDS>
 __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s)
@@ -373,7 +662,15 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     }
     ND_HIP_CHECK(hipMemsetAsync(g.flag_count, 0, kC3CounterBytes, stream));
     const bool stats = z_out != nullptr || p_out != nullptr;
-    {
+    // Low thresholds: the search fused into the streaming pass (speed only, same map).
+    // ND_AMD_C3_FUSED_ALPHA overrides the switch-over (0 = never, 2 = always).
+    static const double fused_alpha = [] {
+        const char *e = getenv("ND_AMD_C3_FUSED_ALPHA");
+        return e ? atof(e) : 0.75;
+    }();
+    const bool fused = k >= 2 && k <= kDenseMax && alpha < fused_alpha;
+    if (!fused || stats) {
+        // the sparse design -- or, with a fused search, only the z / P rasters of it
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (stats)
             hipLaunchKernelGGL((omnibus_c3_global_kernel<T, true>), dim3((unsigned)nblocks),
@@ -383,6 +680,18 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
                                dim3(kC3Threads), 0, stream, g, tab);
     }
     ND_HIP_CHECK(hipGetLastError());
+    if (fused) {
+        if (stats) ND_HIP_CHECK(hipMemsetAsync(g.flag_count, 0, kC3CounterBytes, stream));   // its lists are not used
+        const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+        static const int dense_min = [] {
+            const char *e = getenv("ND_AMD_DENSE_MIN");
+            return e ? atoi(e) : 16;
+        }();
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
+        hipLaunchKernelGGL((omnibus_c3_stream_kernel<T>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
+                           stream, g, tab, scr, dense_min);
+        ND_HIP_CHECK(hipGetLastError());
+    }
 
     // the LDS image of 64 series: up to 150 KB of the CU's 160 KB (one wave per CU then, which still
     // beats a dependent, TLB-missing plane access per date and lane)

@@ -371,6 +371,70 @@ static DenseScreen make_dense_screen(const std::vector<OmniTabEntry> &tab, int k
     return s;
 }
 
+// ---- device side of the screen (shared by the dual-pol and the full-pol kernels) ---------------
+// log2 of a positive finite x as (exponent, log2 of the mantissa in [0.5, 1)): the mantissa's
+// log2 comes from the hardware v_log_f32 (<= 1 ulp of a value in [-1, 0], i.e. <= 6e-8 absolute).
+__device__ __forceinline__ void log2_parts(float x, int &e, float &m)
+{
+    m = __log2f(__builtin_frexpf(x, &e));
+}
+__device__ __forceinline__ void log2_parts(double x, int &e, float &m)
+{
+    m = __log2f((float)__builtin_frexp(x, &e));
+    // (float) of a mantissa just below 1 may round to 1: log2 = 0, error < 1e-7 as budgeted
+}
+
+constexpr float kLogFix = 33554432.f;          // 2^25: fixed-point scale of the mantissa logs
+
+struct ScreenRegs {
+    int re;
+    float rf, a, b;
+};
+__device__ __forceinline__ ScreenRegs screen_regs_load(const DenseScreenEntry *scr_lds, const int lane)
+{
+    const DenseScreenEntry e = scr_lds[lane + 1];          // entries 1 .. 64 in lanes 0 .. 63
+    ScreenRegs r;
+    r.re = e.re;
+    r.rf = e.rf;
+    r.a = e.a;
+    r.b = e.b;
+    return r;
+}
+__device__ __forceinline__ DenseScreenEntry screen_entry(const ScreenRegs &r, const int j)
+{
+    DenseScreenEntry c;
+    c.re = __builtin_amdgcn_readlane(r.re, j - 1);
+    c.rf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.rf), j - 1));
+    c.a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.a), j - 1));
+    c.b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.b), j - 1));
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ float dense_x(const T dets, const bool ok, const int Le, const int Lm,
+                                         const int jj, const DenseScreenEntry &c)
+{
+    int es;
+    float ms;
+    log2_parts(ok ? dets : (T)1, es, ms);
+    const int E = (Le - __mul24(jj, es)) - c.re;
+    const float F = (float)Lm * (1.0f / kLogFix);
+    return (float)E + ((F - c.rf) - (float)jj * ms);
+}
+
+
+template <typename T, typename MT>
+__device__ __forceinline__ void screen_decide(const float x, const float m2, const bool sane,
+                                              const DenseScreenEntry &c, const int t,
+                                              MT &fbits, MT &ibits)
+{
+    const bool fires = sane && (x + m2 < c.a);
+    const bool cant = sane && (x - m2 > c.b);
+    fbits |= fires ? ((MT)1 << t) : (MT)0;
+    ibits |= (fires || cant) ? (MT)0 : ((MT)1 << t);
+}
+
+
 // small cache of per-call tables: they depend only on (k, n_looks, alpha, dtype, p)
 struct TabKey {
     int k, dtype, pol;

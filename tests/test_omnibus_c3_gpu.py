@@ -89,3 +89,44 @@ def test_omnibus_test_class_full_pol_is_opt_in(oracle, device):
     np.testing.assert_array_equal(OmnibusTest(n=looks, alpha=0.9).apply(host).values, want2)
     with pytest.raises(KeyError):
         OmnibusTest(n=looks, alpha=0.9, pol='full').apply(host)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('k', [2, 3, 5, 24, 48, 64])
+def test_c3_low_thresholds_streaming_search(oracle, device, dtype, k):
+    """The thresholds users pass (the reference's default 0.01, the tutorial's 1e-4, and a middle
+    one) run the fused streaming search (omnibus_c3_stream_kernel, up to 64 dates): same map as the
+    generic-p oracle byte for byte, planar and strided, with and without the z / P rasters."""
+    planes = synth.omnibus_stack_c3(seed=100 + k, k=k, ny=12, nx=140, dtype=dtype, change_frac=0.3)
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    for alpha in (1e-4, 0.01, 0.3):
+        want, z0, P0 = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8, stats=True)
+        for layout in ('tyx', 'yxt'):
+            ch, z, P = _run(planes, alpha, 9, device, layout)
+            assert int((ch != want).sum()) == 0, (k, alpha, layout)
+            np.testing.assert_allclose(z, z0, rtol=1e-5, equal_nan=True)
+            np.testing.assert_allclose(P, P0, rtol=1e-5, atol=1e-30, equal_nan=True)
+        if k > 2:
+            assert want.sum() > 0
+
+
+def test_c3_streaming_search_degenerate_values(oracle, device):
+    """Zeros, negatives, NaN, infinities, non-positive-definite dates and tiny / huge magnitudes:
+    whatever the float32 screen cannot vouch for goes to the exact pass, so the map still equals
+    the oracle's."""
+    rng = np.random.default_rng(9)
+    planes = synth.omnibus_stack_c3(seed=77, k=16, ny=10, nx=130, dtype=np.float32, change_frac=0.3)
+    planes = [p.copy() for p in planes]
+    for val in (0.0, -1.0, np.nan, np.inf):
+        m = rng.random(planes[0].shape) < 0.004
+        planes[int(rng.integers(0, 9))][m] = val
+    planes[3][:, 2, 10:40] *= 5.0                      # |C12|^2 > C11 C22: not positive semi-definite
+    for p in planes:
+        p[:, 5, :] *= 1e-12                            # determinants ~1e-36
+        p[:, 6, :] *= 3e9
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    for alpha in (0.01, 0.5):
+        with np.errstate(all='ignore'):
+            want = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8)
+        ch, _, _ = _run(planes, alpha, 9, device)
+        assert int((ch != want).sum()) == 0, alpha

@@ -91,11 +91,11 @@ def case_omnibus(rng):
 
 
 def case_c3(rng):
-    k = int(rng.choice([2, 4, 7, 12, 24, 33]))
+    k = int(rng.choice([2, 3, 4, 7, 12, 24, 33, 48, 63, 64, 65]))
     ny, nx = int(rng.integers(1, 20)), int(rng.integers(1, 200))
     looks = int(rng.choice([3, 9, 16]))
     dtype = rng.choice([np.float32, np.float64])
-    alpha = float(rng.choice([0.5, 0.9, 0.99, 0.9999]))
+    alpha = float(rng.choice([1e-4, 0.01, 0.1, 0.5, 0.9, 0.99, 0.9999]))
     w = wishart(rng, k, ny, nx, looks, dtype, pol=3)
     names = ['C11', 'C22', 'C33', 'C12re', 'C12im', 'C13re', 'C13im', 'C23re', 'C23im']
     planes = [w[n] for n in names]
@@ -104,6 +104,10 @@ def case_c3(rng):
         t0 = rng.integers(1, k, (ny, nx))
         g = np.where((np.arange(k)[:, None, None] >= t0[None]) & m[None], 5.0, 1.0)
         planes = [(p * g).astype(dtype) for p in planes]
+    if rng.random() < 0.3:       # zeros, NaNs, infinities, negative entries, a global scale
+        bad = rng.random((k, ny, nx)) < 0.01
+        planes[int(rng.integers(0, 9))][bad] = rng.choice([0.0, np.nan, np.inf, -1.0])
+        planes = [(p * rng.choice([1.0, 1e-6, 1e5])).astype(dtype) for p in planes]
     desc = dict(k=k, ny=ny, nx=nx, looks=looks, dtype=np.dtype(dtype).name, alpha=alpha)
     with np.errstate(all='ignore'):
         want = O.change_detection_pol([np.moveaxis(p, 0, -1) for p in planes], 3, alpha, looks, njobs=8)
