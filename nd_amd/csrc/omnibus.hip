@@ -1407,8 +1407,10 @@ struct PlaneReader {
     }
 };
 
-// K64: series of 33 .. 64 dates -- the six test masks and the change mask are 64 bits wide
-template <typename T, int PF, int MODE, bool K64 = false>
+// MW: width of the six test masks and of the change mask -- 0: 32 bits (k <= 32), 1: 64 bits
+// (k <= 64), 2: two 64-bit words (k <= 128; the screen's entries 65 .. 128 then sit in a second
+// set of registers, the sum of the mantissa logs is 64 bits wide)
+template <typename T, int PF, int MODE, int MW = 0>
 __global__ void __launch_bounds__(MODE == 2 ? 64 : kRetainThreads)
 omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg,
                          const OmniPmDmaArgs<T> pm)
@@ -1505,14 +1507,24 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     }
     __syncthreads();
     const ScreenRegs scr = screen_regs_load(scr_lds, lane);
+    ScreenRegs scr_hi = scr;
+    if (MW == 2) scr_hi = screen_regs_load(scr_lds + 64, lane);          // entries 65 .. 128
+    auto entry_of = [&](const int jj) -> DenseScreenEntry {
+        if (MW == 2 && jj > 64) return screen_entry(scr_hi, jj - 64);
+        return screen_entry(scr, jj);
+    };
 
     // ---- phase 1 ----
-    typedef typename std::conditional<K64, unsigned long long, unsigned>::type MT;
-    MT gF = 0, gI = 0, m2F = 0, m2I = 0, m3F = 0, m3I = 0;
+    typedef typename std::conditional<MW == 2, Bits128,
+                                      typename std::conditional<MW == 1, unsigned long long, unsigned>::type>::type MT;
+    typedef typename std::conditional<MW == 2, long long, int>::type LmT;
+    MT gF = mask_zero<MT>(), gI = mask_zero<MT>(), m2F = mask_zero<MT>(), m2I = mask_zero<MT>(),
+       m3F = mask_zero<MT>(), m3I = mask_zero<MT>();
     bool bad = false;
     int eabs = 0;
     double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0;
-    int Le = 0, Lm = 0;
+    int Le = 0;
+    LmT Lm = 0;
     DateVal<T> d1, d2;                         // dates t + 1, t + 2
     d1.a = d1.d = d2.a = d2.d = (T)1;
     d1.b = d1.c = d2.b = d2.c = (T)0;
@@ -1539,7 +1551,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
             const double pp = S11 * S22;
             const double dets = pp - ((S12r * S12r) + (S12i * S12i));
             const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
-            const DenseScreenEntry c = screen_entry(scr, jj);
+            const DenseScreenEntry c = entry_of(jj);
             const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
             const float qq = (float)pp * __builtin_amdgcn_rcpf((float)dets);
             const float rel = cu * (float)jj * qq;          // 1.46 * 5 n u * s11 s22 / det
@@ -1652,10 +1664,10 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
 
     // ---- is this wave dense?  candidates = pixels whose global test over the whole series can fire
-    const bool cand = in && (bad || (((gF | gI) & (MT)1) != 0));
+    const bool cand = in && (bad || mask_bit(gF, 0) || mask_bit(gI, 0));
     const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
     bool listed = cand;                                       // a sparse wave lists its candidates
-    MT mask = 0;
+    MT mask = mask_zero<MT>();
     if (dense) {
         bool handoff = in && bad;
         bool done = !in || bad;
@@ -1663,9 +1675,9 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         for (int l = 0; l < k - 1; ++l) {
             bool act = !done && (cur == l);
             if (!__any(act)) continue;
-            const bool gi = (gI >> l) & (MT)1, gf = (gF >> l) & (MT)1;
-            const bool i2 = (m2I >> l) & (MT)1, f2 = (m2F >> l) & (MT)1;
-            const bool i3 = (m3I >> l) & (MT)1, f3 = (m3F >> l) & (MT)1;
+            const bool gi = mask_bit(gI, l), gf = mask_bit(gF, l);
+            const bool i2 = mask_bit(m2I, l), f2 = mask_bit(m2F, l);
+            const bool i3 = mask_bit(m3I, l), f3 = mask_bit(m3F, l);
             int fire = -1;
             bool deep = false;
             if (act) {
@@ -1696,7 +1708,8 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 // marginal tests over 4 and more dates: the dates of ts[l:] once more, from memory
                 if (deep) {
                     T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
-                    int Ld = 0, Lmd = 0;
+                    int Ld = 0;
+                    LmT Lmd = 0;
                     bool searching = true;
                     // four dates in flight per round trip (most searches end at j = 4 or 5)
                     for (int t0 = l; t0 < k && searching; t0 += 4) {
@@ -1744,20 +1757,20 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 }
             }
             if (fire >= 0) {
-                mask |= (MT)1 << fire;                        // :252, l + r with r = j - 1
+                mask_set(mask, fire, true);                   // :252, l + r with r = j - 1
                 cur = fire;                                   // :255
                 if (cur >= k - 1) done = true;                // :256
             }
         }
-        if (handoff) mask = 0;                                // pass B writes that pixel's changes
+        if (handoff) mask = mask_zero<MT>();                  // pass B writes that pixel's changes
         if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
             if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
                 uint32_t *w = reinterpret_cast<uint32_t *>(res);
                 for (int q = 0; q < (k >> 2); ++q)
-                    w[q] = (((unsigned)(mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    w[q] = (mask_nibble(mask, q) * 0x00204081u) & 0x01010101u;
             } else {
-                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & (MT)1);
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)(mask_bit(mask, t) ? 1 : 0);
             }
         }
         listed = handoff;
@@ -2257,8 +2270,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         return e ? atof(e) : 0.75;
     }();
     const bool fused = retain && dense_ok && !stats && g.dense_min <= 64 && alpha < fused_alpha;
-    // Series beyond the register forms (33 .. 64 dates; float64: 17 .. 64): the streaming search with
-    // 64-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
+    // Series beyond the register forms (33 .. 128 dates; float64: 17 .. 128): the streaming search with
+    // 64- or 128-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
     // (k = 48 at alpha = 0.01: 118 ms per 16.7 Mpx).
     const bool stream_long = !dense_ok && pm_ids == nullptr && k <= kDenseMax && dense_env <= 64 &&
                              alpha < fused_alpha;
@@ -2518,11 +2531,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             memset(&nopm, 0, sizeof(nopm));
             const bool buf = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
             if (k <= 32) {
-                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, false>), grid, block, 0, stream, g, tab, scr, nopm);
-                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, false>), grid, block, 0, stream, g, tab, scr, nopm);
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, scr, nopm);
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 0>), grid, block, 0, stream, g, tab, scr, nopm);
+            } else if (k <= 64) {
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 1>), grid, block, 0, stream, g, tab, scr, nopm);
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 1>), grid, block, 0, stream, g, tab, scr, nopm);
             } else {
-                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, true>), grid, block, 0, stream, g, tab, scr, nopm);
-                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, true>), grid, block, 0, stream, g, tab, scr, nopm);
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 2>), grid, block, 0, stream, g, tab, scr, nopm);
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 2>), grid, block, 0, stream, g, tab, scr, nopm);
             }
             g.blocks_per_row = bpr_keep;
         }

@@ -668,7 +668,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         const char *e = getenv("ND_AMD_C3_FUSED_ALPHA");
         return e ? atof(e) : 0.75;
     }();
-    const bool fused = k >= 2 && k <= kDenseMax && alpha < fused_alpha;
+    const bool fused = k >= 2 && k <= 64 && alpha < fused_alpha;      // 64-bit masks
     if (!fused || stats) {
         // the sparse design -- or, with a fused search, only the z / P rasters of it
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);

@@ -300,7 +300,7 @@ struct DenseScreenEntry {
     int re;
     float rf, a, b;
 };
-constexpr int kDenseMax = 64;
+constexpr int kDenseMax = 128;
 struct DenseScreen {
     DenseScreenEntry e[kDenseMax + 1];
 };
@@ -325,7 +325,7 @@ static DenseScreenEntry make_dense_entry(const OmniTabEntry &t, int j, uint32_t 
     const bool lo_ok = t.zlo > -INFINITY && t.zlo < INFINITY;
     // beyond 32 dates the float32 arithmetic of x works on magnitudes up to j (ulp 7.6e-6 at 64) and
     // the fixed-point sum of the mantissa logs passes 2^24 before it is converted: the budget grows
-    // to ~2.5e-5 at j = 64, the margin with it
+    // to ~2.5e-5 at j = 64 and ~6e-5 at j = 128, the margin with it (4.6e-5 / 1.7e-4)
     const double mg0 = 2e-5 + 4e-7 * (double)j + (j > 32 ? 1e-6 * (double)(j - 32) : 0.0);
     double Lhi = 0, Llo = 0;
     if (hi_ok) {
@@ -410,8 +410,10 @@ __device__ __forceinline__ DenseScreenEntry screen_entry(const ScreenRegs &r, co
     return c;
 }
 
-template <typename T>
-__device__ __forceinline__ float dense_x(const T dets, const bool ok, const int Le, const int Lm,
+// Lm: sum of the dates' fixed-point mantissa logs (each in [-2^25, 0]): int up to 64 dates, long long
+// beyond
+template <typename T, typename LmT>
+__device__ __forceinline__ float dense_x(const T dets, const bool ok, const int Le, const LmT Lm,
                                          const int jj, const DenseScreenEntry &c)
 {
     int es;
@@ -422,6 +424,52 @@ __device__ __forceinline__ float dense_x(const T dets, const bool ok, const int 
     return (float)E + ((F - c.rf) - (float)jj * ms);
 }
 
+// ---- bit masks over the dates (position t = date t) ------------------------------------------
+// 32 and 64 dates: plain integers.  Up to 128 dates: two 64-bit words.
+struct Bits128 {
+    unsigned long long lo, hi;
+};
+template <typename M>
+__device__ __forceinline__ M mask_zero()
+{
+    return (M)0;
+}
+template <>
+__device__ __forceinline__ Bits128 mask_zero<Bits128>()
+{
+    return Bits128{0ull, 0ull};
+}
+// set bit i (any i, per lane) where `on`
+template <typename M>
+__device__ __forceinline__ void mask_set(M &m, const int i, const bool on)
+{
+    m |= on ? ((M)1 << i) : (M)0;
+}
+__device__ __forceinline__ void mask_set(Bits128 &m, const int i, const bool on)
+{
+    const unsigned long long b = on ? (1ull << (i & 63)) : 0ull;
+    m.lo |= i < 64 ? b : 0ull;
+    m.hi |= i < 64 ? 0ull : b;
+}
+template <typename M>
+__device__ __forceinline__ bool mask_bit(const M &m, const int i)
+{
+    return ((m >> i) & (M)1) != 0;
+}
+__device__ __forceinline__ bool mask_bit(const Bits128 &m, const int i)
+{
+    return (((i < 64 ? m.lo : m.hi) >> (i & 63)) & 1ull) != 0ull;
+}
+// bits 4 q .. 4 q + 3
+template <typename M>
+__device__ __forceinline__ unsigned mask_nibble(const M &m, const int q)
+{
+    return (unsigned)(m >> (4 * q)) & 0xFu;
+}
+__device__ __forceinline__ unsigned mask_nibble(const Bits128 &m, const int q)
+{
+    return (unsigned)((q < 16 ? m.lo : m.hi) >> (4 * (q & 15))) & 0xFu;
+}
 
 template <typename T, typename MT>
 __device__ __forceinline__ void screen_decide(const float x, const float m2, const bool sane,
@@ -430,8 +478,8 @@ __device__ __forceinline__ void screen_decide(const float x, const float m2, con
 {
     const bool fires = sane && (x + m2 < c.a);
     const bool cant = sane && (x - m2 > c.b);
-    fbits |= fires ? ((MT)1 << t) : (MT)0;
-    ibits |= (fires || cant) ? (MT)0 : ((MT)1 << t);
+    mask_set(fbits, t, fires);
+    mask_set(ibits, t, !(fires || cant));
 }
 
 

@@ -165,13 +165,16 @@ def test_pixel_major_kernel_equals_planar(oracle, device, dtype, k):
 
 
 @pytest.mark.parametrize('dtype,k', [(np.float32, 33), (np.float32, 40), (np.float32, 48), (np.float32, 57),
-                                     (np.float32, 64), (np.float64, 17), (np.float64, 40), (np.float64, 64)])
+                                     (np.float32, 64), (np.float64, 17), (np.float64, 40), (np.float64, 64),
+                                     (np.float32, 65), (np.float32, 96), (np.float32, 127), (np.float32, 128),
+                                     (np.float64, 100), (np.float32, 129)])
 def test_long_series_at_low_thresholds(oracle, device, dtype, k):
-    """33 .. 64 dates (float64: 17 .. 64) at the thresholds users pass: the streaming search with
-    64-bit masks (`stream_long`), planar and strided inputs, against the oracle byte for byte."""
+    """33 .. 128 dates (float64: 17 .. 128) at the thresholds users pass: the streaming search with
+    64- / 128-bit masks (`stream_long`), planar and strided inputs, against the oracle byte for
+    byte (129 dates: beyond the fast forms, still exact)."""
     import torch
     from nd_amd import kernels
-    planes = synth.omnibus_stack(seed=300 + k, k=k, ny=24, nx=200, dtype=dtype, change_frac=0.3)
+    planes = synth.omnibus_stack(seed=300 + k, k=k, ny=24 if k <= 64 else 6, nx=200, dtype=dtype, change_frac=0.3)
     yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
     dev_tyx = [torch.from_numpy(p).to(device) for p in planes]
     dev_yxt = [torch.from_numpy(p).to(device) for p in yxt]
