@@ -699,7 +699,7 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     }
     const int64_t kh = ymax - ymin + 1, kw = xmax - xmin + 1;
     if (kh > kMaxKH || kw > kMaxKH || (kw != 1 && kw != 3 && kw != 5 && kw != 7 && kw != 9 &&
-                                        kw != 11))
+                                        kw != 11 && kw != 13 && kw != 15))
         return 0;
     if (dims[2] < 1 || dims[3] < 1 || dims[2] > 0x7fffffffLL || dims[3] > 0x7fffffffLL) return 0;
     // windows reaching farther than twice the plane from it hit the non-periodic corner of
@@ -768,7 +768,9 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
         case 5: launch_tiled<T, 5>(a, box, nblocks, lds, stream); break;
         case 7: launch_tiled<T, 7>(a, box, nblocks, lds, stream); break;
         case 9: launch_tiled<T, 9>(a, box, nblocks, lds, stream); break;
-        default: launch_tiled<T, 11>(a, box, nblocks, lds, stream); break;
+        case 11: launch_tiled<T, 11>(a, box, nblocks, lds, stream); break;
+        case 13: launch_tiled<T, 13>(a, box, nblocks, lds, stream); break;
+        default: launch_tiled<T, 15>(a, box, nblocks, lds, stream); break;
         }
     }
     return 1;

@@ -855,16 +855,26 @@ static bool launch_stream3(const NlmTiledArgs &a, int64_t nb, hipStream_t stream
 #undef ND_S3
 }
 
+// Dynamic LDS beyond the default 64 KB limit (up to kBigLds of the CU's 160 KB: one block per CU
+// then -- still tens of times faster than the generic kernel the request would otherwise fall to)
+constexpr size_t kBigLds = 150 * 1024;
+#define ND_LAUNCH_LDS(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS)                                          \
+    do {                                                                                              \
+        if ((LDS) > 64 * 1024)                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));        \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ARGS);                                   \
+    } while (0)
+
 template <int R1>
 static void launch_roll(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
 {
     // square windows up to 11 x 11 get the fully unrolled row loop
     if (R1 >= 1 && R1 <= 5 && a.r0 == R1)
-        hipLaunchKernelGGL((nlmeans_window_roll_kernel<R1, (R1 >= 1 && R1 <= 5) ? R1 : -1>),
-                           dim3((unsigned)nb), dim3(256), lds, stream, a);
+        ND_LAUNCH_LDS((nlmeans_window_roll_kernel<R1, (R1 >= 1 && R1 <= 5) ? R1 : -1>),
+                      dim3((unsigned)nb), dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((nlmeans_window_roll_kernel<R1, -1>), dim3((unsigned)nb), dim3(256), lds,
-                           stream, a);
+        ND_LAUNCH_LDS((nlmeans_window_roll_kernel<R1, -1>), dim3((unsigned)nb), dim3(256), lds, stream, a);
 }
 
 static bool launch_roll_r1(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
@@ -1368,11 +1378,9 @@ static void launch_patch2(const NlmTiledArgs &a, int64_t nslices, size_t lds, hi
     constexpr int TYW = Patch2Rows<V>::TYW;
     const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nslices;
     if (a.n_eff >= 0)
-        hipLaunchKernelGGL((nlmeans_patch2_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256),
-                           lds, stream, a);
+        ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((nlmeans_patch2_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256),
-                           lds, stream, a);
+        ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256), lds, stream, a);
 }
 
 template <int F>
@@ -1393,11 +1401,9 @@ static void launch_patch(const NlmTiledArgs &a, int64_t nslices, size_t lds, hip
     constexpr int TYW = (V == 1) ? 16 : 8;
     const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nslices;
     if (a.n_eff >= 0)
-        hipLaunchKernelGGL((nlmeans_patch_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256),
-                           lds, stream, a);
+        ND_LAUNCH_LDS((nlmeans_patch_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL((nlmeans_patch_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256),
-                           lds, stream, a);
+        ND_LAUNCH_LDS((nlmeans_patch_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256), lds, stream, a);
 }
 
 template <int F>
@@ -1483,7 +1489,7 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
             const size_t nw = ((2 * (size_t)a.r1 + 4) + 3) / 4 * 4;
             const size_t lds_r = (size_t)(2 * rz + 1) * (kWinTY + 2 * a.r0) * (kWinTX - 4 + nw) * sizeof(float);
             const int64_t nbr = (int64_t)a.tiles_x * a.tiles_y * nvars;
-            if (lds_r <= 64 * 1024 && nbr <= 0x7fffffffLL) {
+            if (lds_r <= kBigLds && nbr <= 0x7fffffffLL) {
                 KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
                 if (launch_roll_r1(a, nbr, lds_r, stream)) return 1;
             }
@@ -1517,7 +1523,7 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
         const size_t lds2 = (size_t)nvars * rows2 * cols2 * sizeof(float) + (rows2 + cols2) * sizeof(int);
         a.tiles_x = (int)ceil_div(ex + 1, tx2);        // + 1: the tiles start on an even global column
         a.tiles_y = (int)ceil_div(ey, 4 * tyw2);
-        if (lds2 <= 64 * 1024 && (int64_t)a.tiles_x * a.tiles_y * nsl <= 0x7fffffffLL) {
+        if (lds2 <= kBigLds && (int64_t)a.tiles_x * a.tiles_y * nsl <= 0x7fffffffLL) {
             KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
             bool ok2 = false;
             switch (F0) {
@@ -1534,7 +1540,7 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
     const size_t cols = 64 + 2 * (a.r1 + F0);
     const size_t rows = 4 * tyw + 2 * (a.r0 + F0);
     const size_t lds = (size_t)nvars * rows * cols * sizeof(float) + (rows + cols) * sizeof(int);
-    if (lds > 64 * 1024) return 0;
+    if (lds > kBigLds) return 0;
     if ((int64_t)a.tiles_x * a.tiles_y * nsl > 0x7fffffffLL) return 0;
     KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
     bool ok = false;

@@ -130,7 +130,7 @@ def test_tiled_edges_and_tiny_planes(device):
     rng = np.random.default_rng(22)
     for shape in [(2, 33, 129), (1, 65, 257), (3, 2, 3), (1, 1, 300), (2, 31, 127)]:
         a = rng.normal(size=shape).astype(np.float32)
-        for kshape in [(1, 5, 5), (1, 11, 3), (1, 1, 7), (1, 9, 1)]:
+        for kshape in [(1, 5, 5), (1, 11, 3), (1, 1, 7), (1, 9, 1), (1, 15, 15), (1, 3, 13)]:
             k = rng.normal(size=kshape)
             for mode in ('reflect', 'nearest', 'mirror', 'wrap'):
                 np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode),

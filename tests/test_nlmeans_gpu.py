@@ -187,6 +187,9 @@ def test_tiny_weights_follow_the_reference(oracle, device):
     ((3, 37, 131, 2), (1, 2, 2), (1, 1, 1), 0.5, 0.5, 9.0),
     ((7, 70, 259, 1), (1, 4, 4), (1, 1, 1), 0.5, 0.5, -1),
     ((4, 33, 140, 2), (1, 5, 5), (1, 2, 2), 0.5, 0.5, 30.0),
+    # five- and seven-date windows: the ring kernel with more than 64 KB of LDS
+    ((7, 40, 150, 2), (2, 3, 3), (1, 1, 1), 0.5, 0.5, -1),
+    ((9, 36, 131, 1), (3, 2, 2), (1, 1, 1), 0.5, 0.5, 12.0),
 ])
 def test_time_first_layout_window_kernel(oracle, device, case):
     """(time, y, x, var) views of planar stacks, 3-D search window: the reference-compatible mode

@@ -28,3 +28,47 @@ else:
     for alpha in (0.99, 0.5, 0.01):
         ms = t_ms(lambda: kernels.change_detection_c3([st[c] for c in range(9)], alpha=alpha, n=9), 1)
         print('c3 f32 k=48 512x4096 alpha=%g: %.2f ms' % (alpha, ms), flush=True)
+
+if what == 'filters':
+    import numpy as np
+    g = torch.Generator(device=dev).manual_seed(3)
+    k, ny, nx = 8, 2048, 2048
+    for dt in (torch.float32, torch.float64):
+        x = (torch.rand((k, ny, nx), generator=g, device=dev) + 0.5).to(dt)
+        y = torch.empty_like(x)
+        for desc, kern, kw in (('box3', np.ones((1, 3, 3)) / 9, {}), ('box5', np.ones((1, 5, 5)) / 25, {}),
+                               ('box9', np.ones((1, 9, 9)) / 81, {}), ('box15', np.ones((1, 15, 15)) / 225, {}),
+                               ('rand5 zeros', np.where(np.random.default_rng(0).random((1, 5, 5)) < 0.3, 0, 1.0), {}),
+                               ('rand4x6', np.random.default_rng(1).normal(size=(1, 4, 6)), {}),
+                               ('box5 constant', np.ones((1, 5, 5)) / 25, dict(mode='constant')),
+                               ('box3x3x3', np.ones((3, 3, 3)) / 27, {}), ('box 1x1x7', np.ones((1, 1, 7)) / 7, {}),
+                               ('box 3x1x1 (time)', np.ones((3, 1, 1)) / 3, {})):
+            ms = t_ms(lambda: kernels.convolve(x, kern, out=y, **kw), 2)
+            print('conv %s %-18s 8x2048x2048: %8.2f ms  %.2f ns/elem' % (str(dt)[6:], desc, ms, ms * 1e6 / x.numel()), flush=True)
+        for sg in ((0, 1, 1), (0, 2.5, 2.5), (1, 1, 1), (0, 1, 0), (0, 0, 3)):
+            ms = t_ms(lambda: kernels.gaussian_filter(x, sg, out=y), 2)
+            print('gauss %s sigma=%-14s 8x2048x2048: %8.2f ms' % (str(dt)[6:], sg, ms), flush=True)
+    del x, y
+    torch.cuda.empty_cache()
+if what == 'nlm':
+    g = torch.Generator(device=dev).manual_seed(4)
+    for dt in (torch.float32, torch.float64):
+        for nv in (1, 4):
+            k, ny, nx = 6, 1024, 2048
+            x = (torch.rand((nv, k, ny, nx), generator=g, device=dev) + 0.5).to(dt)
+            y = torch.empty_like(x)
+            for pm in (0, 1):
+                for (r, f, ne) in (((0, 3, 3), (0, 1, 1), -1), ((0, 3, 3), (0, 1, 1), 50.0), ((0, 10, 10), (0, 3, 3), -1),
+                                   ((1, 3, 3), (1, 1, 1), 50.0), ((2, 3, 3), (1, 1, 1), -1), ((0, 3, 3), (0, 0, 0), -1),
+                                   ((0, 6, 6), (0, 2, 2), -1), ((1, 3, 3), (0, 1, 1), -1)):
+                    if dt == torch.float64 and (r[1] > 3 or r[0] > 1): continue
+                    def run():
+                        if r[0] == 0 and f[0] == 0:
+                            kernels.pixelwise_nlmeans_3d(x.permute(2, 3, 1, 0), y.permute(2, 3, 1, 0), (r[1], r[2], 0), (f[1], f[2], 0), 0.5, 0.5, ne, patch_mode=pm, neff_policy=0)
+                        else:
+                            kernels.pixelwise_nlmeans_3d(x.permute(1, 2, 3, 0), y.permute(1, 2, 3, 0), r, f, 0.5, 0.5, ne, patch_mode=pm, neff_policy=0)
+                    ms = t_ms(run, 1)
+                    nq = (2 * r[0] + 1) * (2 * r[1] + 1) * (2 * r[2] + 1) - 1
+                    print('nlm %s nv=%d pm=%d r=%s f=%s n_eff=%g: %9.2f ms  %.3f ns/(elem.neighbour)' % (str(dt)[6:], nv, pm, r, f, ne, ms, ms * 1e6 / (x.numel() * nq)), flush=True)
+            del x, y
+            torch.cuda.empty_cache()
