@@ -72,3 +72,33 @@ if what == 'nlm':
                     print('nlm %s nv=%d pm=%d r=%s f=%s n_eff=%g: %9.2f ms  %.3f ns/(elem.neighbour)' % (str(dt)[6:], nv, pm, r, f, ne, ms, ms * 1e6 / (x.numel() * nq)), flush=True)
             del x, y
             torch.cuda.empty_cache()
+
+if what == 'api':
+    # the drop-in classes on device datasets: reference layout (y, x, time) and time-first
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    from nd_amd.filters import BoxcarFilter, GaussianFilter, NLMeansFilter, ConvolutionFilter
+    import numpy as np
+    for k in (24, 48):
+        ny, nx = 2048, 4096
+        st = synth.wishart_c2_stack(k, ny, nx, looks=9, seed=12, device=dev, change_frac=0.01)
+        for layout in (('y', 'x', 'time'), ('time', 'y', 'x')):
+            ds = xr_lite.Dataset()
+            if layout[0] == 'y':
+                v = [st[i].permute(1, 2, 0).contiguous() for i in range(4)]
+            else:
+                v = [st[i].contiguous() for i in range(4)]
+            ds['C11'] = (layout, v[0]); ds['C12'] = (layout, torch.complex(v[1], v[2])); ds['C22'] = (layout, v[3])
+            algos = [('OmnibusTest a=0.99', OmnibusTest(n=9, alpha=0.99)), ('OmnibusTest a=0.01', OmnibusTest(n=9, alpha=0.01)),
+                     ('OmnibusTest ml=3 a=0.01', OmnibusTest(ml=3, alpha=0.01)), ('Boxcar w=3', BoxcarFilter(w=3)),
+                     ('Boxcar w=5', BoxcarFilter(w=5)), ('Gaussian s=1', GaussianFilter(sigma=1.0)),
+                     ('Convolution rand3x3', ConvolutionFilter(kernel=np.random.default_rng(0).normal(size=(3, 3)))),
+                     ('NLMeans tutorial', NLMeansFilter(dims=('time', 'y', 'x'), r=(1, 3, 3), f=1, sigma=0.5, h=0.5, n_eff=50)),
+                     ('NLMeans (y,x) r=3', NLMeansFilter(dims=('y', 'x'), r=3, f=1, sigma=0.5, h=0.5))]
+            for name, algo in algos:
+                ms = t_ms(lambda: algo.apply(ds), 2)
+                print('api k=%d layout=%s %-26s: %8.2f ms' % (k, ''.join(d[0] for d in layout), name, ms), flush=True)
+            del ds, v
+            torch.cuda.empty_cache()
+        del st
+        torch.cuda.empty_cache()
