@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes of pass A from the rocprofv3 PMC passes of an earlier run of the same command
 # (2 x FETCH_SIZE + WRITE_SIZE); reported with its source, never as a live measurement
-PROFILED_TRAFFIC = {('omnibus', 24, 4096, 4096, 0.99): (6.9769e9, 'profiles/r01_omnibus_rocprof.txt')}
+PROFILED_TRAFFIC = {('omnibus', 24, 4096, 4096, 0.99): (6.9762e9, 'profiles/r02_final_omnibus_rocprof.txt')}
 
 DEFAULTS = {'omnibus': (24, 4096, 4096), 'c3': (48, 1024, 8192), 'pipeline': (24, 2048, 16384)}
 # tutorial parameters (examples/tutorial_s1.ipynb cells 11, 15; NLMeansFilter defaults sigma=h=f=1)
