@@ -16,6 +16,8 @@
 // pixel's series (LDS-staged when it fits) and runs the same one-sweep-per-segment search as the
 // dual-pol kernel.  f = 9 (j-1) is odd for even j, so a = f/2 can be a half-integer: the
 // chi-square pair handles both (omnibus_common.hpp).
+#include <type_traits>
+
 #include "omnibus_common.hpp"
 
 namespace nd_amd {
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3A
 }
 
 // ---- pass A with the search fused in (low thresholds), streaming form ---------------------------
-// The full-pol counterpart of omnibus_c2_stream_kernel (omnibus.hip), for up to 64 dates.  At the
+// The full-pol counterpart of omnibus_c2_stream_kernel (omnibus.hip), for up to 128 dates.  At the
 // thresholds users pass (the reference's default alpha = 0.01) nearly every pixel changes at
 // nearly every date, and listing every pixel for pass B costs ~25 ns per pixel (54 ms per 2 Mpx at
 // k = 48).  Here the dates are consumed as they arrive, last date first, three in flight:
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3A
 //     double -> the global test G(t) over ts[t:] from det3 of those sums; the 2- and 3-date sums
 //     a_t + a_t+1 (+ a_t+2) in the reference's type and order from a rolling window -> the marginal
 //     tests M2(t), M3(t), whose determinants are bit-identical to the reference's.  Each test
-//     leaves two bits (fires / undecided) at position t of six 64-bit masks.
+//     leaves two bits (fires / undecided) at position t of six 64- or 128-bit masks.
 //   walk: per segment start a handful of bit operations; marginals over four and more dates
 //     (neither M2 nor M3 fires: ~alpha of the rows) re-read the dates from memory.
 // Decisions come from the float32 screen of omnibus_common.hpp (p-agnostic: z = z0 + c L2); whatever
@@ -205,13 +207,16 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3A
 // |dx| <= sqrt2 gamma sqrt(ab)), which gives |D_ref - D| <= (3 + 3 * 4 sqrt2) gamma abc < 21 gamma abc
 // plus < 40 u abc for the reference's own evaluation of D in `floating`:
 //   |D_ref - D| <= (21 n + 20) u abc      -> band 1.46 j (21 n + 20) u abc / D in log2 units.
-template <typename T>
+// MW = 1: 64-bit masks (k <= 64); 2: two-word masks, second register set of screen entries, 64-bit
+// sum of the mantissa logs (k <= 128) -- as in omnibus_c2_stream_kernel
+template <typename T, int MW>
 __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3Args<T> g, const OmniTab tab,
                                                                        const DenseScreen scr_arg,
                                                                        const int dense_min)
 {
     constexpr int PF = 3;
-    typedef unsigned long long MT;
+    typedef typename std::conditional<MW == 2, Bits128, unsigned long long>::type MT;
+    typedef typename std::conditional<MW == 2, long long, int>::type LmT;
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t b = blockIdx.x;
@@ -239,15 +244,23 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
         for (int j = tid; j <= k; j += kC3Threads) g.tab_dev[j] = tab.e[j];
     __syncthreads();
     const ScreenRegs scr = screen_regs_load(scr_lds, lane);
+    ScreenRegs scr_hi = scr;
+    if (MW == 2) scr_hi = screen_regs_load(scr_lds + 64, lane);          // entries 65 .. 128
+    auto entry_of = [&](const int jj) -> DenseScreenEntry {
+        if (MW == 2 && jj > 64) return screen_entry(scr_hi, jj - 64);
+        return screen_entry(scr, jj);
+    };
 
     // ---- phase 1 ----
-    MT gF = 0, gI = 0, m2F = 0, m2I = 0, m3F = 0, m3I = 0;
+    MT gF = mask_zero<MT>(), gI = mask_zero<MT>(), m2F = mask_zero<MT>(), m2I = mask_zero<MT>(),
+       m3F = mask_zero<MT>(), m3I = mask_zero<MT>();
     bool bad = false;
     int eabs = 0;
     double S[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) S[c] = 0.0;
-    int Le = 0, Lm = 0;
+    int Le = 0;
+    LmT Lm = 0;
     T d1[9], d2[9];                            // dates t + 1, t + 2
 #pragma unroll
     for (int c = 0; c < 9; ++c) d1[c] = d2[c] = (c < 3) ? (T)1 : (T)0;
@@ -275,7 +288,7 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
             const int jj = k - t;
             const double dets = det3<double>(S);
             const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
-            const DenseScreenEntry c = screen_entry(scr, jj);
+            const DenseScreenEntry c = entry_of(jj);
             const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
             const float qq = (float)((S[0] * S[1]) * S[2]) * __builtin_amdgcn_rcpf((float)dets);
             const float rel = (cu * (21.f * (float)jj + 20.f)) * qq;
@@ -334,10 +347,10 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
     const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
     uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
 
-    const bool cand = in && (bad || (((gF | gI) & (MT)1) != 0));
+    const bool cand = in && (bad || mask_bit(gF, 0) || mask_bit(gI, 0));
     const bool dense = __popcll(__ballot(cand)) >= dense_min;
     bool listed = cand;                                       // a sparse wave lists its candidates
-    MT mask = 0;
+    MT mask = mask_zero<MT>();
     if (dense) {
         bool handoff = in && bad;
         bool done = !in || bad;
@@ -345,9 +358,9 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
         for (int l = 0; l < k - 1; ++l) {
             const bool act = !done && (cur == l);
             if (!__any(act)) continue;
-            const bool gi = (gI >> l) & (MT)1, gf = (gF >> l) & (MT)1;
-            const bool i2 = (m2I >> l) & (MT)1, f2 = (m2F >> l) & (MT)1;
-            const bool i3 = (m3I >> l) & (MT)1, f3 = (m3F >> l) & (MT)1;
+            const bool gi = mask_bit(gI, l), gf = mask_bit(gF, l);
+            const bool i2 = mask_bit(m2I, l), f2 = mask_bit(m2F, l);
+            const bool i3 = mask_bit(m3I, l), f3 = mask_bit(m3F, l);
             int fire = -1;
             bool deep = false;
             if (act) {
@@ -380,7 +393,8 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
                     T s[9];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) s[c] = (T)0;
-                    int Ld = 0, Lmd = 0;
+                    int Ld = 0;
+                    LmT Lmd = 0;
                     bool searching = true;
                     for (int t0 = l; t0 < k && searching; t0 += 2) {
                         T qb[2][9];
@@ -424,20 +438,20 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
                 }
             }
             if (fire >= 0) {
-                mask |= (MT)1 << fire;                        // nd/_change.pyx:252
+                mask_set(mask, fire, true);                   // nd/_change.pyx:252
                 cur = fire;                                   // :255
                 if (cur >= k - 1) done = true;                // :256
             }
         }
-        if (handoff) mask = 0;                                // pass B writes that pixel's changes
+        if (handoff) mask = mask_zero<MT>();                  // pass B writes that pixel's changes
         if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
             if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
                 uint32_t *w = reinterpret_cast<uint32_t *>(res);
                 for (int q = 0; q < (k >> 2); ++q)
-                    w[q] = (((unsigned)(mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    w[q] = (mask_nibble(mask, q) * 0x00204081u) & 0x01010101u;
             } else {
-                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & (MT)1);
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)(mask_bit(mask, t) ? 1 : 0);
             }
         }
         listed = handoff;
@@ -668,7 +682,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         const char *e = getenv("ND_AMD_C3_FUSED_ALPHA");
         return e ? atof(e) : 0.75;
     }();
-    const bool fused = k >= 2 && k <= 64 && alpha < fused_alpha;      // 64-bit masks
+    const bool fused = k >= 2 && k <= kDenseMax && k <= kTabArgs && alpha < fused_alpha;
     if (!fused || stats) {
         // the sparse design -- or, with a fused search, only the z / P rasters of it
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
@@ -688,8 +702,12 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
             return e ? atoi(e) : 16;
         }();
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
-        hipLaunchKernelGGL((omnibus_c3_stream_kernel<T>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
-                           stream, g, tab, scr, dense_min);
+        if (k <= 64)
+            hipLaunchKernelGGL((omnibus_c3_stream_kernel<T, 1>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
+                               stream, g, tab, scr, dense_min);
+        else
+            hipLaunchKernelGGL((omnibus_c3_stream_kernel<T, 2>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
+                               stream, g, tab, scr, dense_min);
         ND_HIP_CHECK(hipGetLastError());
     }
 

@@ -92,12 +92,12 @@ def test_omnibus_test_class_full_pol_is_opt_in(oracle, device):
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
-@pytest.mark.parametrize('k', [2, 3, 5, 24, 48, 64])
+@pytest.mark.parametrize('k', [2, 3, 5, 24, 48, 64, 65, 96])
 def test_c3_low_thresholds_streaming_search(oracle, device, dtype, k):
     """The thresholds users pass (the reference's default 0.01, the tutorial's 1e-4, and a middle
-    one) run the fused streaming search (omnibus_c3_stream_kernel, up to 64 dates): same map as the
+    one) run the fused streaming search (omnibus_c3_stream_kernel, up to 96 dates): same map as the
     generic-p oracle byte for byte, planar and strided, with and without the z / P rasters."""
-    planes = synth.omnibus_stack_c3(seed=100 + k, k=k, ny=12, nx=140, dtype=dtype, change_frac=0.3)
+    planes = synth.omnibus_stack_c3(seed=100 + k, k=k, ny=12 if k <= 64 else 4, nx=140, dtype=dtype, change_frac=0.3)
     yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
     for alpha in (1e-4, 0.01, 0.3):
         want, z0, P0 = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8, stats=True)

@@ -262,7 +262,11 @@ def main():
     fails = 0
     t_end = time.time() + a.seconds
     i = 0
+    t_say = time.time() + 60.0
     while time.time() < t_end:
+        if time.time() > t_say:              # a heartbeat: silent runs are taken for hung ones
+            print('progress', count, 'failures', fails, flush=True)
+            t_say = time.time() + 60.0
         name = names[i % len(names)]
         rng = np.random.default_rng([a.seed, i])
         try:
