@@ -218,3 +218,27 @@ def test_every_kernel_form_gives_the_same_map(env):
     assert len(lines) == 10, out.stdout[-2000:]
     for r in lines:
         assert r['bytes_differing'] == 0, r
+
+
+@pytest.mark.parametrize('dtype,k', [('float32', 40), ('float64', 24), ('float32', 80)])
+def test_long_series_statistics_at_scale(oracle, dtype, k):
+    """Series beyond the register forms on a raster large enough for the device-side density gate:
+    the map of the streaming search (64- / 128-bit masks) equals the oracle on sampled pixels and
+    whole rows, asking for the z / P rasters does not change it, and the rasters themselves do not
+    depend on the threshold (they come from the plain pass A in both regimes)."""
+    import torch
+    from nd_amd import kernels, synth as dsynth
+    from oracle import checks
+    dev = torch.device('cuda:0')
+    ny, nx = 1536, 2048
+    st = dsynth.wishart_c2_stack(k, ny, nx, looks=9, seed=5 + k, device=dev, change_frac=0.02)
+    st = st.to(getattr(torch, dtype))
+    ch = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.01, n=9)
+    ch_s, z, P = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.01, n=9, stats=True)
+    _, z2, P2 = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9, stats=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ch, ch_s)
+    assert torch.equal(z, z2) and torch.equal(P, P2)
+    res = checks.omnibus_sample(st, ch, 0.01, 9, nsample=3000, rows=(0, ny - 1), seed=3)
+    assert res['bad'] == 0, res
+    assert res['flagged_fraction'] > 0.5
