@@ -72,6 +72,32 @@ def _covariance_planes(ds_m, device, names=_VARS):
     return stack
 
 
+def _planes_in_place(ds_m, device, names):
+    """Time-first device datasets (the CF / NetCDF order (time, y, x)) already ARE planar: real
+    variables are used where they lie (the C ABI takes one pointer per plane set and one set of
+    strides), only what does not share their strides -- the two halves of an interleaved complex
+    term -- is packed.  Returns the list of planes, or None when the dataset is laid out
+    differently (the transpose kernels of _covariance_planes then build the stack)."""
+    arrs = []
+    for v in names:
+        if v not in ds_m.data_vars:
+            return None
+        da = ds_m[v]
+        if set(da.dims) != {'time', 'y', 'x'} or len(da.dims) != 3:
+            return None
+        a = da.transpose('time', 'y', 'x').values
+        if not (_device.is_tensor(a) and a.is_cuda and a.device == torch.device(device)
+                and a.dtype in (torch.float32, torch.float64)):
+            return None
+        arrs.append(a)
+    if len({a.dtype for a in arrs}) != 1 or len({tuple(a.shape) for a in arrs}) != 1:
+        return None
+    ref = next((a for a in arrs if a.is_contiguous()), None)
+    if ref is None or ref.numel() == 0 or ref.data_ptr() % 16:
+        return None
+    return [a if a.stride() == ref.stride() and a.data_ptr() % 16 == 0 else a.contiguous() for a in arrs]
+
+
 def _multilook_planes(stack, ml):
     """BoxcarFilter(w=ml) with dims ('y', 'x') (nd/change.py:61-63) applied to the planar stack
     (4, time, y, x): every (variable, date) plane is filtered on its own, exactly as the filter
@@ -120,7 +146,10 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
                     *[da.transpose('y', 'x', 'time').values for da in vals], alpha=alpha, n=int(n),
                     stats=stats)
         if res is None:
-            stack = _covariance_planes(ds_m, dev, _VARS3 if full_pol else _VARS)
+            names = _VARS3 if full_pol else _VARS
+            stack = None if ml is not None else _planes_in_place(ds_m, dev, names)
+            if stack is None:
+                stack = _covariance_planes(ds_m, dev, names)
             if ml is not None:      # spatial multilooking first; the looks multiply accordingly
                 stack, n = _multilook_planes(stack, int(ml)), ml * ml
             if full_pol:

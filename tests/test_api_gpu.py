@@ -323,6 +323,50 @@ def test_complex_torch_tensors_stay_on_device(oracle, device):
     np.testing.assert_array_equal(ch.values.cpu().numpy(), oracle.change_detection_planes(yxt, 0.9, 9).astype(bool))
 
 
+def test_time_first_device_variables_are_used_in_place(oracle, device):
+    """(time, y, x) device datasets -- the NetCDF / CF order -- are planar already: real variables
+    are read where they lie, the halves of a complex C12 are packed; odd widths, separate
+    C12__re / C12__im variables, a sliced (non-contiguous) variable that sends the dataset down
+    the general path, float64, and the full-pol test."""
+    import torch
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    for dtype, shape in ((np.float32, (9, 11, 37)), (np.float64, (6, 5, 130))):
+        k, ny, nx = shape
+        planes = synth.omnibus_stack(seed=31 + nx, k=k, ny=ny, nx=nx, dtype=dtype, change_frac=0.3)
+        yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+        want = oracle.change_detection_planes(yxt, 0.9, 9).astype(bool)
+        t = [torch.from_numpy(p).to(device) for p in planes]
+        dims = ('time', 'y', 'x')
+        for variant in ('complex', 'split', 'sliced'):
+            ds = xr_lite.Dataset()
+            if variant == 'sliced':
+                big = torch.zeros((k, ny, nx + 3), dtype=t[0].dtype, device=device)
+                big[:, :, 1:nx + 1] = t[0]
+                ds['C11'] = (dims, big[:, :, 1:nx + 1])
+            else:
+                ds['C11'] = (dims, t[0])
+            if variant == 'complex':
+                ds['C12'] = (dims, torch.complex(t[1], t[2]))
+            else:
+                ds['C12__re'] = (dims, t[1])
+                ds['C12__im'] = (dims, t[2])
+            ds['C22'] = (dims, t[3])
+            ch = OmnibusTest(n=9, alpha=0.9).apply(ds)
+            assert ch.values.is_cuda and ch.dims == ('y', 'x', 'time')
+            np.testing.assert_array_equal(ch.values.cpu().numpy(), want, err_msg=variant)
+    p3 = synth.omnibus_stack_c3(seed=5, k=6, ny=7, nx=41, dtype=np.float32, change_frac=0.3)
+    want3 = oracle.change_detection_pol([np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in p3], 3, 0.9, 9)
+    ds = xr_lite.Dataset()
+    t3 = [torch.from_numpy(p).to(device) for p in p3]
+    for i, name in enumerate(('C11', 'C22', 'C33')):
+        ds[name] = (('time', 'y', 'x'), t3[i])
+    for j, name in enumerate(('C12', 'C13', 'C23')):
+        ds[name] = (('time', 'y', 'x'), torch.complex(t3[3 + 2 * j], t3[4 + 2 * j]))
+    ch3 = OmnibusTest(n=9, alpha=0.9, pol='full').apply(ds)
+    np.testing.assert_array_equal(ch3.values.cpu().numpy(), want3.astype(bool))
+
+
 def test_nlmeans_dataset_paths_use_fast_layout(oracle, device):
     """Datasets with the reference's (y, x, time) variables, large enough for the re-layout path:
     dims ('y','x') and the tutorial's dims ('time','y','x') against the oracle on the stacked array."""
