@@ -287,6 +287,16 @@ int nd_amd_timing_enable(int capacity);
 int nd_amd_timing_collect(int32_t *kernel_ids, float *ms, int max_n, int *n_out);
 int nd_amd_timing_dropped(void);
 
+/* ------------------------------------------------------------------------
+ * Interleaved complex -> real and imaginary arrays of the same contiguous
+ * shape: the device side of nd.io.disassemble_complex (nd/io.py:26-69,
+ * called at nd/change.py:59 and nd/filters.py:132-134) for a variable that
+ * is already in (time, y, x) order.  `in`: n complex values of the real type
+ * `dtype` (2 n reals), 16-byte aligned like the outputs.
+ * ---------------------------------------------------------------------- */
+int nd_amd_split_complex(const void *in, void *out_re, void *out_im, int dtype, int64_t n,
+                         void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,7 +95,16 @@ def _planes_in_place(ds_m, device, names):
     ref = next((a for a in arrs if a.is_contiguous()), None)
     if ref is None or ref.numel() == 0 or ref.data_ptr() % 16:
         return None
-    return [a if a.stride() == ref.stride() and a.data_ptr() % 16 == 0 else a.contiguous() for a in arrs]
+    out = [a if a.stride() == ref.stride() and a.data_ptr() % 16 == 0 else None for a in arrs]
+    for i, v in enumerate(names):
+        # the two halves of one interleaved complex term: a single pass over its memory
+        if out[i] is None and v.endswith('__re') and v[:-4] + '__im' in names:
+            j = names.index(v[:-4] + '__im')
+            if out[j] is None:
+                pair = kernels.split_complex(arrs[i], arrs[j])
+                if pair is not None:
+                    out[i], out[j] = pair
+    return [a if a is not None else arrs[i].contiguous() for i, a in enumerate(out)]
 
 
 def _multilook_planes(stack, ml):

@@ -242,3 +242,83 @@ extern "C" int nd_amd_relayout_planar_complex(const void *in, void *out_re, void
         return relayout_impl<float>(in, out_re, out_im, npix, k, 2, out_date_stride, true, stream);
     return relayout_impl<double>(in, out_re, out_im, npix, k, 2, out_date_stride, true, stream);
 }
+
+// ---- interleaved complex -> two real arrays of the same (contiguous) shape --------------------
+// The device side of disassemble_complex (nd/io.py:26-69) for data that is already planar: a
+// complex64 / complex128 variable in (time, y, x) order becomes C12__re and C12__im in one pass
+// over its memory (two strided torch copies read it twice).  A thread moves four complex values:
+// two 16-byte loads, one 16-byte store per half.
+namespace nd_amd {
+template <typename T>
+__global__ void __launch_bounds__(256) split_complex_kernel(const T *__restrict__ in, T *__restrict__ re,
+                                                            T *__restrict__ im, int64_t n)
+{
+    constexpr int V = 16 / (int)sizeof(T);          // elements per 16-byte access
+    struct alignas(16) Vec {
+        T v[V];
+    };
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i0 + V <= n) {
+        const Vec a = *reinterpret_cast<const Vec *>(in + 2 * i0);
+        const Vec b = *reinterpret_cast<const Vec *>(in + 2 * i0 + V);
+        Vec r, m;
+#pragma unroll
+        for (int j = 0; j < V / 2; ++j) {
+            r.v[j] = a.v[2 * j];
+            m.v[j] = a.v[2 * j + 1];
+            r.v[V / 2 + j] = b.v[2 * j];
+            m.v[V / 2 + j] = b.v[2 * j + 1];
+        }
+        *reinterpret_cast<Vec *>(re + i0) = r;
+        *reinterpret_cast<Vec *>(im + i0) = m;
+    } else {
+        for (int64_t i = i0; i < n; ++i) {
+            re[i] = in[2 * i];
+            im[i] = in[2 * i + 1];
+        }
+    }
+}
+}  // namespace nd_amd
+
+extern "C" int nd_amd_split_complex(const void *in, void *out_re, void *out_im, int dtype, int64_t n,
+                                    void *hip_stream)
+{
+    using namespace nd_amd;
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_split_complex: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (n < 0) {
+        set_error("nd_amd_split_complex: negative length");
+        return ND_AMD_EINVAL;
+    }
+    if (n == 0) return ND_AMD_OK;
+    if (!in || !out_re || !out_im) {
+        set_error("nd_amd_split_complex: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    if ((((uintptr_t)in | (uintptr_t)out_re | (uintptr_t)out_im) & 15) != 0) {
+        set_error("nd_amd_split_complex: pointers must be 16-byte aligned");
+        return ND_AMD_EINVAL;
+    }
+    const int v = dtype == ND_AMD_F32 ? 4 : 2;
+    const int64_t nblocks = ceil_div(ceil_div(n, v), 256);
+    if (nblocks > 0x7fffffffLL) {
+        set_error("nd_amd_split_complex: array too large for one launch");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    {
+        KernelTimer timer(ND_AMD_KERNEL_RELAYOUT, stream);
+        if (dtype == ND_AMD_F32)
+            hipLaunchKernelGGL((split_complex_kernel<float>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                               static_cast<const float *>(in), static_cast<float *>(out_re),
+                               static_cast<float *>(out_im), n);
+        else
+            hipLaunchKernelGGL((split_complex_kernel<double>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                               static_cast<const double *>(in), static_cast<double *>(out_re),
+                               static_cast<double *>(out_im), n);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+    return ND_AMD_OK;
+}

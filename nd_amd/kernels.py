@@ -255,6 +255,37 @@ def relayout_planar_complex(src_re, src_im, dst_re, dst_im):
     return True
 
 
+def split_complex(src_re, src_im):
+    """The `.real` / `.imag` views of ONE contiguous complex CUDA tensor as two packed real tensors
+    of the same shape, in one pass over its memory (nd_amd_split_complex).  None when the views
+    are anything else (the caller then packs them one by one)."""
+    if not (torch.is_tensor(src_re) and torch.is_tensor(src_im) and src_re.is_cuda
+            and src_re.dtype in _DT and src_im.dtype == src_re.dtype and src_re.shape == src_im.shape
+            and src_re.device == src_im.device and src_re.numel() > 0):
+        return None
+    es = src_re.element_size()
+    if src_im.data_ptr() != src_re.data_ptr() + es or src_re.stride() != src_im.stride():
+        return None
+    # a contiguous complex tensor seen through a real view: every stride doubled, innermost 2
+    want = []
+    acc = 2
+    for n_ in reversed(src_re.shape):
+        want.append(acc)
+        acc *= n_
+    want = tuple(reversed(want))
+    if any(s_ != w_ for s_, w_, n_ in zip(src_re.stride(), want, src_re.shape) if n_ > 1):
+        return None
+    if src_re.data_ptr() % 16:
+        return None
+    dev = src_re.device
+    with torch.cuda.device(dev):
+        re = torch.empty(src_re.shape, dtype=src_re.dtype, device=dev)
+        im = torch.empty(src_re.shape, dtype=src_re.dtype, device=dev)
+        _lib.check(_lib.lib().nd_amd_split_complex(_ptr(src_re), _ptr(re), _ptr(im), _DT[src_re.dtype],
+                                                   src_re.numel(), _stream_ptr(dev)))
+    return re, im
+
+
 def relayout_pixel_major(src, dst):
     """Inverse of relayout_planar: planar (time, y, x) `src` (x fastest, any plane pitch) into
     `dst` laid out (y, x, time) with time fastest (a real tensor or one half of a complex one).
