@@ -338,6 +338,19 @@ def footprint(weights, origin=0, convolution=True):
     return offs, np.ascontiguousarray(weights[keep], np.float64)
 
 
+def _may_overlap(a, b):
+    """Conservative test: the address ranges the two tensors span intersect."""
+    if a.device != b.device or a.numel() == 0 or b.numel() == 0:
+        return False
+
+    def span(t):
+        lo = t.data_ptr()
+        hi = lo + (sum((n - 1) * abs(st) for n, st in zip(t.shape, t.stride())) + 1) * t.element_size()
+        return lo, hi
+    (a0, a1), (b0, b1) = span(a), span(b)
+    return a0 < b1 and b0 < a1
+
+
 def correlate_footprint(inp, out, offsets, weights, mode='reflect', cval=0.0):
     """out[i] = (T) sum_t weights[t] * inp[extend(i + offsets[t])], double
     accumulation in tap order.  inp/out: CUDA tensors, same shape, ndim <= 4."""
@@ -388,6 +401,11 @@ def convolve(inp, kernel, out=None, mode='reflect', cval=0.0, origin=0):
         raise RuntimeError('filter weights array has incorrect shape.')
     if out is None:
         out = torch.empty_like(inp)
+    elif _may_overlap(inp, out):
+        # scipy filters into a temporary when input and output share memory; the kernels read
+        # neighbours of what they write
+        out.copy_(convolve(inp, kernel, None, mode, cval, origin))
+        return out
     nd = inp.dim()
     span = [d for d in range(nd) if kernel.shape[d] > 1]
     tail = list(range(nd - len(span), nd))
@@ -484,6 +502,9 @@ def gaussian_filter(inp, sigma, out=None, mode='reflect', cval=0.0, truncate=4.0
     in the array dtype (scipy filters `output` in place from the second axis on)."""
     if out is None:
         out = torch.empty_like(inp)
+    elif _may_overlap(inp, out):
+        out.copy_(gaussian_filter(inp, sigma, None, mode, cval, truncate))
+        return out
     nd = inp.dim()
     sigmas = [float(sigma)] * nd if np.isscalar(sigma) else [float(s) for s in sigma]
     if len(sigmas) != nd:

@@ -167,3 +167,19 @@ def test_register_window_kernel(device, mode):
     kernels.convolve(view, k, out=out, mode=mode)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), ndi.convolve(view.cpu().numpy(), k, mode=mode))
+
+
+def test_output_may_alias_input(device):
+    """scipy filters into a temporary when output and input share memory; so do the wrappers."""
+    import scipy.ndimage as ndi
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(61)
+    a = rng.normal(size=(3, 70, 300)).astype(np.float32)
+    k = np.ones((1, 3, 3)) / 9.0
+    t = torch.from_numpy(a.copy()).to(device)
+    kernels.convolve(t, k, out=t)
+    np.testing.assert_array_equal(t.cpu().numpy(), ndi.convolve(a, k))
+    t = torch.from_numpy(a.copy()).to(device)
+    kernels.gaussian_filter(t, (0, 1, 1), out=t)
+    np.testing.assert_array_equal(t.cpu().numpy(), ndi.gaussian_filter(a, (0, 1, 1)))
