@@ -297,6 +297,11 @@ int nd_amd_timing_dropped(void);
 int nd_amd_split_complex(const void *in, void *out_re, void *out_im, int dtype, int64_t n,
                          void *hip_stream);
 
+/* The inverse (nd.io.assemble_complex, nd/io.py:72-123): two real arrays of n
+ * elements -> n interleaved complex values.  16-byte aligned pointers. */
+int nd_amd_merge_complex(const void *in_re, const void *in_im, void *out, int dtype, int64_t n,
+                         void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,7 @@ SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_omnibus_c3_workspace_bytes', 'nd_amd_omnibus_c3',
            'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_correlate1d_yx', 'nd_amd_nlmeans3d',
            'nd_amd_relayout_planar', 'nd_amd_relayout_planar_complex',
-           'nd_amd_relayout_pixel_major', 'nd_amd_split_complex',
+           'nd_amd_relayout_pixel_major', 'nd_amd_split_complex', 'nd_amd_merge_complex',
            'nd_amd_timing_enable', 'nd_amd_timing_collect', 'nd_amd_timing_dropped')
 
 _lib = None
@@ -74,6 +74,8 @@ def lib():
     L.nd_amd_correlate1d.restype = i32
     L.nd_amd_correlate1d.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                      i32, i32, C.POINTER(dbl), i32, dbl, vp]
+    L.nd_amd_merge_complex.restype = i32
+    L.nd_amd_merge_complex.argtypes = [vp, vp, vp, i32, i64, vp]
     L.nd_amd_split_complex.restype = i32
     L.nd_amd_split_complex.argtypes = [vp, vp, vp, i32, i64, vp]
     L.nd_amd_correlate1d_yx.restype = i32

@@ -322,3 +322,79 @@ extern "C" int nd_amd_split_complex(const void *in, void *out_re, void *out_im, 
     ND_HIP_CHECK(hipGetLastError());
     return ND_AMD_OK;
 }
+
+// ---- two real arrays -> one interleaved complex array (the inverse of nd_amd_split_complex) -----
+namespace nd_amd {
+template <typename T>
+__global__ void __launch_bounds__(256) merge_complex_kernel(const T *__restrict__ re, const T *__restrict__ im,
+                                                            T *__restrict__ out, int64_t n)
+{
+    constexpr int V = 16 / (int)sizeof(T);
+    struct alignas(16) Vec {
+        T v[V];
+    };
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i0 + V <= n) {
+        const Vec r = *reinterpret_cast<const Vec *>(re + i0);
+        const Vec m = *reinterpret_cast<const Vec *>(im + i0);
+        Vec a, b;
+#pragma unroll
+        for (int j = 0; j < V / 2; ++j) {
+            a.v[2 * j] = r.v[j];
+            a.v[2 * j + 1] = m.v[j];
+            b.v[2 * j] = r.v[V / 2 + j];
+            b.v[2 * j + 1] = m.v[V / 2 + j];
+        }
+        *reinterpret_cast<Vec *>(out + 2 * i0) = a;
+        *reinterpret_cast<Vec *>(out + 2 * i0 + V) = b;
+    } else {
+        for (int64_t i = i0; i < n; ++i) {
+            out[2 * i] = re[i];
+            out[2 * i + 1] = im[i];
+        }
+    }
+}
+}  // namespace nd_amd
+
+extern "C" int nd_amd_merge_complex(const void *in_re, const void *in_im, void *out, int dtype, int64_t n,
+                                    void *hip_stream)
+{
+    using namespace nd_amd;
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_merge_complex: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (n < 0) {
+        set_error("nd_amd_merge_complex: negative length");
+        return ND_AMD_EINVAL;
+    }
+    if (n == 0) return ND_AMD_OK;
+    if (!in_re || !in_im || !out) {
+        set_error("nd_amd_merge_complex: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    if ((((uintptr_t)in_re | (uintptr_t)in_im | (uintptr_t)out) & 15) != 0) {
+        set_error("nd_amd_merge_complex: pointers must be 16-byte aligned");
+        return ND_AMD_EINVAL;
+    }
+    const int v = dtype == ND_AMD_F32 ? 4 : 2;
+    const int64_t nblocks = ceil_div(ceil_div(n, v), 256);
+    if (nblocks > 0x7fffffffLL) {
+        set_error("nd_amd_merge_complex: array too large for one launch");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    {
+        KernelTimer timer(ND_AMD_KERNEL_RELAYOUT, stream);
+        if (dtype == ND_AMD_F32)
+            hipLaunchKernelGGL((merge_complex_kernel<float>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                               static_cast<const float *>(in_re), static_cast<const float *>(in_im),
+                               static_cast<float *>(out), n);
+        else
+            hipLaunchKernelGGL((merge_complex_kernel<double>), dim3((unsigned)nblocks), dim3(256), 0, stream,
+                               static_cast<const double *>(in_re), static_cast<const double *>(in_im),
+                               static_cast<double *>(out), n);
+    }
+    ND_HIP_CHECK(hipGetLastError());
+    return ND_AMD_OK;
+}

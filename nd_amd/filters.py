@@ -248,9 +248,25 @@ class ConvolutionFilter(Filter):
         if not _adapter.iscomplexobj(arr):
             _convolve_into(arr, nd_kernel, output, **self.kwargs)
         elif _device.is_tensor(arr):
+            halves_in = torch.view_as_real(arr).unbind(-1)
+            # a contiguous complex variable whose window axes come last (time-first data): split
+            # it in one pass, filter two packed arrays, merge in one pass -- instead of packing
+            # and scattering each strided half separately
+            tail_window = all(n == 1 for n in nd_kernel.shape[:-2]) if arr.ndim >= 2 else False
+            pair = kernels.split_complex(*halves_in) if (tail_window and _device.is_tensor(output)
+                                                          and output.is_contiguous()
+                                                          and arr.numel() >= (1 << 16)) else None
+            if pair is not None:
+                done = [torch.empty_like(pair[0]), torch.empty_like(pair[1])]
+                for part_in, part_out in zip(pair, done):
+                    _convolve_into(part_in, nd_kernel, part_out, **self.kwargs)
+                if kernels.merge_complex(done[0], done[1], output):
+                    return
+                for part, part_out in zip(done, torch.view_as_real(output).unbind(-1)):
+                    part_out.copy_(part)
+                return
             # interleaved complex memory seen as two strided real views
-            for part_in, part_out in zip(torch.view_as_real(arr).unbind(-1),
-                                         torch.view_as_real(output).unbind(-1)):
+            for part_in, part_out in zip(halves_in, torch.view_as_real(output).unbind(-1)):
                 _convolve_into(part_in, nd_kernel, part_out, **self.kwargs)
         else:
             # host complex array: one upload and one download of the interleaved data, the two

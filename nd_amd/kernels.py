@@ -286,6 +286,24 @@ def split_complex(src_re, src_im):
     return re, im
 
 
+def merge_complex(re, im, out):
+    """Two packed real CUDA tensors -> the contiguous complex tensor `out` of the same shape, one
+    pass (nd_amd_merge_complex).  False when the tensors are not of that form."""
+    if not (torch.is_tensor(out) and out.is_complex() and out.is_cuda and out.is_contiguous()
+            and torch.is_tensor(re) and torch.is_tensor(im) and re.is_contiguous() and im.is_contiguous()
+            and re.shape == out.shape and im.shape == out.shape and re.dtype in _DT and im.dtype == re.dtype
+            and torch.view_as_real(out).dtype == re.dtype and re.device == out.device == im.device
+            and out.numel() > 0):
+        return False
+    if (re.data_ptr() | im.data_ptr() | out.data_ptr()) % 16:
+        return False
+    dev = out.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nd_amd_merge_complex(_ptr(re), _ptr(im), _ptr(out), _DT[re.dtype],
+                                                   re.numel(), _stream_ptr(dev)))
+    return True
+
+
 def relayout_pixel_major(src, dst):
     """Inverse of relayout_planar: planar (time, y, x) `src` (x fastest, any plane pitch) into
     `dst` laid out (y, x, time) with time fastest (a real tensor or one half of a complex one).

@@ -577,3 +577,29 @@ def test_relayout_declines_series_beyond_the_staging_buffer(device):
     o = torch.ones((2, 7000, 1, 2), device=device)
     assert not kernels.relayout_planar_complex(c.real, c.imag, o[0], o[1])
     assert bool((dst == 1).all()) and bool((o == 1).all())
+
+
+def test_complex_variable_time_first_split_filter_merge(device):
+    """A contiguous complex64 / complex128 device variable in (time, y, x) order: ConvolutionFilter /
+    BoxcarFilter split it in one pass, filter two packed arrays and merge them (nd/filters.py:261-265
+    filters real and imaginary parts separately) -- bit-equal to scipy on each part."""
+    import scipy.ndimage as ndi
+    import torch
+    from nd_amd import xr_lite
+    from nd_amd.filters import BoxcarFilter, ConvolutionFilter
+    rng = np.random.default_rng(71)
+    for cdtype in (np.complex64, np.complex128):
+        z = (rng.normal(size=(3, 90, 257)) + 1j * rng.normal(size=(3, 90, 257))).astype(cdtype)
+        ds = xr_lite.Dataset()
+        ds['C12'] = (('time', 'y', 'x'), torch.from_numpy(z).to(device))
+        ds['C11'] = (('time', 'y', 'x'), torch.from_numpy(np.ascontiguousarray(z.real)).to(device))
+        kern = rng.normal(size=(5, 5))
+        for flt, k2 in ((BoxcarFilter(w=3), np.ones((3, 3)) / 9.0), (ConvolutionFilter(kernel=kern), kern)):
+            out = flt.apply(ds)
+            got = out['C12'].values.cpu().numpy()
+            k3 = k2.reshape((1,) + k2.shape)
+            want = ndi.convolve(z.real, k3) + 1j * ndi.convolve(z.imag, k3)
+            np.testing.assert_array_equal(got, want.astype(cdtype))
+            np.testing.assert_array_equal(out['C11'].values.cpu().numpy(), ndi.convolve(z.real, k3))
+            # the input is left as it was
+            np.testing.assert_array_equal(ds['C12'].values.cpu().numpy(), z)
