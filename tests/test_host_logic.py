@@ -238,3 +238,21 @@ def test_layout_recognition_helpers():
     # CPU tensors are declined by the wrappers themselves
     assert kernels.relayout_planar(t, p) is False
     assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
+
+
+def test_overlap_test_of_the_filter_wrappers():
+    """kernels._may_overlap: conservative address-range test behind `out` aliasing `inp`."""
+    import torch
+    from nd_amd import kernels
+    a = torch.zeros((4, 10, 12))
+    assert kernels._may_overlap(a, a)
+    assert kernels._may_overlap(a[1:], a[:2])
+    assert not kernels._may_overlap(a[:2], a[2:])
+    assert not kernels._may_overlap(a, torch.zeros_like(a))
+    assert kernels._may_overlap(a[:, :, :6], a[:, :, 6:])        # interleaved columns: ranges intersect
+    assert not kernels._may_overlap(a[:0], a)
+    z = torch.zeros((5, 7), dtype=torch.complex64)
+    assert kernels._may_overlap(z.real, z.imag)
+    # the packed-split helpers decline anything that is not a CUDA tensor pair
+    assert kernels.split_complex(z.real, z.imag) is None
+    assert kernels.merge_complex(torch.zeros((5, 7)), torch.zeros((5, 7)), z) is False
