@@ -1499,8 +1499,11 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         }
     }
     if (tid == 0) {
+        // static indices only, and no more entries than this instantiation's series can have (one
+        // thread copies them while the block waits: 129 entries cost 7 % of a 24-date block)
+        constexpr int NJ = MW == 0 ? 32 : (MW == 1 ? 64 : kDenseMax);
 #pragma unroll
-        for (int j = 0; j <= kDenseMax; ++j) scr_lds[j] = scr_arg.e[j];      // static indices only
+        for (int j = 0; j <= NJ; ++j) scr_lds[j] = scr_arg.e[j];
     }
     if (g.write_tab && b == 0) {
         for (int j = tid; j <= k; j += kThreads) g.tab_dev[j] = tab.e[j];

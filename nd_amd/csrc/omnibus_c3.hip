@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
     for (int u = 0; u < PF; ++u) load(k - 1 - u > 0 ? k - 1 - u : 0, ring[u]);
     if (tid == 0) {
 #pragma unroll 1
-        for (int j = 0; j <= kDenseMax; ++j) scr_lds[j] = scr_arg.e[j];
+        for (int j = 0; j <= k; ++j) scr_lds[j] = scr_arg.e[j];       // entries beyond k are never looked up
     }
     if (g.write_tab && b == 0)
         for (int j = tid; j <= k; j += kC3Threads) g.tab_dev[j] = tab.e[j];

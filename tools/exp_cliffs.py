@@ -102,3 +102,19 @@ if what == 'api':
             torch.cuda.empty_cache()
         del st
         torch.cuda.empty_cache()
+
+if what == 'nodata':
+    # rasters with nodata margins (NaN or zero fill over 30 % of the pixels, all dates)
+    k, ny, nx = 24, 2048, 4096
+    base = synth.wishart_c2_stack(k, ny, nx, looks=9, seed=3, device=dev, change_frac=0.01)
+    for fill in ('none', 'nan', 'zero', 'nan one date'):
+        st = base.clone()
+        if fill == 'nan':
+            st[:, :, :, : int(0.3 * nx)] = float('nan')
+        elif fill == 'zero':
+            st[:, :, :, : int(0.3 * nx)] = 0.0
+        elif fill == 'nan one date':
+            st[:, 5, :, : int(0.3 * nx)] = float('nan')
+        for alpha in (0.01, 0.99):
+            ms = t_ms(lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9), 2)
+            print('nodata fill=%-13s alpha=%g: %8.2f ms' % (fill, alpha, ms), flush=True)
