@@ -499,7 +499,11 @@ template <typename T>
 __global__ void __launch_bounds__(kRetainThreads) omnibus_c2_sample_kernel(const OmniSampleArgs<T> a)
 {
     const int tid = threadIdx.x;
-    const int64_t b = (int64_t)blockIdx.x * a.block_stride;
+    // one block out of every `block_stride`, at a pseudo-random place inside its interval: a plain
+    // stride aliases with the row length (4096-pixel rows, stride 64: every sample in the first
+    // 256 columns -- a nodata margin there made the gate see an empty raster)
+    const int64_t jitter = (int64_t)(((unsigned)blockIdx.x * 0x9E3779B1u) >> 8) % a.block_stride;
+    const int64_t b = (int64_t)blockIdx.x * a.block_stride + jitter;
     const int64_t row = b / a.blocks_per_row;
     const int64_t x0 = (b - row * a.blocks_per_row) * (int64_t)kRetainThreads + tid;
     const bool in = x0 < a.nx;
@@ -1524,6 +1528,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     MT gF = mask_zero<MT>(), gI = mask_zero<MT>(), m2F = mask_zero<MT>(), m2I = mask_zero<MT>(),
        m3F = mask_zero<MT>(), m3I = mask_zero<MT>();
     bool bad = false;
+    bool dead = false;       // a date whose determinant is NaN or exactly 0: see below
     int eabs = 0;
     double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0;
     int Le = 0;
@@ -1538,6 +1543,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
         const bool ok = (det > (T)0) && (det < (T)INFINITY) && (q.a > (T)0);
         bad = bad || !ok;
+        dead = dead || !((det > (T)0) || (det < (T)0));
         int e0;
         float mf;
         log2_parts(ok ? det : (T)1, e0, mf);
@@ -1659,6 +1665,15 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
     // |log2| of every partial product stays below 900: the reference's double product neither
     // overflows nor loses precision to subnormals, so its logarithm is what the sums here model
     bad = bad || (eabs > 900);
+    // Nodata pixels need no exact pass.  A NaN determinant at any date makes the product of
+    // determinants NaN, an exactly zero one makes it 0 (or NaN): ln Q of the test over the whole
+    // series is then NaN or -inf, z is NaN or +-inf, and P is NaN or 0 -- never above alpha
+    // (nd/_change.pyx:239-242), so the search ends at its first step with no change anywhere.
+    if (dead) {
+        bad = false;
+        gF = mask_zero<MT>();
+        gI = mask_zero<MT>();
+    }
 
     const unsigned shard = (unsigned)(b % kShards);
     const int64_t wpx0 = bpx0 + (tid & ~63);                  // first pixel of this wave in its row

@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
     MT gF = mask_zero<MT>(), gI = mask_zero<MT>(), m2F = mask_zero<MT>(), m2I = mask_zero<MT>(),
        m3F = mask_zero<MT>(), m3I = mask_zero<MT>();
     bool bad = false;
+    bool dead = false;       // a date whose determinant is NaN or exactly 0 (omnibus.hip)
     int eabs = 0;
     double S[9];
 #pragma unroll
@@ -275,6 +276,7 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
         const bool ok = (det > (T)0) && (det < (T)INFINITY) && (q[0] > (T)0) && (q[1] > (T)0) &&
                         (q[2] > (T)0) && (mn12 >= (T)0) && (mn13 >= (T)0) && (mn23 >= (T)0);
         bad = bad || !ok;
+        dead = dead || !((det > (T)0) || (det < (T)0));
         int e0;
         float mf;
         log2_parts(ok ? det : (T)1, e0, mf);
@@ -340,6 +342,13 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
     }
     // the reference's double product of determinants stays in the normal range (omnibus.hip)
     bad = bad || (eabs > 900);
+    // nodata: the product of determinants is NaN or 0, P of the whole-series test NaN or 0 -- no
+    // change anywhere, and no exact pass needed (see omnibus_c2_stream_kernel)
+    if (dead) {
+        bad = false;
+        gF = mask_zero<MT>();
+        gI = mask_zero<MT>();
+    }
 
     const unsigned shard = (unsigned)(b % kC3Shards);
     const int64_t wpx0 = bpx0 + (tid & ~63);

@@ -130,3 +130,22 @@ def test_c3_streaming_search_degenerate_values(oracle, device):
             want = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8)
         ch, _, _ = _run(planes, alpha, 9, device)
         assert int((ch != want).sum()) == 0, alpha
+
+
+def test_c3_nodata_margins(oracle, device):
+    """NaN / zero fill and single bad dates under the full-pol streaming search: no change, no
+    exact pass, same map as the oracle."""
+    planes = [p.copy() for p in synth.omnibus_stack_c3(seed=88, k=20, ny=8, nx=200, dtype=np.float32, change_frac=0.3)]
+    for p in planes:
+        p[:, :, 0:40] = np.nan
+        p[:, :, 40:80] = 0.0
+        p[4, :, 80:100] = 0.0
+    planes[2][7, :, 100:120] = np.nan
+    planes[0][0, :, 120:140] = np.inf
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    for alpha in (1e-4, 0.01, 0.5):
+        with np.errstate(all='ignore'):
+            want = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8)
+        ch, _, _ = _run(planes, alpha, 9, device)
+        assert int((ch != want).sum()) == 0, alpha
+        assert not ch[:, 0:140].any() and ch[:, 140:].any()

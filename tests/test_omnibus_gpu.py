@@ -191,3 +191,33 @@ def test_long_series_at_low_thresholds(oracle, device, dtype, k):
     got = kernels.change_detection(*dev_tyx, alpha=0.01, n=9, dims=('time', 'y', 'x'), stats=True)
     torch.cuda.synchronize()
     _compare(tuple(g.cpu().numpy() for g in got), want)
+
+
+@pytest.mark.parametrize('dtype,k', [(np.float32, 24), (np.float32, 40), (np.float64, 12), (np.float32, 80)])
+def test_nodata_margins_at_low_thresholds(oracle, device, dtype, k):
+    """Nodata as real products carry it -- NaN or zero fill over whole columns, a NaN / zero / inf
+    at a single date -- at the thresholds that run the streaming search, which ends such pixels at
+    once (no change anywhere, nd/_change.pyx:239-242) instead of handing them to the exact pass."""
+    import torch
+    from nd_amd import kernels
+    planes = [p.copy() for p in synth.omnibus_stack(seed=500 + k, k=k, ny=16, nx=260, dtype=dtype, change_frac=0.3)]
+    for p in planes:
+        p[:, :, 0:40] = np.nan                     # NaN margin, every date
+        p[:, :, 40:80] = 0.0                       # zero margin, every date
+    planes[0][3, :, 80:110] = np.nan               # one variable, one date
+    planes[2][k - 1, :, 110:140] = np.nan
+    for p in planes:
+        p[1, :, 140:170] = 0.0                     # a zero matrix at one date
+    planes[3][0, :, 170:200] = np.inf
+    planes[1][2, :, 200:215] = -np.inf
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    dev = [torch.from_numpy(p).to(device) for p in planes]
+    for alpha in (1e-4, 0.01, 0.3, 0.99):
+        with np.errstate(all='ignore'):
+            want = oracle.change_detection_planes(yxt, alpha, 9, njobs=8)
+        got = kernels.change_detection(*dev, alpha=alpha, n=9, dims=('time', 'y', 'x'))
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        assert int((got != want).sum()) == 0, (k, alpha)
+        assert not got[:, 0:215].any()             # nodata never changes
+        assert got[:, 215:].any()

@@ -116,5 +116,12 @@ if what == 'nodata':
         elif fill == 'nan one date':
             st[:, 5, :, : int(0.3 * nx)] = float('nan')
         for alpha in (0.01, 0.99):
+            from nd_amd import _lib
             ms = t_ms(lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9), 2)
-            print('nodata fill=%-13s alpha=%g: %8.2f ms' % (fill, alpha, ms), flush=True)
+            _lib.timing_enable(64)
+            kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
+            km = {}
+            for n_, v in _lib.timing_collect():
+                km[n_] = km.get(n_, 0.0) + v
+            _lib.timing_enable(0)
+            print('nodata fill=%-13s alpha=%g: %8.2f ms' % (fill, alpha, ms), {a: round(b, 3) for a, b in km.items()}, flush=True)
