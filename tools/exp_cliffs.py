@@ -125,3 +125,43 @@ if what == 'nodata':
                 km[n_] = km.get(n_, 0.0) + v
             _lib.timing_enable(0)
             print('nodata fill=%-13s alpha=%g: %8.2f ms' % (fill, alpha, ms), {a: round(b, 3) for a, b in km.items()}, flush=True)
+
+if what == 'clustered':
+    # changes as they occur in real scenes: contiguous regions instead of isolated pixels
+    from nd_amd import _lib
+    k, ny, nx = 24, 2048, 4096
+    base = synth.wishart_c2_stack(k, ny, nx, looks=9, seed=3, device=dev, change_frac=0.0)
+    for frac, desc in ((0.0, 'no change'), (0.05, '5 % in one block'), (0.2, '20 % in one block'), (0.5, 'half the raster')):
+        st = base.clone()
+        rows = int(ny * frac)
+        if rows:
+            st[:, 12:, 300:300 + rows, :] *= 4.0
+        for alpha in (0.01, 0.5, 0.99):
+            ms = t_ms(lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9), 2)
+            _lib.timing_enable(64)
+            kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
+            km = {}
+            for n_, v in _lib.timing_collect():
+                km[n_] = km.get(n_, 0.0) + v
+            _lib.timing_enable(0)
+            print('clustered %-18s alpha=%g: %8.2f ms' % (desc, alpha, ms), {a: round(b, 3) for a, b in km.items()}, flush=True)
+
+if what == 'scale':
+    # dark targets: small backscatter values, long series (the reference's double product of
+    # determinants then leaves the normal range and the fast forms hand the pixel to the exact pass)
+    from nd_amd import _lib
+    for k in (24, 48, 64):
+        ny, nx = 1024, 4096
+        base = synth.wishart_c2_stack(k, ny, nx, looks=9, seed=3, device=dev, change_frac=0.01)
+        for scale in (1.0, 1e-2, 1e-3, 1e-4):
+            st = base * scale
+            for alpha in (0.01, 0.99):
+                ms = t_ms(lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9), 1)
+                _lib.timing_enable(64)
+                ch = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
+                km = {}
+                for n_, v in _lib.timing_collect():
+                    km[n_] = km.get(n_, 0.0) + v
+                _lib.timing_enable(0)
+                print('scale k=%d x%g alpha=%g: %8.2f ms changes/px %.2f' % (k, scale, alpha, ms, float(ch.sum()) / (ny * nx)),
+                      {a: round(b, 3) for a, b in km.items()}, flush=True)
