@@ -304,3 +304,33 @@ def _partial_core_case(full, r, f):
         assert bool((probe == -7.0).all())
     torch.cuda.synchronize()
     assert torch.equal(acc[:, :, 3:47, 5:133], ref[:, :, 3:47, 5:133])
+
+
+def test_window_kernels_with_nodata(oracle, device):
+    """NaN / inf margins and isolated NaNs under the unit-weight window kernels (streaming
+    three-date form, ring form, 2-D form) and the signed patch kernels: NaN spreads over exactly
+    the windows that hold it, as in the reference."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(91)
+    a = rng.gamma(4.0, 0.25, (5, 40, 150, 2)).astype(np.float32)          # (t, y, x, var)
+    a[:, :, 0:12, :] = np.nan
+    a[2, 20, 70, 0] = np.nan
+    a[4, 5, 100, 1] = np.inf
+    planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)
+    for r, f, ne, pm in (((1, 3, 3), (1, 1, 1), 50.0, 0), ((2, 2, 2), (1, 1, 1), -1, 0), ((0, 3, 3), (0, 1, 1), -1, 0),
+                         ((0, 3, 3), (0, 1, 1), -1, 1), ((0, 2, 2), (0, 1, 1), 6.0, 1)):
+        want = np.empty_like(a)
+        with np.errstate(all='ignore'):
+            oracle.pixelwise_nlmeans_3d(a, want, r, f, 0.5, 0.5, ne, neff_policy=0, njobs=8, patch_mode=pm)
+        out = torch.empty_like(planar)
+        kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, 0.5, 0.5, ne,
+                                     patch_mode=pm, neff_policy=0)
+        torch.cuda.synchronize()
+        got = out.permute(1, 2, 3, 0).cpu().numpy()
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=str((r, f, ne, pm)))
+        if pm == 0:
+            np.testing.assert_array_equal(got, want)
+        else:
+            ok = ~np.isnan(want)
+            np.testing.assert_allclose(got[ok], want[ok], rtol=RTOL)
