@@ -870,11 +870,12 @@ template <int R1>
 static void launch_roll(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
 {
     // square windows up to 11 x 11 get the fully unrolled row loop
-    if (R1 >= 1 && R1 <= 5 && a.r0 == R1)
+    if (R1 >= 1 && R1 <= 5 && a.r0 == R1) {
         ND_LAUNCH_LDS((nlmeans_window_roll_kernel<R1, (R1 >= 1 && R1 <= 5) ? R1 : -1>),
                       dim3((unsigned)nb), dim3(256), lds, stream, a);
-    else
+    } else {
         ND_LAUNCH_LDS((nlmeans_window_roll_kernel<R1, -1>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+    }
 }
 
 static bool launch_roll_r1(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
@@ -1377,10 +1378,11 @@ static void launch_patch2(const NlmTiledArgs &a, int64_t nslices, size_t lds, hi
 {
     constexpr int TYW = Patch2Rows<V>::TYW;
     const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nslices;
-    if (a.n_eff >= 0)
+    if (a.n_eff >= 0) {
         ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256), lds, stream, a);
-    else
+    } else {
         ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+    }
 }
 
 template <int F>
@@ -1400,10 +1402,11 @@ static void launch_patch(const NlmTiledArgs &a, int64_t nslices, size_t lds, hip
 {
     constexpr int TYW = (V == 1) ? 16 : 8;
     const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nslices;
-    if (a.n_eff >= 0)
+    if (a.n_eff >= 0) {
         ND_LAUNCH_LDS((nlmeans_patch_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256), lds, stream, a);
-    else
+    } else {
         ND_LAUNCH_LDS((nlmeans_patch_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+    }
 }
 
 template <int F>

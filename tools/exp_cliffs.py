@@ -165,3 +165,26 @@ if what == 'scale':
                 _lib.timing_enable(0)
                 print('scale k=%d x%g alpha=%g: %8.2f ms changes/px %.2f' % (k, scale, alpha, ms, float(ch.sum()) / (ny * nx)),
                       {a: round(b, 3) for a, b in km.items()}, flush=True)
+
+if what == 'small':
+    # interactive sizes: where host overhead, not the kernels, sets the time
+    from nd_amd import xr_lite
+    from nd_amd.change import OmnibusTest
+    from nd_amd.filters import BoxcarFilter, NLMeansFilter, GaussianFilter
+    import numpy as np
+    for ny, nx in ((64, 64), (512, 512), (1024, 1024)):
+        k = 24
+        st = synth.wishart_c2_stack(k, ny, nx, looks=9, seed=12, device=dev, change_frac=0.01)
+        for where in ('device', 'host'):
+            ds = xr_lite.Dataset()
+            v = [st[i].permute(1, 2, 0).contiguous() for i in range(4)]
+            c12 = torch.complex(v[1], v[2])
+            if where == 'host':
+                ds['C11'] = (('y', 'x', 'time'), v[0].cpu().numpy()); ds['C12'] = (('y', 'x', 'time'), c12.cpu().numpy()); ds['C22'] = (('y', 'x', 'time'), v[3].cpu().numpy())
+            else:
+                ds['C11'] = (('y', 'x', 'time'), v[0]); ds['C12'] = (('y', 'x', 'time'), c12); ds['C22'] = (('y', 'x', 'time'), v[3])
+            for name, algo in (('OmnibusTest a=0.01', OmnibusTest(n=9, alpha=0.01)), ('Boxcar w=3', BoxcarFilter(w=3)),
+                               ('Gaussian s=1', GaussianFilter(sigma=1.0)),
+                               ('NLMeans tutorial', NLMeansFilter(dims=('time', 'y', 'x'), r=(1, 3, 3), f=1, sigma=0.5, h=0.5, n_eff=50))):
+                ms = t_ms(lambda: algo.apply(ds), 5)
+                print('small %4dx%-4d %-6s %-20s: %8.3f ms' % (ny, nx, where, name, ms), flush=True)
