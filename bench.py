@@ -492,6 +492,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (nd_amd has no CPU path)')
+    # ND_AMD_BENCH_REHEARSE=gloo: the N > 1 code path on a box with fewer GPUs than ranks (ranks
+    # share the devices, gloo instead of RCCL, which refuses two ranks on one device).  A rehearsal
+    # of the sharding / reduction logic (tests/test_multigpu_gpu.py), never a measurement.
+    rehearse = os.environ.get('ND_AMD_BENCH_REHEARSE', '') == 'gloo'
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -503,7 +509,11 @@ def main():
         # the one JSON line
         if os.environ.get('NCCL_DEBUG', '').upper() in ('VERSION', 'INFO', 'TRACE'):
             os.environ['NCCL_DEBUG'] = 'WARN'
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    rdev = torch.device('cpu') if rehearse else dev      # where the two scalar reductions live
 
     def barrier():
         torch.cuda.synchronize()
@@ -516,10 +526,10 @@ def main():
     dt, avg, out = timed(w.step, args.steps, args.warmup, barrier)
 
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([w.npix], dtype=torch.float64, device=dev)
+        tot = torch.tensor([w.npix], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_px = float(tot.item())
     else:
@@ -539,7 +549,8 @@ def main():
             'metric': w.metric(), 'value': value, 'unit': 'Mpixels/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic' if not rehearse else
+            'synthetic; REHEARSAL: ranks share devices over gloo, not a measurement',
             'config': {
                 'workload': w.describe(),
                 'arithmetic': 'float32 planes and running sums; float64 product of determinants, '

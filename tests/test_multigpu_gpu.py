@@ -6,6 +6,10 @@
     test below, so the sharded kernels, the in-place margin exchange on device buffers and the
     global-edge reflection run across ranks on every box;
 
+  * `test_bench_launch_line_with_two_ranks`: the driver's N > 1 launch line of bench.py with two
+    ranks sharing the GPU over gloo (ND_AMD_BENCH_REHEARSE) -- the sharding, reduction and
+    one-JSON-line logic of the scaling bench, which only the driver can run on real 8-GPU nodes.
+
 Two-GPU checks (skipped on a one-GPU box):
 
   * torch.distributed over `nccl`, one fresh process per GPU: halo exchange into the shard margins,
@@ -188,3 +192,42 @@ def test_devices_argument_with_one_device_is_todays_path(oracle, device):
     want = oracle.change_detection_planes(yxt, 0.9, 9).astype(bool)
     np.testing.assert_array_equal(OmnibusTest(n=9, alpha=0.9, devices=[0]).apply(host).values, want)
     np.testing.assert_array_equal(OmnibusTest(n=9, alpha=0.9, njobs=4).apply(host).values, want)
+
+
+@pytest.mark.parametrize('workload,extra', [('omnibus', []), ('omnibus', ['--scaling', 'strong']),
+                                            ('pipeline', []), ('c3', [])])
+def test_bench_launch_line_with_two_ranks(workload, extra, tmp_path):
+    """The driver's N > 1 launch of bench.py (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 ...), rehearsed with two ranks that share this box's
+    GPU over gloo (ND_AMD_BENCH_REHEARSE): row partition per rank, the max-over-ranks time, the
+    whole-job pixel count, the halo exchange of the pipeline workload, ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ND_AMD_BENCH_REHEARSE='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    ny, nx, k = (96, 512, 8) if workload != 'pipeline' else (64, 512, 6)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--workload', workload, '--ny', str(ny), '--nx', str(nx), '--k', str(k)] + extra
+    # output into files, not pipes: a pipe stays open for as long as any descendant of the launcher
+    # holds it, and the launcher's exit is what this test waits for
+    with open(tmp_path / 'out', 'w') as fo, open(tmp_path / 'err', 'w') as fe:
+        p = subprocess.run(cmd, cwd=root, env=env, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL,
+                           timeout=240)
+    stdout, stderr = (tmp_path / 'out').read_text(), (tmp_path / 'err').read_text()
+    assert p.returncode == 0, stderr[-3000:]
+    # gloo announces its connections on stdout, both ranks interleaved (the rehearsal's transport, not
+    # bench.py's output; RCCL's banner is silenced in bench.py): everything else is the one JSON line
+    banner = set('[Gloo] Rank 0 1 is connected to 1 peer ranks. Expected number of connected peer ranks is : 1')
+    lines = [ln for ln in stdout.splitlines() if ln.strip() and not set(ln) <= banner]
+    assert len(lines) == 1, stdout                      # the contract: one JSON line, rank 0 only
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['steps'] == 2 and res['warmup'] == 1
+    assert res['scaling'] == ('strong' if extra else 'weak')
+    assert res['value'] > 0 and res['ms_per_step'] > 0
+    total_rows = ny if extra else 2 * ny               # weak: every rank owns `ny` rows
+    want = total_rows * nx / (res['ms_per_step'] * 1e-3) / 1e6
+    assert abs(res['value'] - want) <= 1e-6 * want
+    assert 'REHEARSAL' in res['data'] and 'roofline' in res
