@@ -1339,11 +1339,17 @@ __device__ __forceinline__ float f32_from_next(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xF, 0xF, true));
 }
 
-template <int R>
+template <int R, bool DWIN>
 __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs a)
 {
     constexpr int FEED = (R + 3) / 4;               // feeder lanes at either end of the wave
-    constexpr int NY = 2 * R + 1, PD = 3, RING = NY + PD;
+    constexpr int NY = 2 * R + 1, PD = 3;
+    // DWIN: the window of 2 R + 1 rows is kept as float64 (a row is converted once, when it enters
+    // the window, instead of once per output row it contributes to); only the PD rows in flight
+    // stay float32.  WN window slots: the next multiple of PD, so that both slot indices are
+    // compile-time constants under one unrolling
+    constexpr int WN = DWIN ? ((NY + PD - 1) / PD) * PD : 1;
+    constexpr int RING = DWIN ? WN : NY + PD;
     constexpr int SW = (64 - 2 * FEED) * 4;         // columns written per wave
     const int lane = threadIdx.x & 63;
     int64_t wid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1381,7 +1387,8 @@ __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs
         return v;
     };
 
-    f32x4 ring[RING];
+    f32x4 ring[DWIN ? PD : RING];
+    double dwin[WN][4];
     const int nt = (ye - ys) + 2 * R;               // input rows this wave consumes
 #pragma unroll
     for (int t = 0; t < PD; ++t)
@@ -1395,17 +1402,32 @@ __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs
         for (int pu = 0; pu < RING; ++pu) {
             const int t = t0 + pu;
             if (t < nt) {
-                if (t + PD < nt) ring[(pu + PD) % RING] = load_row(t + PD);
+                if constexpr (DWIN) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dwin[pu][c] = (double)ring[pu % PD][c];
+                    if (t + PD < nt) ring[pu % PD] = load_row(t + PD);
+                } else {
+                    if (t + PD < nt) ring[(pu + PD) % RING] = load_row(t + PD);
+                }
                 if (t >= 2 * R) {
                     // ---- pass along y on this lane's four columns: rows t - 2R .. t, centre t - R
                     float ty[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        double o = (double)ring[(pu + RING - R) % RING][c] * a.wy[0];
+                        double o;
+                        if constexpr (DWIN) {
+                            o = dwin[(pu + RING - R) % RING][c] * a.wy[0];
 #pragma unroll
-                        for (int d = R; d >= 1; --d)
-                            o = o + ((double)ring[(pu + 2 * RING - R - d) % RING][c] +
-                                     (double)ring[(pu + RING - R + d) % RING][c]) * a.wy[d];
+                            for (int d = R; d >= 1; --d)
+                                o = o + (dwin[(pu + 2 * RING - R - d) % RING][c] +
+                                         dwin[(pu + RING - R + d) % RING][c]) * a.wy[d];
+                        } else {
+                            o = (double)ring[(pu + RING - R) % RING][c] * a.wy[0];
+#pragma unroll
+                            for (int d = R; d >= 1; --d)
+                                o = o + ((double)ring[(pu + 2 * RING - R - d) % RING][c] +
+                                         (double)ring[(pu + RING - R + d) % RING][c]) * a.wy[d];
+                        }
                         ty[c] = (float)o;           // the intermediate array, in the array dtype
                     }
                     // ---- pass along x: R values from either side through the neighbouring lanes
@@ -1539,6 +1561,8 @@ extern "C" int nd_amd_correlate1d_yx(const void *in, void *out, int dtype, const
     // rows per wave: the 2 R rows read ahead of the first output are re-read by the next chunk
     int64_t rpc = R >= 3 ? 128 : 64;
     while (rpc > 16 && (int64_t)a.nstrips * ceil_div(ny, rpc) * nb < 12288) rpc /= 2;
+    static const int rpc_env = getenv("ND_AMD_YX_RPC") ? atoi(getenv("ND_AMD_YX_RPC")) : 0;
+    if (rpc_env > 0) rpc = rpc_env;
     a.rows_per_chunk = (int)rpc;
     a.nchunks = (int)ceil_div(ny, rpc);
     a.vec_in = (((uintptr_t)in & 15) == 0 && (sbi & 3) == 0 && (si[2] & 3) == 0) ? 1 : 0;
@@ -1558,15 +1582,24 @@ extern "C" int nd_amd_correlate1d_yx(const void *in, void *out, int dtype, const
     {
         KernelTimer timer(ND_AMD_KERNEL_CORRELATE1D, stream);
         const dim3 grid((unsigned)nblocks), block(256);
+        static const int dwin_env = getenv("ND_AMD_YX_DWIN") ? atoi(getenv("ND_AMD_YX_DWIN")) : -1;
+        // measured on 24 x 4096 x 4096 (tools/exp_gauss_yx.py): the float64 window wins from radius 6
+        // (sigma 1.5: 0.90 -> 0.85 ms, sigma 2: 1.14 -> 0.98 ms) and loses below (registers: 118 vs 82
+        // at radius 4)
+        const bool dw = dwin_env >= 0 ? dwin_env != 0 : R >= 6;
+#define ND_YX(RR)                                                                                  \
+    case RR:                                                                                       \
+        if (dw) hipLaunchKernelGGL((correlate1d_yx_kernel<RR, true>), grid, block, 0, stream, a);   \
+        else hipLaunchKernelGGL((correlate1d_yx_kernel<RR, false>), grid, block, 0, stream, a);     \
+        break;
         switch (R) {
-        case 1: hipLaunchKernelGGL((correlate1d_yx_kernel<1>), grid, block, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((correlate1d_yx_kernel<2>), grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((correlate1d_yx_kernel<3>), grid, block, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((correlate1d_yx_kernel<4>), grid, block, 0, stream, a); break;
-        case 5: hipLaunchKernelGGL((correlate1d_yx_kernel<5>), grid, block, 0, stream, a); break;
-        case 6: hipLaunchKernelGGL((correlate1d_yx_kernel<6>), grid, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL((correlate1d_yx_kernel<8>), grid, block, 0, stream, a); break;
+            ND_YX(1) ND_YX(2) ND_YX(3) ND_YX(4) ND_YX(5) ND_YX(6)
+        default:
+            if (dw) hipLaunchKernelGGL((correlate1d_yx_kernel<8, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((correlate1d_yx_kernel<8, false>), grid, block, 0, stream, a);
+            break;
         }
+#undef ND_YX
     }
     ND_HIP_CHECK(hipGetLastError());
     return ND_AMD_OK;
