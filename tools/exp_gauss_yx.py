@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     print(json.dumps(res))
 else:
     for dw in ('0', '1'):
-        for rpc in ('0', '64', '32'):
+        for rpc in ('0', '64'):
             env = dict(os.environ, ND_AMD_YX_DWIN=dw, ND_AMD_YX_RPC=rpc)
             fn = '/tmp/gyx_%s_%s.out' % (dw, rpc)
             with open(fn, 'w') as fo:
