@@ -208,7 +208,7 @@ __device__ __forceinline__ int nlm_reflect_i(int64_t i, int64_t shape)
 // stage (rows x cols) of variable v, slice i2, top-left global coordinate (gy0, gx0), into lds
 __device__ __forceinline__ void nlm_stage(const NlmTiledArgs &a, float *lds, int *ymap, int *xmap,
                                           int rows, int cols, int64_t gy0, int64_t gx0, int64_t i2,
-                                          int v, int tid)
+                                          int v, int tid, bool *nonfinite = nullptr)
 {
     for (int i = tid; i < rows + cols; i += 256) {
         // Positions that feed a written pixel reflect into the tile (checked on the host); the
@@ -239,7 +239,10 @@ __device__ __forceinline__ void nlm_stage(const NlmTiledArgs &a, float *lds, int
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * 256 + tid;
-            if (e < n) lds[e] = buf[u];
+            if (e < n) {
+                lds[e] = buf[u];
+                if (nonfinite) *nonfinite = *nonfinite || !(fabsf(buf[u]) < INFINITY);
+            }
         }
     }
     __syncthreads();
@@ -1142,15 +1145,35 @@ __device__ __forceinline__ f2_t patch2_row_sums(const f2_t e)
         hs.x = (dpp_from_prev(P) + P) + dpp_from_next(e.x);
         hs.y = (dpp_from_prev(e.y) + P) + dpp_from_next(P);
     } else {
-        const float C = (dpp_from_prev(P) + P) + dpp_from_next(P);
-        hs.x = C + dpp_from_prev(dpp_from_prev(e.y));
-        hs.y = C + dpp_from_next(dpp_from_next(e.x));
+        // columns 2l-3 .. 2l+3 and 2l-2 .. 2l+4 out of three-column pieces, every step one addition
+        // with a wave-shifted operand (v_add_f32_dpp; fetching e(2l-3) and e(2l+4) by themselves
+        // takes two shifts each):  T(l) = e(2l-1) + P(l),  U(l) = P(l) + e(2l+2)
+        const float T = dpp_from_prev(e.y) + P;
+        const float U = P + dpp_from_next(e.x);
+        hs.x = (dpp_from_prev(T) + P) + dpp_from_next(P);
+        hs.y = (dpp_from_prev(P) + P) + dpp_from_next(U);
     }
     return hs;
 }
 
-template <int F, int V, int TYW, bool NEFF>
-__global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs a)
+// MC: the margin as a compile-time constant (0: from r1).  With the row pitch of the tile known at
+// compile time the rows of a column become immediate offsets of the LDS instructions instead of
+// one address register per row, each advanced by a vector addition at every search offset.
+constexpr int kPatch2Margin = 16;
+// Waves per SIMD the register allocation is held to.  One variable: 3 (168 registers; the few
+// values that no longer fit are spilled outside the offset loop) -- the cross-lane row sums are
+// chains of dependent additions with DPP wait states, and a third wave fills them: config 3
+// 53 -> 46 ms; 4 waves gain nothing more.  Several variables: 2 (3 spills inside the loop:
+// 4 variables 34 -> 59 ms); unbounded, the n_eff forms pass 256 registers and run one wave per
+// SIMD (58 -> 93 ms).  Measured with tools/exp_nlm_cc.py.
+#ifndef ND_P2_W1
+#define ND_P2_W1 3
+#endif
+#ifndef ND_P2_WV
+#define ND_P2_WV 2
+#endif
+template <int F, int V, int TYW, bool NEFF, int MC>
+__global__ void __launch_bounds__(256, V == 1 ? ND_P2_W1 : ND_P2_WV) nlmeans_patch2_kernel(const NlmTiledArgs a)
 {
     extern __shared__ __align__(16) unsigned char nd_smem_n[];
     constexpr int HL = Patch2Geom<F>::HL, TX = Patch2Geom<F>::TX, TY = 4 * TYW;
@@ -1158,7 +1181,8 @@ __global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs 
     const int lane = tid & 63, wave = tid >> 6;
     const int r0 = a.r0, r1 = a.r1;
     const int halo0 = r0 + F;
-    const int M = r1 + 2 * HL + (r1 & 1);        // left / right margin: even, >= r1 + F and >= r1 + 2 HL
+    // left / right margin: even, >= r1 + F and >= r1 + 2 HL
+    const int M = MC ? MC : r1 + 2 * HL + (r1 & 1);
     const int cols = TX + 2 * M, rows = TY + 2 * halo0;
     float *lds = reinterpret_cast<float *>(nd_smem_n);               // [V][rows][cols]
     int *ymap = reinterpret_cast<int *>(lds + V * rows * cols);
@@ -1175,12 +1199,17 @@ __global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs 
     const int64_t xs = a.clo1 - ((a.off1 + a.clo1) & 1);
     const int64_t y0 = a.clo0 + (int64_t)ty * TY, x0 = xs + (int64_t)tx * TX;
 
+    bool nonfinite = false;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         __syncthreads();
         nlm_stage(a, lds + v * rows * cols, ymap, xmap, rows, cols, a.off0 + y0 - halo0,
-                  a.off1 + x0 - M, i2, v, tid);
+                  a.off1 + x0 - M, i2, v, tid, &nonfinite);
     }
+    // A patch sum can only be NaN when the tile holds a NaN or an infinity (squares of finite
+    // differences are finite or +inf, and +inf gives the weight 0 like the reference's exp(-inf)):
+    // tiles of finite values -- all but nodata areas -- skip the NaN bookkeeping of the loop below
+    const bool tile_nonfinite = __syncthreads_or(nonfinite ? 1 : 0) != 0;
 
     // this lane: tile columns 2 (lane - HL), + 1 (feeder lanes: columns outside the tile), rows
     // wave*TYW .. wave*TYW + TYW - 1; LDS column of the pair's first element is even
@@ -1197,21 +1226,27 @@ __global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs 
         for (int v = 0; v < V; ++v) ws[p][v] = (f2_t){0.f, 0.f};
     }
     // the reference divides in double; reciprocals in float32 differ by ~1e-7 relative
-    const float inv_norm = (float)(1.0 / (double)a.dsq_norm);
     const float exp2_scale = (float)(-1.4426950408889634 / a.h2);      // w = 2^(m * exp2_scale)
-    const f2_t inv_norm2 = (f2_t){inv_norm, inv_norm};
-    const f2_t neg_two_sigma2 = (f2_t){-(float)a.two_sigma2, -(float)a.two_sigma2};
+    const float c1 = (float)((double)exp2_scale / (double)a.dsq_norm);
+    const float c0 = (float)(-(double)a.two_sigma2 * (double)exp2_scale);
+    const f2_t exp_c1 = (f2_t){c1, c1}, exp_c0 = (f2_t){c0, c0};
     const f2_t zero2 = (f2_t){0.f, 0.f};
     f2_t ssum[TYW];
 #pragma unroll
     for (int p = 0; p < TYW; ++p) ssum[p] = zero2;
 
+    auto search = [&](auto track_nan) {
     for (int dy = -r0; dy <= r0; ++dy) {
         f2_t twf[TYW];                    // NEFF = false: float32 partial sums of this search row
 #pragma unroll
         for (int p = 0; p < TYW; ++p) twf[p] = (f2_t){0.f, 0.f};
-        for (int dx = -r1; dx <= r1; ++dx) {
-            if (dy == 0 && dx == 0) continue;
+        // three search offsets per trip: their LDS reads then share one address register per row
+        // (the offsets along x are immediates); trips beyond r1 and the centre are skipped
+        for (int dx0 = -r1; dx0 <= r1; dx0 += 3)
+#pragma unroll
+        for (int du = 0; du < 3; ++du) {
+            const int dx = dx0 + du;
+            if (dx > r1 || (dy == 0 && dx == 0)) continue;
             f2_t H[2 * F + 1], Q[2 * F + 1];      // rings: row sums, and sums of two adjacent rows
 #pragma unroll
             for (int s = 0; s < TYW + 2 * F; ++s) {
@@ -1245,14 +1280,18 @@ __global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs 
                     } else {
                         S = ((Q[(s - 5) % NR] + Q[(s - 3) % NR]) + Q[(s - 1) % NR]) + H[s % NR];
                     }
-                    ssum[p] = ssum[p] + S;          // NaN anywhere in the pixel's patch sums sticks here
-                    const f2_t t = __builtin_elementwise_fma(S, inv_norm2, neg_two_sigma2);
-                    // max(t, 0): a NaN would be dropped here, `ssum` remembers it (exact path below)
-                    const f2_t m = pk_max(t, zero2);
-                    const f2_t ma = m * exp2_scale;
+                    if (decltype(track_nan)::value)
+                        ssum[p] = ssum[p] + S;      // NaN anywhere in the pixel's patch sums sticks here
+                    // w = exp(-max(d2 / norm - 2 sigma^2, 0) / h^2) = min(2^(S c1 + c0), 1): one fused
+                    // multiply-add for the exponent, and the hardware exponential with the clamp
+                    // modifier (result clamped to [0, 1]; a NaN would be dropped here, `ssum`
+                    // remembers it for the exact path below).  The s_nop covers the wait state a
+                    // transcendental result needs before an ordinary vector instruction reads it,
+                    // which the compiler does not insert around inline assembly.
+                    const f2_t ma = __builtin_elementwise_fma(S, exp_c1, exp_c0);
                     f2_t w;
-                    w.x = __builtin_amdgcn_exp2f(ma.x);
-                    w.y = __builtin_amdgcn_exp2f(ma.y);
+                    asm("v_exp_f32_e64 %0, %2 clamp\n\tv_exp_f32_e64 %1, %3 clamp\n\ts_nop 0"
+                        : "=&v"(w.x), "=v"(w.y) : "v"(ma.x), "v"(ma.y));
                     if (NEFF) {
                         // the self weight solves a quadratic whose discriminant cancels: the two
                         // weight sums it is made of are kept in double, like the reference's
@@ -1284,6 +1323,11 @@ __global__ void __launch_bounds__(256) nlmeans_patch2_kernel(const NlmTiledArgs 
             }
         }
     }
+    };
+    if (tile_nonfinite)
+        search(std::true_type{});
+    else
+        search(std::false_type{});
 
     const bool feeder = (lane < HL) || (lane >= 64 - HL);
     // Pixels whose largest float32 weight is (nearly) zero: the reference's double weights are
@@ -1378,10 +1422,19 @@ static void launch_patch2(const NlmTiledArgs &a, int64_t nslices, size_t lds, hi
 {
     constexpr int TYW = Patch2Rows<V>::TYW;
     const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nslices;
+    const bool mc = a.r1 + 2 * Patch2Geom<F>::HL + (a.r1 & 1) <= kPatch2Margin;    // as the host sized the tile
     if (a.n_eff >= 0) {
-        ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, true>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        if (mc) {
+            ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, true, kPatch2Margin>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        } else {
+            ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, true, 0>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        }
     } else {
-        ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, false>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        if (mc) {
+            ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, false, kPatch2Margin>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        } else {
+            ND_LAUNCH_LDS((nlmeans_patch2_kernel<F, V, TYW, false, 0>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        }
     }
 }
 
@@ -1521,7 +1574,8 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
     if (!no_patch2 && F0 >= 1) {
         // cross-lane form: two columns per lane
         const int hl = (F0 == 3) ? 2 : 1, tx2 = 2 * (64 - 2 * hl), tyw2 = (nvars == 1) ? Patch2Rows<1>::TYW : Patch2Rows<2>::TYW;
-        const int m = a.r1 + 2 * hl + (a.r1 & 1);
+        int m = a.r1 + 2 * hl + (a.r1 & 1);
+        if (m <= kPatch2Margin) m = kPatch2Margin;     // the constant-pitch instantiation (launch_patch2)
         const size_t cols2 = (size_t)tx2 + 2 * (size_t)m, rows2 = 4 * (size_t)tyw2 + 2 * (size_t)(a.r0 + F0);
         const size_t lds2 = (size_t)nvars * rows2 * cols2 * sizeof(float) + (rows2 + cols2) * sizeof(int);
         a.tiles_x = (int)ceil_div(ex + 1, tx2);        // + 1: the tiles start on an even global column
