@@ -438,7 +438,10 @@ def extras(main, barrier, dev):
     x = torch.empty((1, k, ny, nx), device=dev)
     for t in range(k):
         u = torch.rand((4, ny, nx), generator=g, device=dev)
-        x[0, t] = -0.25 * torch.log(u).sum(dim=0)              # Gamma(4, 0.25)
+        # Gamma(4, 0.25).  torch.rand draws from [0, 1): a zero (one draw in 2^24) would put an
+        # infinity into a variate that has none, and every pixel within r + f of it would take the
+        # kernel's exact per-pixel path
+        x[0, t] = -0.25 * torch.log(u.clamp_min_(2.0 ** -25)).sum(dim=0)
     y = torch.empty_like(x)
     r, f = (0, 10, 10), (0, 3, 3)
     for pm in (0, 1):

@@ -900,6 +900,28 @@ static bool launch_roll_r1(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStr
 }
 
 // ---- patch_mode 1: sliding patch-row sums ---------------------------------------------------
+// A NaN inside the pixel's OWN patch makes every patch distance NaN (it enters each of them), hence
+// every weight, both weight sums and the weighted sums: the reference's result is NaN for every
+// variable (nd/_filters.pyx:386-420; the self weight is 1, NaN or -- when n_eff - 1 == 0 -- the error
+// case, which is left to the full evaluation).  Nodata regions therefore cost one look at the patch
+// instead of the whole search window in double precision.
+template <int F, int V>
+__device__ __forceinline__ bool nlm_own_patch_nan(const float *lds, int plane, int cols, int py, int px)
+{
+    bool nan = false;
+#ifdef ND_NO_OWN_NAN
+    return false;
+#endif
+    for (int i = -F; i <= F; ++i)
+        for (int j = -F; j <= F; ++j)
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float c = lds[v * plane + (py + i) * cols + px + j];
+                nan = nan || (c != c);
+            }
+    return nan;
+}
+
 template <int F, int V, int TYW, bool NEFF>
 __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a)
 {
@@ -947,11 +969,16 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
     const float neg_inv_h2 = (float)(-1.0 / a.h2);
     const float two_sigma2 = (float)a.two_sigma2;
 
+    // Non-finite row sums (NaN / inf data) must not enter the sliding sum -- NaN - NaN and inf - inf
+    // would stay in it for every row further down: they count as 0 there, and the pixels whose
+    // 2F + 1 rows hold one are evaluated by the exact path below
+    unsigned nonfinite_mask = 0;
     for (int dy = -r0; dy <= r0; ++dy) {
         for (int dx = -r1; dx <= r1; ++dx) {
             if (dy == 0 && dx == 0) continue;
             double S = 0.0;
             double H[TYW + 2 * F];
+            int bad_age = 1 << 20;                 // rows since the last non-finite row sum
 #pragma unroll
             for (int s = 0; s < TYW + 2 * F; ++s) {
                 // patch-row sum of squared differences at image row (cy0 - F + s)
@@ -967,11 +994,14 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
                         hs = hs + df * df;
                     }
                 }
-                H[s] = (double)hs;
+                const bool hbad = !(hs < INFINITY);
+                H[s] = hbad ? 0.0 : (double)hs;
+                bad_age = hbad ? 0 : bad_age + 1;
                 S = S + H[s];
                 if (s >= 2 * F + 1) S = S - H[s - 2 * F - 1];
                 if (s >= 2 * F) {
                     const int p = s - 2 * F;
+                    if (bad_age <= 2 * F) nonfinite_mask |= 1u << p;
                     // weight argument in float32 from here on (the patch-row sums already are):
                     // relative error ~1e-7 of d2, far inside the budget
                     const float d2 = (float)S * inv_norm;
@@ -1009,7 +1039,8 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
     for (int p = 0; p < TYW; ++p) {
         const int64_t y = y0 + wave * TYW + p;
         if (y < a.chi0 && x < a.chi1) {
-            if (!(wmax[p] >= 1e-30f) || (NEFF && nlm_neff_ill(tw[p], NEFF ? tsq[p] : 0.0, a.n_eff))) {
+            if (!(wmax[p] >= 1e-30f) || ((nonfinite_mask >> p) & 1u) ||
+                (NEFF && nlm_neff_ill(tw[p], NEFF ? tsq[p] : 0.0, a.n_eff))) {
                 exact_mask |= 1u << p;
                 continue;
             }
@@ -1033,6 +1064,13 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
             if (!((exact_mask >> p) & 1u)) continue;
             // nd/_filters.pyx:363-420 for this one pixel, from the staged tile
             const int py = cy0 + p;
+            if (!(a.n_eff >= 0 && (a.n_eff - 1.0) == 0) && nlm_own_patch_nan<F, V>(lds, rows * cols, cols, py, cx)) {
+                const int64_t y = y0 + wave * TYW + p;
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] = __builtin_nanf("");
+                continue;
+            }
             double t_w = 0.0, t_sq = 0.0, m_w = 0.0;
             float wsum[V];
 #pragma unroll
@@ -1369,6 +1407,14 @@ __global__ void __launch_bounds__(256, V == 1 ? ND_P2_W1 : ND_P2_WV) nlmeans_pat
             // nd/_filters.pyx:363-420 for this one pixel, from the staged tile
             const int p = pc >> 1, c = pc & 1;
             const int py = cy0 + p, pxc = cx + c;
+            if (!(a.n_eff >= 0 && (a.n_eff - 1.0) == 0) && nlm_own_patch_nan<F, V>(lds, rows * cols, cols, py, pxc)) {
+                const int64_t y = y0 + wave * TYW + p;
+                const int64_t x = x0 + 2 * (lane - HL) + c;
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] = __builtin_nanf("");
+                continue;
+            }
             double t_w = 0.0, t_sq = 0.0, m_w = 0.0;
             float wsum[V];
 #pragma unroll

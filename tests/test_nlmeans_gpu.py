@@ -319,7 +319,10 @@ def test_window_kernels_with_nodata(oracle, device):
     a[4, 5, 100, 1] = np.inf
     planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)
     for r, f, ne, pm in (((1, 3, 3), (1, 1, 1), 50.0, 0), ((2, 2, 2), (1, 1, 1), -1, 0), ((0, 3, 3), (0, 1, 1), -1, 0),
-                         ((0, 3, 3), (0, 1, 1), -1, 1), ((0, 2, 2), (0, 1, 1), 6.0, 1)):
+                         ((0, 3, 3), (0, 1, 1), -1, 1), ((0, 2, 2), (0, 1, 1), 6.0, 1),
+                         # f = 0: the one-column-per-lane patch kernel, whose sliding sum down the
+                         # column must not carry a NaN / inf row sum along
+                         ((0, 3, 3), (0, 0, 0), -1, 1), ((0, 2, 2), (0, 0, 0), 6.0, 1)):
         want = np.empty_like(a)
         with np.errstate(all='ignore'):
             oracle.pixelwise_nlmeans_3d(a, want, r, f, 0.5, 0.5, ne, neff_policy=0, njobs=8, patch_mode=pm)

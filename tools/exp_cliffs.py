@@ -188,3 +188,27 @@ if what == 'small':
                                ('NLMeans tutorial', NLMeansFilter(dims=('time', 'y', 'x'), r=(1, 3, 3), f=1, sigma=0.5, h=0.5, n_eff=50))):
                 ms = t_ms(lambda: algo.apply(ds), 5)
                 print('small %4dx%-4d %-6s %-20s: %8.3f ms' % (ny, nx, where, name, ms), flush=True)
+
+if what == 'nlm_nodata':
+    # non-local means on rasters with nodata margins (30 % of the columns NaN / zero on all dates)
+    g = torch.Generator(device=dev).manual_seed(5)
+    for desc, shape, r, f, sg, h, ne in (('tutorial r=(1,3,3) f=1 V=4', (4, 12, 1024, 4096), (1, 3, 3), (1, 1, 1), 1.0, 1.0, 50.0),
+                                         ('7x7 / 21x21 V=1', (1, 6, 2048, 4096), (0, 10, 10), (0, 3, 3), 0.5, 0.5, -1.0)):
+        base = torch.rand(shape, generator=g, device=dev) + 0.5
+        out = torch.empty_like(base)
+        for fill in ('none', 'nan', 'zero'):
+            x = base.clone()
+            if fill == 'nan':
+                x[..., : int(0.3 * shape[-1])] = float('nan')
+            elif fill == 'zero':
+                x[..., : int(0.3 * shape[-1])] = 0.0
+            for pm in (0, 1):
+                if r[0] == 0:
+                    fn = lambda: kernels.pixelwise_nlmeans_3d(x.permute(2, 3, 1, 0), out.permute(2, 3, 1, 0), (r[1], r[2], 0), (f[1], f[2], 0), sg, h, ne, patch_mode=pm)
+                else:
+                    fn = lambda: kernels.pixelwise_nlmeans_3d(x.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, sg, h, ne, patch_mode=pm)
+                try:
+                    ms = t_ms(fn, 2)
+                    print('nlm_nodata %-28s fill=%-5s patch_mode %d: %9.2f ms' % (desc, fill, pm, ms), flush=True)
+                except Exception as e:
+                    print('nlm_nodata %-28s fill=%-5s patch_mode %d: %s' % (desc, fill, pm, str(e)[:80]), flush=True)
