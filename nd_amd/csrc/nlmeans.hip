@@ -972,13 +972,13 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
     // Non-finite row sums (NaN / inf data) must not enter the sliding sum -- NaN - NaN and inf - inf
     // would stay in it for every row further down: they count as 0 there, and the pixels whose
     // 2F + 1 rows hold one are evaluated by the exact path below
-    unsigned nonfinite_mask = 0;
+    unsigned nonfinite_mask = 0, nan_mask = 0;
     for (int dy = -r0; dy <= r0; ++dy) {
         for (int dx = -r1; dx <= r1; ++dx) {
             if (dy == 0 && dx == 0) continue;
             double S = 0.0;
             double H[TYW + 2 * F];
-            int bad_age = 1 << 20;                 // rows since the last non-finite row sum
+            int bad_age = 1 << 20, nan_age = 1 << 20;      // rows since the last non-finite / NaN row sum
 #pragma unroll
             for (int s = 0; s < TYW + 2 * F; ++s) {
                 // patch-row sum of squared differences at image row (cy0 - F + s)
@@ -997,11 +997,13 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
                 const bool hbad = !(hs < INFINITY);
                 H[s] = hbad ? 0.0 : (double)hs;
                 bad_age = hbad ? 0 : bad_age + 1;
+                nan_age = (hs != hs) ? 0 : nan_age + 1;
                 S = S + H[s];
                 if (s >= 2 * F + 1) S = S - H[s - 2 * F - 1];
                 if (s >= 2 * F) {
                     const int p = s - 2 * F;
                     if (bad_age <= 2 * F) nonfinite_mask |= 1u << p;
+                    if (nan_age <= 2 * F) nan_mask |= 1u << p;
                     // weight argument in float32 from here on (the patch-row sums already are):
                     // relative error ~1e-7 of d2, far inside the budget
                     const float d2 = (float)S * inv_norm;
@@ -1039,6 +1041,13 @@ __global__ void __launch_bounds__(256) nlmeans_patch_kernel(const NlmTiledArgs a
     for (int p = 0; p < TYW; ++p) {
         const int64_t y = y0 + wave * TYW + p;
         if (y < a.chi0 && x < a.chi1) {
+            if (((nan_mask >> p) & 1u) && !(a.n_eff >= 0 && (a.n_eff - 1.0) == 0)) {
+                // a NaN patch distance: NaN weight, NaN sums, NaN result (nd/_filters.pyx:386-420)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] = __builtin_nanf("");
+                continue;
+            }
             if (!(wmax[p] >= 1e-30f) || ((nonfinite_mask >> p) & 1u) ||
                 (NEFF && nlm_neff_ill(tw[p], NEFF ? tsq[p] : 0.0, a.n_eff))) {
                 exact_mask |= 1u << p;
@@ -1368,6 +1377,8 @@ __global__ void __launch_bounds__(256, V == 1 ? ND_P2_W1 : ND_P2_WV) nlmeans_pat
         search(std::false_type{});
 
     const bool feeder = (lane < HL) || (lane >= 64 - HL);
+    // (with n_eff - 1 == 0 the reference takes its error branch instead: left to the exact path)
+    const bool nan_is_final = !(a.n_eff >= 0 && (a.n_eff - 1.0) == 0);
     // Pixels whose largest float32 weight is (nearly) zero: the reference's double weights are
     // still non-zero there and decide the self weight and the (denormal) sums, so those pixels
     // are recomputed below exactly as the reference does.
@@ -1381,6 +1392,14 @@ __global__ void __launch_bounds__(256, V == 1 ? ND_P2_W1 : ND_P2_WV) nlmeans_pat
             if (feeder || !(y < a.chi0 && x < a.chi1 && x >= a.clo1)) continue;
             const float wm = c ? wmax[p].y : wmax[p].x;
             const float sp = c ? ssum[p].y : ssum[p].x;
+            if (!(sp == sp) && nan_is_final) {
+                // some patch distance of this pixel is NaN: so are that weight, both weight sums and
+                // every weighted sum in the reference (nd/_filters.pyx:386-420) -- the result is NaN
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] = __builtin_nanf("");
+                continue;
+            }
             if (!(wm >= 1e-30f) || !(sp == sp) || (NEFF && nlm_neff_ill(tw[p][c], NEFF ? tsq[p][c] : 0.0, a.n_eff))) {
                 exact_mask |= 1u << (2 * p + c);
                 continue;
