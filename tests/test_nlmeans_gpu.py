@@ -337,3 +337,22 @@ def test_window_kernels_with_nodata(oracle, device):
         else:
             ok = ~np.isnan(want)
             np.testing.assert_allclose(got[ok], want[ok], rtol=RTOL)
+
+
+def test_one_column_patch_kernel_forced(tmp_path):
+    """The one-column-per-lane patch kernel normally serves only f = 0 and tiles beyond 150 KB of
+    LDS; forced for every signed-mode case (ND_AMD_NLM_PATCH1, read once per process, hence the one
+    child process) it must pass the same nodata, random-oracle and tiling-invariance checks -- its
+    sliding sum down the column once carried NaN row sums along."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ND_AMD_NLM_PATCH1='1')
+    with open(tmp_path / 'log', 'w') as fo:
+        p = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider',
+                            '-k', 'nodata or oracle_random or halo or tiny_weights or planar_layout'],
+                           env=env, stdout=fo, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=900,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    log = (tmp_path / 'log').read_text()
+    assert p.returncode == 0, log[-3000:]
+    assert ' passed' in log and 'failed' not in log, log[-1000:]
