@@ -56,6 +56,7 @@ extern "C" {
 #define ND_AMD_KERNEL_OMNIBUS_DENSE  9
 #define ND_AMD_KERNEL_OMNIBUS_FUSED  10   /* pass A with the change-point search fused in */
 #define ND_AMD_KERNEL_OMNIBUS_SAMPLE 11   /* density sample that gates the fused form */
+#define ND_AMD_KERNEL_OMNIBUS_EXACT  12   /* pass B, exact form behind the register form (marked pixels only) */
 
 int nd_amd_abi_version(void);
 const char *nd_amd_last_error(void);

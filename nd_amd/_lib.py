@@ -17,7 +17,7 @@ MODES = {'reflect': 0, 'constant': 1, 'nearest': 2, 'mirror': 3, 'wrap': 4,
          'grid-constant': 1, 'grid-mirror': 0, 'grid-wrap': 4}
 KERNEL_NAMES = {1: 'omnibus_c2_global', 2: 'omnibus_c2_search', 3: 'correlate',
                 4: 'nlmeans', 5: 'boxcar_tiled', 6: 'nlmeans_tiled', 7: 'correlate1d',
-                8: 'relayout', 9: 'omnibus_c2_dense', 10: 'omnibus_c2_fused', 11: 'omnibus_c2_sample'}
+                8: 'relayout', 9: 'omnibus_c2_dense', 10: 'omnibus_c2_fused', 11: 'omnibus_c2_sample', 12: 'omnibus_c2_exact'}
 
 # every symbol include/nd_amd.h declares
 SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',

@@ -1882,6 +1882,13 @@ struct OmniSearchArgs {
     const uint32_t *gate;
     uint32_t gate_n;
     int gate_mode;
+    // Hand-over between the register form and the exact form of pass B: one word per 64 list
+    // entries of a shard (bit = the screen could not decide a test of that pixel).  The register
+    // form writes every word of the lists it walks; the LDS form, run behind it with the same
+    // lists, searches exactly the marked pixels.  nullptr: the LDS form searches every pixel.
+    unsigned long long *hand_bits;
+    uint32_t hand_words;          // words per shard
+    uint32_t *hand_count;         // number of marked pixels (zeroed with the list counters)
 };
 
 // ---- the zero-fill of the change map, done by pass B --------------------------------------
@@ -2136,7 +2143,14 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
 
     for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
         const uint32_t idx = base + lane;
-        const bool active = idx < n;
+        bool active = idx < n;
+        if (s.hand_bits != nullptr) {
+            // behind the register form: only the pixels it marked (usually none at all)
+            if (__builtin_nontemporal_load(s.hand_count) == 0u) return;
+            const unsigned long long marked = s.hand_bits[(size_t)shard * s.hand_words + (base >> 6)];
+            if (marked == 0ull) continue;
+            active = active && ((marked >> lane) & 1ull);
+        }
         const int64_t pix = active ? (int64_t)list[idx] : 0;
         const int64_t row = pix / s.nx;
         const int64_t col = pix - row * s.nx;
@@ -2328,6 +2342,276 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     while (__any(fp.left > 0)) fp.step();
 }
 
+// -----------------------------------------------------------------------------------------
+// pass B, register form (k <= 32 float / 16 double): the listed pixel's series sits in registers,
+// not in LDS, and the wave walks the dates 0 .. k-1 TOGETHER, once per round of segments:
+//
+//   round r: every unfinished lane folds the dates of its CURRENT segment [l, k) -- dates before l
+//            are masked to zero, so a lane's running sums are (0 + a_l) + a_l+1 + ... in
+//            `floating`, the reference's own additions in its order (nd/_change.pyx:64-69), and the
+//            date index is wave-uniform: register arrays with static indices, straight-line code
+//            the scheduler can interleave.  Per date one test per lane at most (the marginal test
+//            over ts[l:t+1] while none has fired, the global test at the last date), decided by the
+//            float32 / integer screen of dense_search (exact integer sums of per-date log2 parts
+//            instead of the double product, DenseScreenEntry); after the last date a lane commits
+//            its first firing date if the global test fired (nd/_change.pyx:247-256) and starts the
+//            next segment there.
+//   A test the screen cannot decide (about 3e-5 of them) pauses its lane for the rest of the
+//            round.  Behind the unrolled dates, under a WAVE-UNIFORM branch, the wave re-folds
+//            that test with the reference's double product of determinants, evaluates it exactly
+//            (exact_test) and notes the verdict in a pair of bit masks; the segment is then walked
+//            again with the verdict in place of the screen.  The branch is uniform and ends by
+//            loading the series again (from the dump, L2-resident) so that the series registers are
+//            dead while the double-precision log / exp / chi-square code runs: that code needs a
+//            hundred registers and would otherwise set the budget of the whole kernel (in a
+//            divergent branch the registers of the lanes that skip it stay live).
+//   A pixel outside the screen's domain altogether (a determinant <= 0 or non-finite, exponents
+//            summing beyond 900) is marked in `hand_bits` and left to the LDS form, which runs
+//            behind this kernel on the marked pixels only (it returns at once while `hand_count`
+//            says there are none).
+//
+// Against the LDS form: no 24.5 KB image per wave (3 waves per SIMD instead of 1.5) and no double
+// arithmetic in the loop.  Same decisions, same map.
+// -----------------------------------------------------------------------------------------
+// P(z over jj matrices) > alpha, evaluated with the reference's rounding points; `valid` = this
+// lane really has a test (the others ride along under the uniform branch and must not steer the
+// chi-square loop)
+template <typename T>
+__device__ __forceinline__ bool exact_test(const Accum<T> &A, const int jj, const double nlooks,
+                                           const OmniTabEntry *ep, const double alpha, const bool valid)
+{
+    const OmniTabEntry e = *ep;
+    const T zp = z_stat<T>(A, jj, nlooks, e);
+    const double zd = (double)zp;
+    // 0 = cannot fire (z < zlo, or NaN), 1 = fires for certain (zhi < z < inf), 2 = inside the
+    // exact band: needs the chi-square pair
+    int verdict = !valid ? 0 : (!(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2));
+    if (verdict == 2) {
+        double zv[1] = {zd}, P1[1], P2[1];
+        chisq_pair<1>(zv, 4 * (jj - 1), e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+        verdict = ((double)P > alpha) ? 1 : 0;
+    }
+    return verdict == 1;
+}
+
+// waves per SIMD the register budget is held to
+template <typename T, int KMAX>
+constexpr int search_regs_waves()
+{
+    return KMAX * 4 * (int)sizeof(T) / 4 <= 96 ? 3 : 2;
+}
+
+template <typename T, int KMAX>
+__global__ void __launch_bounds__(64, (search_regs_waves<T, KMAX>()))
+omnibus_c2_search_regs_kernel(const OmniSearchArgs<T> s, const DenseScreen scr_arg)
+{
+    static_assert(KMAX <= 32, "the change and verdict masks are 32 bits wide");
+    __shared__ DenseScreenEntry scr_lds[KMAX + 1];
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) scr_lds[j] = scr_arg.e[j];      // static indices only
+    }
+    __syncthreads();
+    // (opaque copy of k: the per-date predicates would otherwise be hoisted out of the loops)
+    int k = s.k;
+    asm volatile("" : "+s"(k));
+    const unsigned shard = blockIdx.x % kShards;
+    const unsigned lblock = blockIdx.x / kShards;
+    const unsigned nlblock = gridDim.x / kShards;
+    const uint32_t n = s.flag_count[shard * kCounterStride];
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+
+    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < n;
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+
+        // ---- the series, every load in flight at once ----
+        // (one base address + constant offsets from the dump; four running pointers over the
+        // planes: a 64-bit address per date and plane would not fit the register budget)
+        T v[KMAX][4];
+        auto load_series = [&]() {
+            if (idx < s.dump_cap) {
+                const T *d = s.dump + ((int64_t)shard * s.dump_cap + idx) * (int64_t)(4 * k);
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) {
+                    if (t < k) {
+                        const Pack<T, 4> q = *reinterpret_cast<const Pack<T, 4> *>(d + 4 * t);
+                        v[t][0] = q.v[0];
+                        v[t][1] = q.v[1];
+                        v[t][2] = q.v[2];
+                        v[t][3] = q.v[3];
+                    } else {
+                        // (every element defined by every call: nothing of an earlier load stays live)
+                        v[t][0] = v[t][1] = v[t][2] = v[t][3] = (T)0;
+                    }
+                }
+            } else {
+                const int64_t row = pix / s.nx;
+                const int64_t col = pix - row * s.nx;
+                const int64_t off = row * s.sy + col * s.sx;
+                const T *p11 = s.c11 + off * s.m11, *p12r = s.c12r + off * s.m12;
+                const T *p12i = s.c12i + off * s.m12, *p22 = s.c22 + off * s.m22;
+                const int64_t d11 = s.st * s.m11, d12 = s.st * s.m12, d22 = s.st * s.m22;
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) {
+                    if (t < k) {
+                        v[t][0] = *p11;
+                        v[t][1] = *p12r;
+                        v[t][2] = *p12i;
+                        v[t][3] = *p22;
+                        p11 += d11;
+                        p12r += d12;
+                        p12i += d12;
+                        p22 += d22;
+                    } else {
+                        v[t][0] = v[t][1] = v[t][2] = v[t][3] = (T)0;
+                    }
+                }
+            }
+        };
+        load_series();
+
+        // ---- is the pixel inside the screen's domain?  every determinant positive and finite, and
+        // |log2| of every partial product below 900: the reference's double product of determinants
+        // is then a normal number, and the integer sums of the walk model its logarithm
+        bool handoff = false;
+        {
+            int eabs = 0;
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                if (t < k) {
+                    const T det = (v[t][0] * v[t][3]) - ((v[t][1] * v[t][1]) + (v[t][2] * v[t][2]));
+                    const bool okd = (det > (T)0) && (det < (T)INFINITY) && (v[t][0] > (T)0);
+                    int e0;
+                    float mf;
+                    log2_parts(okd ? det : (T)1, e0, mf);
+                    eabs += e0 < 0 ? -e0 : e0;
+                    handoff = handoff || !okd;
+                }
+            }
+            handoff = active && (handoff || eabs > 900);
+        }
+
+        bool done = !active || handoff;
+        int l = 0;                 // segment start
+        unsigned cmask = 0u;       // bit t: change detected at date t
+        unsigned ov_m = 0u, ov_f = 0u;   // tests of the current segment decided exactly: which, verdict
+        while (__any(!done)) {
+            T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
+            int Le = 0, Lm = 0;
+            int fire_at = -1;      // first date of this segment whose marginal test fired
+            int und_t = -1;        // date of a test the screen could not decide: lane paused
+            bool gfire = false;    // the global test of ts[l:] fired
+            // The dates in front of every unfinished lane's segment are skipped.  Most lanes are
+            // finished after two rounds; the few whose series keeps firing (half a dozen rounds in
+            // a typical wave) start late in the series, so the later rounds are short.
+            int lmin = done ? KMAX : l;
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                const int o = __shfl_xor(lmin, sh);
+                lmin = o < lmin ? o : lmin;
+            }
+            lmin = __builtin_amdgcn_readfirstlane(lmin);
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                if (t < k && t >= lmin) {
+                    const bool in_seg = !done && (und_t < 0) && (t >= l);
+                    const T a = in_seg ? v[t][0] : (T)0, b = in_seg ? v[t][1] : (T)0;
+                    const T c = in_seg ? v[t][2] : (T)0, d = in_seg ? v[t][3] : (T)0;
+                    const T det = (a * d) - ((b * b) + (c * c));
+                    int e0;
+                    float mf;
+                    log2_parts(in_seg ? det : (T)1, e0, mf);          // (masked dates: e0 + mf = 0, as two parts)
+                    const int m0 = (int)rintf(mf * kLogFix);
+                    s11 = s11 + a;
+                    s12r = s12r + b;
+                    s12i = s12i + c;
+                    s22 = s22 + d;
+                    Le += in_seg ? e0 : 0;
+                    Lm += in_seg ? m0 : 0;
+                    const int jj = t - l + 1;
+                    const bool last = (t == k - 1);
+                    // a marginal test while none has fired yet (j >= 2); at the last date the same
+                    // evaluation is the global test, needed even if a marginal fired earlier
+                    const bool need = in_seg && (jj >= 2) && (fire_at < 0 || last);
+                    if (__any(need)) {
+                        if (need) {
+                            bool fires;
+                            if ((ov_m >> t) & 1u) {
+                                fires = (ov_f >> t) & 1u;
+                            } else {
+                                const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                                const bool ok = (dets > (T)0) && (dets < (T)INFINITY);
+                                const DenseScreenEntry ce = scr_lds[jj];
+                                const float x = dense_x<T>(dets, ok, Le, Lm, jj, ce);
+                                fires = ok && (x < ce.a);
+                                const bool cant = ok && (x > ce.b);
+                                if (!(fires || cant)) und_t = t;       // exact evaluation behind the dates
+                            }
+                            if (fires && fire_at < 0) fire_at = t;
+                            if (last) gfire = fires;
+                        }
+                    }
+                }
+            }
+            if (__any(und_t >= 0)) {
+                // WAVE-UNIFORM from here to the reload: every lane goes through the exact
+                // evaluation (lanes without an undecided test with valid = false).
+                const bool valid = und_t >= 0;
+                const int te = valid ? und_t : l;
+                Accum<T> A;
+                A.reset();
+#pragma unroll
+                for (int u = 0; u < KMAX; ++u)
+                    if (u < k) {
+                        if (u >= l && u <= te) A.step(v[u][0], v[u][1], v[u][2], v[u][3]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);             // the series is dead from here on
+                int jj = te - l + 1;
+                jj = jj < 1 ? 1 : (jj > k ? k : jj);
+                const bool f = exact_test<T>(A, jj, s.nlooks, s.tab + jj, s.alpha, valid);
+                if (valid) {
+                    ov_m |= 1u << und_t;
+                    ov_f |= f ? (1u << und_t) : 0u;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_series();
+            } else if (true) {
+                // (no undecided test in the wave: commit)
+            }
+            if (!done && und_t < 0) {
+                if (gfire) {
+                    cmask |= 1u << fire_at;                // :252, l + r with r = j - 1
+                    l = fire_at;                           // :255
+                    ov_m = 0u;
+                    ov_f = 0u;
+                    if (l >= k - 1) done = true;           // :256
+                } else {
+                    done = true;                           // :241-242
+                }
+            }
+        }
+        {
+            const unsigned long long hm = __ballot(handoff);
+            if (lane == 0) {
+                s.hand_bits[(size_t)shard * s.hand_words + (base >> 6)] = hm;
+                if (hm != 0ull) atomicAdd(s.hand_count, (unsigned)__popcll(hm));
+            }
+        }
+        if (active && !handoff) {
+            uint8_t *res = s.change + pix * (int64_t)k;
+            if (s.bits != nullptr)
+                store_change_row(res, k, (unsigned long long)cmask);    // nobody else writes this row
+            else
+                for (int u = 1; u < k; ++u)                // the row was zero-filled upstream
+                    if ((cmask >> u) & 1u) res[u] = 1;
+        }
+    }
+}
+
 // =========================================================================================
 // host side
 // =========================================================================================
@@ -2367,8 +2651,8 @@ std::vector<OmniTabEntry> get_table_impl(int k, uint32_t n_looks, double alpha, 
 // recommended size holds the series of 1/8 of the pixels (a listed pixel beyond the capacity is
 // gathered from the planes by pass B instead: slower, never wrong).
 struct OmniWorkspace {
-    size_t off_count, off_tab, off_idx, off_dense, off_bits, off_dump, min_total, recommended;
-    uint32_t segd;
+    size_t off_count, off_tab, off_idx, off_dense, off_bits, off_hand, off_dump, min_total, recommended;
+    uint32_t segd, hand_words;
 };
 
 constexpr int kRetainMaxF32 = 48, kRetainMaxF64 = 24;
@@ -2404,7 +2688,10 @@ static OmniWorkspace omni_layout(int64_t npix, int64_t ny, int64_t k, size_t ele
     // listed-pixel map: one bit per pixel (OmniGlobalArgs::bits)
     w.off_bits = w.off_dense + align256((size_t)(w.segd + kMaxSlabs * kSlabSegdExtra) * kShards *
                                         sizeof(uint32_t));
-    w.off_dump = w.off_bits + align256((size_t)ceil_div(npix, 64) * sizeof(unsigned long long) + 8);
+    w.off_hand = w.off_bits + align256((size_t)ceil_div(npix, 64) * sizeof(unsigned long long) + 8);
+    // hand-over marks of the register form of pass B: one bit per list entry (OmniSearchArgs::hand_bits)
+    w.hand_words = (omni_seg(npix, ny) + kMaxSlabs * kSlabSegExtra) / 64 + kMaxSlabs + 1;
+    w.off_dump = w.off_hand + align256((size_t)w.hand_words * kShards * sizeof(unsigned long long));
     w.min_total = w.off_dump;
     const size_t per = (size_t)k * 4 * elem;
     size_t cap = ((size_t)npix / 8 / kShards + 63) & ~(size_t)63;   // per shard
@@ -2660,6 +2947,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         return e ? atoi(e) != 0 : false;
     }();
     unsigned long long *const bits_ws = reinterpret_cast<unsigned long long *>(ws + w.off_bits);
+    unsigned long long *const hand_ws = reinterpret_cast<unsigned long long *>(ws + w.off_hand);
     const bool bits_ok = fill_in_b_env && retain && flat && k >= 2 && k <= 64;
     g.bits = bits_ok ? bits_ws : nullptr;
     bool b_fill = false;          // did a pass A that leaves the fill to pass B feed this call's lists?
@@ -2747,7 +3035,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     };
     auto launch_search = [&](hipStream_t sq, const uint32_t *count, const uint32_t *idx, const T *dump,
                              uint32_t seg, uint32_t dump_cap, int64_t npix_listed,
-                             const unsigned long long *bits, int gate_mode_b) -> int {
+                             const unsigned long long *bits, int gate_mode_b,
+                             unsigned long long *hand, uint32_t hand_words) -> int {
         OmniSearchArgs<T> s;
         s.c11 = g.c11;
         s.c12r = g.c12r;
@@ -2776,6 +3065,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         s.gate = g.gate;
         s.gate_n = g.gate_n;
         s.gate_mode = gate_mode_b;
+        s.hand_bits = nullptr;
+        s.hand_words = hand_words;
+        s.hand_count = const_cast<uint32_t *>(count) + 3;    // word 3 of the lists' first counter line
         const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);      // screen constants
         const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T) + scr_bytes;
         // the LDS image of 64 series may take up to 150 KB of the CU's 160 KB: for long series that is
@@ -2790,17 +3082,46 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         if (per_shard > 64) per_shard = 64;
         if (per_shard < 1) per_shard = 1;
         const int64_t sblocks = per_shard * kShards;
-        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
         static const int mode_env = [] {
-            const char *e = getenv("ND_AMD_SEARCH_MODE");
+            const char *e = getenv("ND_AMD_SEARCH_MODE");     // 0 LDS image, 1 from memory, 2 registers
             return e ? atoi(e) : -1;
         }();
-        const int mode = mode_env >= 0 ? mode_env : (use_lds ? 0 : 1);
+        // The register form serves the series lengths of dense_search, as long as the screen can
+        // decide tests at all (it cannot where omega2 leaves [0, 1], e.g. single-look data: every
+        // test would cost a second walk of its segment) and pass B does not also fill the map.
+        bool regs_ok = k >= 2 && k <= (sizeof(T) == 4 ? 32 : 16) && bits == nullptr;
+        DenseScreen scr;
+        if (regs_ok) {
+            scr = make_dense_screen<T>(htab, (int)k, n_looks);
+            for (int j = 2; j <= (int)k; ++j)
+                if (!(scr.e[j].a > -INFINITY) && !(scr.e[j].b < INFINITY)) regs_ok = false;
+        }
+        const bool regs_form = regs_ok && (mode_env < 0 || mode_env == 2);
+        if (regs_form) {
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+            s.hand_bits = hand;
+            const dim3 gr((unsigned)sblocks), bl(64);
+            if (k <= 8)
+                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<T, 8>), gr, bl, 0, sq, s, scr);
+            else if (k <= 16)
+                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<T, 16>), gr, bl, 0, sq, s, scr);
+            else if (sizeof(T) == 4 && k <= 24)
+                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<float, 24>), gr, bl, 0, sq,
+                                   reinterpret_cast<const OmniSearchArgs<float> &>(s), scr);
+            else if (sizeof(T) == 4)
+                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<float, 32>), gr, bl, 0, sq,
+                                   reinterpret_cast<const OmniSearchArgs<float> &>(s), scr);
+        }
+        // the exact form: every listed pixel, or (behind the register form) the marked ones
+        KernelTimer timer(regs_form ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+        const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : (use_lds ? 0 : 1);
+        // (behind the register form there is usually nothing left: a quarter of the blocks)
+        const int64_t xblocks = regs_form ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
         if (mode == 0 && use_lds)
-            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0>), dim3((unsigned)sblocks), dim3(64),
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0>), dim3((unsigned)xblocks), dim3(64),
                                lds_bytes, sq, s);
         else
-            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 1>), dim3((unsigned)sblocks), dim3(64),
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 1>), dim3((unsigned)xblocks), dim3(64),
                                0, sq, s);
         return ND_AMD_OK;
     };
@@ -3069,7 +3390,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             if (g.dense_min <= 64)
                 launch_dense(sq, count_s, idx_s, dense_s, dump_s, seg_s, segd_s, cap_s, nb * kRetainThreads);
             {
-                const int rc = launch_search(sq, count_s, idx_s, dump_s, seg_s, cap_s, nb * kRetainThreads, nullptr, 0);
+                const uint32_t hw_s = seg_s / 64 + 1;
+                const int rc = launch_search(sq, count_s, idx_s, dump_s, seg_s, cap_s, nb * kRetainThreads, nullptr, 0,
+                                             hand_ws + (size_t)si * kShards * hw_s, hw_s);
                 if (rc != ND_AMD_OK) return rc;
             }
             ND_HIP_CHECK(hipGetLastError());
@@ -3098,7 +3421,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // ---- pass B ----
     {
         const int rc = launch_search(stream, flag_count, flag_idx, g.dump, g.seg, g.dump_cap, npix,
-                                     b_fill ? g.bits : nullptr, b_gate_mode);
+                                     b_fill ? g.bits : nullptr, b_gate_mode, hand_ws, g.seg / 64 + 1);
         if (rc != ND_AMD_OK) return rc;
     }
     ND_HIP_CHECK(hipGetLastError());
