@@ -40,9 +40,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes of pass A from the rocprofv3 PMC passes of an earlier run of the same command
-# (2 x FETCH_SIZE + WRITE_SIZE); reported with its source, never as a live measurement
-PROFILED_TRAFFIC = {('omnibus', 24, 4096, 4096, 0.99): (6.9762e9, 'profiles/r02_final_omnibus_rocprof.txt')}
+# HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) of every
+# workload's kernels, from separate rocprofv3 --pmc passes over `bench.py --traffic-run KEY`
+# (tools/collect_traffic.sh writes the file, with the commit it was taken at).  Reported with its
+# source; a workload or kernel the file does not hold gets traffic = null.
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
+
+
+def profiled_traffic(key, hint):
+    """-> (bytes per launch, source) of the kernel of workload `key` whose symbol contains `hint`
+    (the largest one if several do), or (None, None)."""
+    try:
+        tab = json.load(open(TRAFFIC_FILE))
+    except Exception:
+        return None, None
+    rows = [r for r in tab.get('workloads', {}).get(key, []) if hint in r['kernel']]
+    if not rows:
+        return None, None
+    r = max(rows, key=lambda r: r['traffic_bytes'])
+    return r['traffic_bytes'], ('%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py '
+                                '--traffic-run %s` at commit %s; kernel %s)'
+                                % (os.path.relpath(TRAFFIC_FILE, ROOT), key, tab.get('commit', '?'),
+                                   r['kernel'][:60]))
 
 DEFAULTS = {'omnibus': (24, 4096, 4096), 'c3': (48, 1024, 8192), 'pipeline': (24, 2048, 16384)}
 # tutorial parameters (examples/tutorial_s1.ipynb cells 11, 15; NLMeansFilter defaults sigma=h=f=1)
@@ -70,6 +89,9 @@ def parse():
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch of the dominant kernel from a separate '
                          'rocprofv3 --pmc pass, copied into roofline.traffic')
+    ap.add_argument('--traffic-run', default=None, metavar='KEY',
+                    help='run only workload KEY (headline or one of the extras) for a few steps, '
+                         'no timing events, no checks: the command rocprofv3 --pmc is pointed at')
     a = ap.parse_args()
     dk, dy, dx = DEFAULTS[a.workload]
     a.k, a.ny, a.nx = a.k or dk, a.ny or dy, a.nx or dx
@@ -106,20 +128,39 @@ def _kernel_avgs(kt):
     return {n: sum(v) / len(v) for n, v in by.items()}
 
 
-def timed(fn, steps, warmup, barrier, launches_per_step=8):
+TRAFFIC_MODE = False       # --traffic-run: plain loops, no events, no checks
+
+
+def timed(fn, steps, warmup, barrier, launches_per_step=8, only=None, per_step=None):
     """W untimed calls, then EXACTLY `steps` calls between two barriers.  -> (seconds, kernel
-    averages from the library's HIP events on the launch stream, last result)."""
+    averages from the library's HIP events on the launch stream, last result).
+    only: names of the kernels to time (an event pair costs a few microseconds of stream time; the
+    headline times its dominant kernel only).  per_step: a list that receives the duration of
+    every step in ms (one torch event per step boundary on the launch stream)."""
     from nd_amd import _lib
+    if TRAFFIC_MODE:
+        out = None
+        for _ in range(max(1, min(steps, 3))):
+            out = fn()
+        barrier()
+        return 1.0, {}, out
+    import torch
     _lib.timing_enable(launches_per_step * (steps + warmup) + 16)
+    _lib.timing_select(only)
     out = None
     for _ in range(warmup):
         out = fn()
     barrier()
     _lib.timing_collect()          # drop the warm-up launches; the events themselves are reused
     _lib.timing_dropped()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if ev:
+        ev[0].record()
+    for i in range(steps):
         out = fn()
+        if ev:
+            ev[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     kt = _lib.timing_collect()
@@ -127,6 +168,8 @@ def timed(fn, steps, warmup, barrier, launches_per_step=8):
     _lib.timing_enable(0)
     if dropped:
         raise RuntimeError('%d kernel launches were not timed: timing ring too small' % dropped)
+    if ev:
+        per_step.extend(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
     return dt, _kernel_avgs(kt), out
 
 
@@ -317,7 +360,12 @@ def _free():
     torch.cuda.empty_cache()
 
 
-def extras(main, barrier, dev):
+EXTRA_KEYS = ('omnibus_a0.01', 'omnibus_a0.0001', 'pm_a0.99', 'pm_a0.01', 'c3_a0.99', 'c3_a0.01',
+              'boxcar3', 'boxcar5', 'gauss1', 'nlm_pm0', 'nlm_pm1', 'pipeline')
+
+
+def extras(main, barrier, dev, only=None):
+    """The other kernels of the path.  only = one of EXTRA_KEYS: just that workload (--traffic-run)."""
     import numpy as np
     import torch
     from nd_amd import kernels
@@ -325,169 +373,209 @@ def extras(main, barrier, dev):
     from oracle import oracle as O
     out = []
     cores = _usable_cores()
+    quick = TRAFFIC_MODE
 
-    def entry(workload, dt, steps, npix, km, roof, match, **more):
-        e = {'workload': workload, 'ms': dt / steps * 1e3, 'Mpx_per_s': npix * steps / dt / 1e6,
-             'kernels_ms': km, 'roofline': roof, 'matches_oracle_on_sample': match}
+    def want(*keys):
+        return only is None or only in keys
+
+    def roof(key, hint, dom, km, alg_bytes, note=None):
+        traffic, source = profiled_traffic(key, hint)
+        return roofline(dom, km[dom], alg_bytes, note=note, traffic=traffic, traffic_source=source)
+
+    def entry(key, workload, dt, steps, npix, km, roof_, match, **more):
+        e = {'key': key, 'workload': workload, 'ms': dt / steps * 1e3, 'Mpx_per_s': npix * steps / dt / 1e6,
+             'kernels_ms': km, 'roofline': roof_, 'matches_oracle_on_sample': match}
         e.update(more)
         out.append(e)
 
-    # -- OmnibusTest at the thresholds users actually pass: the reference default and the tutorial's
     a = main.a
+    # -- OmnibusTest at the thresholds users actually pass: the reference default and the tutorial's
     for alpha in (0.01, 1e-4):
+        key = 'omnibus_a%g' % alpha
+        if not want(key):
+            continue
         fn = lambda: kernels.change_detection(*main.stack, alpha=alpha, n=a.looks)       # noqa: E731
         dt, km, ch = timed(fn, 10, 10, barrier)
+        if quick:
+            continue
         res = checks.omnibus_sample(main.stack, ch, alpha, a.looks, nsample=20000, seed=8)
         dom = max(km, key=km.get)
-        entry('OmnibusTest C2 %dt x %d x %d f32, alpha=%g (dense regime: %.3f of pixels change)'
+        entry(key, 'OmnibusTest C2 %dt x %d x %d f32, alpha=%g (dense regime: %.3f of pixels change)'
               % (main.k, main.rows, main.nx, alpha, res['flagged_fraction']), dt, 10, main.npix, km,
-              roofline(dom, km[dom], main.alg_bytes,
-                       note='search fused into the streaming pass over the planes (VALU-issue bound: '
-                            '~4.1 k vector instructions per 64 pixels); bytes = planes read once + '
-                            'change map written once'),
+              roof(key, 'stream_kernel', dom, km, main.alg_bytes,
+                   note='search fused into the streaming pass over the planes (VALU-issue bound); '
+                        'bytes = planes read once + change map written once'),
               res['bad'] == 0, sample=res)
-    del ch
+        del ch
 
     # -- the same test on data in the reference's own layout ((y, x, time), C12 interleaved complex):
     #    what OmnibusTest.apply(ds) receives from a reference-layout dataset
-    yxt = [main.stack[v].permute(1, 2, 0).contiguous() for v in range(4)]
-    c12 = torch.complex(yxt[1], yxt[2])
-    pmv = (yxt[0], c12.real, c12.imag, yxt[3])
-    del yxt
-    for alpha in (0.99, 0.01):
-        fn = lambda: kernels.change_detection_pixel_major(*pmv, alpha=alpha, n=a.looks)      # noqa: E731
-        dt, km, ch = timed(fn, 10, 10, barrier)
-        ref = kernels.change_detection(*main.stack, alpha=alpha, n=a.looks)
-        same = bool(torch.equal(ch, ref))
-        res = checks.omnibus_sample(main.stack, ch, alpha, a.looks, nsample=20000, seed=9)
-        dom = max(km, key=km.get)
-        entry('OmnibusTest C2 %dt x %d x %d f32 in the reference layout (y, x, time), C12 complex64, '
-              'alpha=%g' % (main.k, main.rows, main.nx, alpha), dt, 10, main.npix, km,
-              roofline(dom, km[dom], main.alg_bytes,
+    if want('pm_a0.99', 'pm_a0.01'):
+        yxt = [main.stack[v].permute(1, 2, 0).contiguous() for v in range(4)]
+        c12 = torch.complex(yxt[1], yxt[2])
+        pmv = (yxt[0], c12.real, c12.imag, yxt[3])
+        del yxt
+        for alpha in (0.99, 0.01):
+            key = 'pm_a%g' % alpha
+            if not want(key):
+                continue
+            fn = lambda: kernels.change_detection_pixel_major(*pmv, alpha=alpha, n=a.looks)      # noqa: E731
+            dt, km, ch = timed(fn, 10, 10, barrier)
+            if quick:
+                continue
+            ref = kernels.change_detection(*main.stack, alpha=alpha, n=a.looks)
+            same = bool(torch.equal(ch, ref))
+            res = checks.omnibus_sample(main.stack, ch, alpha, a.looks, nsample=20000, seed=9)
+            dom = max(km, key=km.get)
+            entry(key, 'OmnibusTest C2 %dt x %d x %d f32 in the reference layout (y, x, time), C12 complex64, '
+                  'alpha=%g' % (main.k, main.rows, main.nx, alpha), dt, 10, main.npix, km,
+                  roof(key, 'pm_dma' if alpha > 0.5 else 'stream_kernel', dom, km, main.alg_bytes,
                        note='LDS-DMA staging of pixel-major spans (global_load_lds_dwordx4)' if alpha > 0.5 else
                        'streaming search, every lane reading its own pixel-major series from memory '
                        'in 16-byte pieces (no LDS images)'),
-              res['bad'] == 0 and same, sample=res, equal_to_planar_map=same)
-    del ch, ref, c12, pmv
-    _free()
+                  res['bad'] == 0 and same, sample=res, equal_to_planar_map=same)
+            del ch, ref
+        del c12, pmv
+        _free()
 
     # -- full-pol C3, config 4's single-GPU share
     class A:
         pass
-    a3 = A()
-    a3.__dict__.update(a.__dict__)
-    a3.k, a3.ny, a3.nx, a3.alpha, a3.scaling = 48, 1024, 8192, 0.99, 'weak'
-    w = OmnibusC3(a3, 0, 1, dev)
-    dt, km, ch = timed(w.step, 10, 10, barrier)
-    res = w.check(ch)
-    entry(w.describe(), dt, 10, w.npix, km, roofline(w.dom, km[w.dom], w.alg_bytes), res['bad'] == 0,
-          sample=res)
-    # the same stack at the reference's default threshold: the full-pol streaming search
-    a3.alpha = 0.01
-    dt, km, ch = timed(w.step, 10, 10, barrier)
-    res = w.check(ch)
-    dom = max(km, key=km.get)
-    entry(w.describe(), dt, 10, w.npix, km, roofline(dom, km[dom], w.alg_bytes,
-          note='search fused into the streaming pass (omnibus_c3_stream_kernel)'), res['bad'] == 0, sample=res)
-    del w, ch
-    _free()
+    if want('c3_a0.99', 'c3_a0.01'):
+        a3 = A()
+        a3.__dict__.update(a.__dict__)
+        a3.k, a3.ny, a3.nx, a3.alpha, a3.scaling = 48, 1024, 8192, 0.99, 'weak'
+        w = OmnibusC3(a3, 0, 1, dev)
+        for alpha in (0.99, 0.01):      # the benchmark's threshold, then the reference's default
+            key = 'c3_a%g' % alpha
+            if not want(key):
+                continue
+            a3.alpha = alpha
+            dt, km, ch = timed(w.step, 10, 10, barrier)
+            if quick:
+                continue
+            res = w.check(ch)
+            dom = w.dom if alpha > 0.5 else max(km, key=km.get)
+            entry(key, w.describe(), dt, 10, w.npix, km,
+                  roof(key, 'omnibus_c3_global' if alpha > 0.5 else 'omnibus_c3_stream', dom, km, w.alg_bytes,
+                       note=None if alpha > 0.5 else 'search fused into the streaming pass (omnibus_c3_stream_kernel)'),
+                  res['bad'] == 0, sample=res)
+            del ch
+        del w
+        _free()
 
-    # -- boxcar 3x3 (the multilooking step in front of the test), 24t x 4096 x 4096
     g = torch.Generator(device=dev).manual_seed(7)
-    x = torch.rand((24, 4096, 4096), generator=g, device=dev) + 0.5
-    y = torch.empty_like(x)
-    for wdt in (3, 5):
-        kern = np.ones((1, wdt, wdt)) / float(wdt * wdt)
-        # (sub-millisecond kernels behind host-side checks: the device needs ~10 ms of work to be
-        # back at its sustained clocks -- 40 launches back to back are flat from the second on,
-        # tools/exp_launch_times.py)
-        dt, km, _ = timed(lambda: kernels.convolve(x, kern, out=y), 20, 20, barrier)
-        res = checks.convolve_bands(x, y, kern[0], [(0, 40), (2030, 2070), (4056, 4096)], [0, 23])
-        dom = max(km, key=km.get)
-        e = dict(sample=res)
-        if wdt == 5:
-            crop = np.ascontiguousarray(x[:, :2048, :2048].cpu().numpy())
-            t0 = time.perf_counter()
-            O.convolve_reflect_mt(crop, kern, njobs=cores)
-            dtc = time.perf_counter() - t0
-            e['cpu_baseline'] = {'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
-                                 'kind': 'port', 'sample': '24 x 2048 x 2048 crop, %.2f s' % dtc}
-        entry('BoxcarFilter %dx%d on 24t x 4096 x 4096 f32 (scipy.ndimage.convolve arithmetic)'
-              % (wdt, wdt), dt, 20, x.numel(), km, roofline(dom, km[dom], 8 * x.numel()),
-              res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
-    # -- GaussianFilter(dims=('y', 'x'), sigma=1): both passes in one kernel
-    import scipy.ndimage as ndi
-    # (warm-up launches first: the host-side baseline just above leaves the GPU at idle clocks)
-    dt, km, _ = timed(lambda: kernels.gaussian_filter(x, (0, 1.0, 1.0), out=y), 20, 20, barrier)
-    res = checks.gaussian_bands(x, y, 1.0, [(0, 40), (2030, 2070), (4056, 4096)], [0, 23])
-    dom = max(km, key=km.get)
-    crop = np.ascontiguousarray(x[:4, :2048, :2048].cpu().numpy())
-    t0 = time.perf_counter()
-    ndi.gaussian_filter(crop, (0, 1.0, 1.0))
-    dtc = time.perf_counter() - t0
-    entry('GaussianFilter sigma=1 (9 taps along y, then along x) on 24t x 4096 x 4096 f32 '
-          '(scipy.ndimage.gaussian_filter arithmetic, float32 intermediate)', dt, 20, x.numel(), km,
-          roofline(dom, km[dom], 8 * x.numel(),
-                   note='one read and one write of the array for both passes'),
-          res['bad'] == 0, unit_note='Mpx_per_s counts px.t', sample=res,
-          cpu_baseline={'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': 1,
-                        'kind': 'reference', 'sample': 'scipy.ndimage.gaussian_filter (the reference\'s '
-                        'own arithmetic for this filter) on a 4 x 2048 x 2048 crop, %.2f s' % dtc})
-    del x, y
-    _free()
+    # -- boxcar 3x3 / 5x5 (the multilooking step in front of the test) and the fused Gaussian, 24t x 4096 x 4096
+    if want('boxcar3', 'boxcar5', 'gauss1'):
+        x = torch.rand((24, 4096, 4096), generator=g, device=dev) + 0.5
+        y = torch.empty_like(x)
+        for wdt in (3, 5):
+            key = 'boxcar%d' % wdt
+            if not want(key):
+                continue
+            kern = np.ones((1, wdt, wdt)) / float(wdt * wdt)
+            # (sub-millisecond kernels behind host-side checks: the device needs ~10 ms of work to be
+            # back at its sustained clocks -- 40 launches back to back are flat from the second on,
+            # tools/exp_launch_times.py)
+            dt, km, _ = timed(lambda: kernels.convolve(x, kern, out=y), 20, 20, barrier)
+            if quick:
+                continue
+            res = checks.convolve_bands(x, y, kern[0], [(0, 40), (2030, 2070), (4056, 4096)], [0, 23])
+            dom = max(km, key=km.get)
+            e = dict(sample=res)
+            if wdt == 5:
+                crop = np.ascontiguousarray(x[:, :2048, :2048].cpu().numpy())
+                t0 = time.perf_counter()
+                O.convolve_reflect_mt(crop, kern, njobs=cores)
+                dtc = time.perf_counter() - t0
+                e['cpu_baseline'] = {'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
+                                     'kind': 'port', 'sample': '24 x 2048 x 2048 crop, %.2f s' % dtc}
+            entry(key, 'BoxcarFilter %dx%d on 24t x 4096 x 4096 f32 (scipy.ndimage.convolve arithmetic)'
+                  % (wdt, wdt), dt, 20, x.numel(), km, roof(key, 'correlate', dom, km, 8 * x.numel()),
+                  res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
+        # -- GaussianFilter(dims=('y', 'x'), sigma=1): both passes in one kernel
+        if want('gauss1'):
+            import scipy.ndimage as ndi
+            # (warm-up launches first: the host-side baseline just above leaves the GPU at idle clocks)
+            dt, km, _ = timed(lambda: kernels.gaussian_filter(x, (0, 1.0, 1.0), out=y), 20, 20, barrier)
+            if not quick:
+                res = checks.gaussian_bands(x, y, 1.0, [(0, 40), (2030, 2070), (4056, 4096)], [0, 23])
+                dom = max(km, key=km.get)
+                crop = np.ascontiguousarray(x[:4, :2048, :2048].cpu().numpy())
+                t0 = time.perf_counter()
+                ndi.gaussian_filter(crop, (0, 1.0, 1.0))
+                dtc = time.perf_counter() - t0
+                entry('gauss1', 'GaussianFilter sigma=1 (9 taps along y, then along x) on 24t x 4096 x 4096 f32 '
+                      '(scipy.ndimage.gaussian_filter arithmetic, float32 intermediate)', dt, 20, x.numel(), km,
+                      roof('gauss1', 'correlate1d', dom, km, 8 * x.numel(),
+                           note='one read and one write of the array for both passes'),
+                      res['bad'] == 0, unit_note='Mpx_per_s counts px.t', sample=res,
+                      cpu_baseline={'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': 1,
+                                    'kind': 'reference', 'sample': 'scipy.ndimage.gaussian_filter (the reference\'s '
+                                    'own arithmetic for this filter) on a 4 x 2048 x 2048 crop, %.2f s' % dtc})
+        del x, y
+        _free()
 
     # -- non-local means, BASELINE config 3: 7x7 patch / 21x21 search, 12t x 4096 x 4096
-    k, ny, nx = 12, 4096, 4096
-    x = torch.empty((1, k, ny, nx), device=dev)
-    for t in range(k):
-        u = torch.rand((4, ny, nx), generator=g, device=dev)
-        # Gamma(4, 0.25).  torch.rand draws from [0, 1): a zero (one draw in 2^24) would put an
-        # infinity into a variate that has none, and every pixel within r + f of it would take the
-        # kernel's exact per-pixel path
-        x[0, t] = -0.25 * torch.log(u.clamp_min_(2.0 ** -25)).sum(dim=0)
-    y = torch.empty_like(x)
-    r, f = (0, 10, 10), (0, 3, 3)
-    for pm in (0, 1):
-        steps = 5 if pm == 0 else 2
-        fn = lambda: kernels.pixelwise_nlmeans_3d(x.permute(2, 3, 1, 0), y.permute(2, 3, 1, 0),    # noqa: E731
-                                                  (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, patch_mode=pm)
-        dt, km, _ = timed(fn, steps, 1, barrier)
-        res = checks.nlmeans_crops(x, y, r, f, 0.5, 0.5, -1, pm, [(2040, 3000), (0, 0)], size=(6, 48))
-        dom = max(km, key=km.get)
-        nq = 21 * 21 - 1
-        flop = x.numel() * nq * (49 * 3 + 8) if pm else x.numel() * nq * 2
-        e = dict(sample=res, TFLOPs_naive_formula=flop / (dt / steps) / 1e12)
-        if pm == 1:
-            crop = np.ascontiguousarray(x[:, :1, :640, :640].permute(2, 3, 1, 0).cpu().numpy())
-            o = np.empty_like(crop)
-            t0 = time.perf_counter()
-            O.pixelwise_nlmeans_3d(crop, o, (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, njobs=cores, patch_mode=1)
-            dtc = time.perf_counter() - t0
-            e['cpu_baseline'] = {'value': 640 * 640 / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
-                                 'kind': 'port', 'sample': '640 x 640 crop of one date, %.2f s' % dtc}
-        entry('NLMeansFilter 7x7 patch / 21x21 search on 12t x 4096 x 4096 f32, patch distances %s'
-              % ('as compiled (reference: window mean)' if pm == 0 else 'signed (true patch distances)'),
-              dt, steps, x.numel(), km,
-              roofline(dom, km[dom], 8 * x.numel(),
+    if want('nlm_pm0', 'nlm_pm1'):
+        k, ny, nx = 12, 4096, 4096
+        x = torch.empty((1, k, ny, nx), device=dev)
+        for t in range(k):
+            u = torch.rand((4, ny, nx), generator=g, device=dev)
+            # Gamma(4, 0.25).  torch.rand draws from [0, 1): a zero (one draw in 2^24) would put an
+            # infinity into a variate that has none, and every pixel within r + f of it would take the
+            # kernel's exact per-pixel path
+            x[0, t] = -0.25 * torch.log(u.clamp_min_(2.0 ** -25)).sum(dim=0)
+        y = torch.empty_like(x)
+        r, f = (0, 10, 10), (0, 3, 3)
+        for pm in (0, 1):
+            key = 'nlm_pm%d' % pm
+            if not want(key):
+                continue
+            steps = 5 if pm == 0 else 2
+            fn = lambda: kernels.pixelwise_nlmeans_3d(x.permute(2, 3, 1, 0), y.permute(2, 3, 1, 0),    # noqa: E731
+                                                      (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, patch_mode=pm)
+            dt, km, _ = timed(fn, steps, 1, barrier)
+            if quick:
+                continue
+            res = checks.nlmeans_crops(x, y, r, f, 0.5, 0.5, -1, pm, [(2040, 3000), (0, 0)], size=(6, 48))
+            dom = max(km, key=km.get)
+            nq = 21 * 21 - 1
+            flop = x.numel() * nq * (49 * 3 + 8) if pm else x.numel() * nq * 2
+            e = dict(sample=res, TFLOPs_naive_formula=flop / (dt / steps) / 1e12)
+            if pm == 1:
+                crop = np.ascontiguousarray(x[:, :1, :640, :640].permute(2, 3, 1, 0).cpu().numpy())
+                o = np.empty_like(crop)
+                t0 = time.perf_counter()
+                O.pixelwise_nlmeans_3d(crop, o, (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, njobs=cores, patch_mode=1)
+                dtc = time.perf_counter() - t0
+                e['cpu_baseline'] = {'value': 640 * 640 / dtc / 1e6, 'unit': 'M px.t/s', 'cores': cores,
+                                     'kind': 'port', 'sample': '640 x 640 crop of one date, %.2f s' % dtc}
+            entry(key, 'NLMeansFilter 7x7 patch / 21x21 search on 12t x 4096 x 4096 f32, patch distances %s'
+                  % ('as compiled (reference: window mean)' if pm == 0 else 'signed (true patch distances)'),
+                  dt, steps, x.numel(), km,
+                  roof(key, 'nlmeans', dom, km, 8 * x.numel(),
                        note='VALU/LDS-bound: HBM traffic is 8 B per px.t, the fraction of HBM peak is '
                             'reported for completeness'),
-              res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
-    del x, y
-    _free()
+                  res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
+        del x, y
+        _free()
 
     # -- the tutorial pipeline, config 5's single-GPU share
-    ap = A()
-    ap.__dict__.update(a.__dict__)
-    ap.k, ap.ny, ap.nx, ap.alpha, ap.scaling, ap.patch_mode = 24, 2048, 16384, TUT['alpha'], 'weak', 0
-    w = Pipeline(ap, 0, 1, dev)
-    # two warm-up steps: the filter's output alternates between two 12.9 GB buffers, and the first
-    # allocation of each costs tens of milliseconds of hipMalloc
-    dt, km, ch = timed(w.step, 3, 2, barrier)
-    res = w.check(ch)
-    entry(w.describe(), dt, 3, w.npix, km, roofline(w.dom, km[w.dom], w.alg_bytes),
-          res['bad'] == 0 and res['change_bad'] == 0, sample=res)
-    del w, ch
-    _free()
+    if want('pipeline'):
+        ap = A()
+        ap.__dict__.update(a.__dict__)
+        ap.k, ap.ny, ap.nx, ap.alpha, ap.scaling, ap.patch_mode = 24, 2048, 16384, TUT['alpha'], 'weak', 0
+        w = Pipeline(ap, 0, 1, dev)
+        # two warm-up steps: the filter's output alternates between two 12.9 GB buffers, and the first
+        # allocation of each costs tens of milliseconds of hipMalloc
+        dt, km, ch = timed(w.step, 3, 2, barrier)
+        if not quick:
+            res = w.check(ch)
+            entry('pipeline', w.describe(), dt, 3, w.npix, km, roof('pipeline', 'nlmeans', w.dom, km, w.alg_bytes),
+                  res['bad'] == 0 and res['change_bad'] == 0, sample=res)
+        del w, ch
+        _free()
     return out
 
 
@@ -530,7 +618,25 @@ def main():
 
     w = WORKLOADS[args.workload](args, rank, world, dev)
     torch.cuda.synchronize()
-    dt, avg, out = timed(w.step, args.steps, args.warmup, barrier)
+    if args.traffic_run is not None:
+        # the command the rocprofv3 --pmc passes of tools/collect_traffic.sh are pointed at
+        global TRAFFIC_MODE
+        TRAFFIC_MODE = True
+        if args.traffic_run == 'headline':
+            timed(w.step, 3, 0, barrier)
+        else:
+            extras(w, barrier, dev, only=args.traffic_run)
+        print(json.dumps({'traffic_run': args.traffic_run}))
+        return
+    # The timed region: every step is the whole call; inside it only the dominant kernel carries
+    # the library's event pair (each pair costs a few microseconds of stream time, and the
+    # roofline needs that kernel's duration measured live here), plus one torch event per step
+    # boundary for the spread.  The other kernels' durations come from a second, untimed loop.
+    per_step = []
+    dt, avg, out = timed(w.step, args.steps, args.warmup, barrier, only=[w.dom], per_step=per_step)
+    _, avg_all, _ = timed(w.step, max(3, min(args.steps, 10)), 1, barrier)
+    for name, ms in avg_all.items():
+        avg.setdefault(name, ms)
 
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
@@ -545,16 +651,22 @@ def main():
     flagged = float((out.sum(dim=2) > 0).float().mean().item())
 
     if rank == 0:
-        key = (w.name, w.k, args.ny, w.nx, args.alpha)
-        traffic, source = PROFILED_TRAFFIC.get(key, (None, None)) if world == 1 else (None, None)
+        is_default = (w.name == 'omnibus' and (w.k, args.ny, w.nx, args.alpha, args.looks, args.change_frac)
+                      == (24, 4096, 4096, 0.99, 9, 0.01))
+        traffic, source = (profiled_traffic('headline', 'omnibus_c2_retain')
+                           if world == 1 and is_default else (None, None))
         if args.traffic_bytes is not None:
             traffic, source = args.traffic_bytes, '--traffic-bytes'
         # the kernel the roofline is quoted on: the workload's pass A, or (low thresholds, where the
         # search is fused into the one streaming kernel) whichever kernel takes the time
         dom_k = w.dom if w.dom in avg else max(avg, key=avg.get)
+        ps = sorted(per_step)
         res = {
             'metric': w.metric(), 'value': value, 'unit': 'Mpixels/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'step_ms': {'min': ps[0], 'median': ps[len(ps) // 2], 'max': ps[-1],
+                        'note': 'per-step durations from one event per step boundary on the launch '
+                                'stream, this rank'} if ps else None,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic' if not rehearse else
             'synthetic; REHEARSAL: ranks share devices over gloo, not a measurement',
@@ -569,13 +681,25 @@ def main():
                                'one point-to-point halo exchange per step'),
             },
             'kernels_ms': avg,
-            'roofline': roofline(dom_k, avg[dom_k], w.alg_bytes, traffic=traffic,
-                                 traffic_source=source,
-                                 note='algorithmic bytes = planes read once + change map written once'
-                                 if w.name != 'pipeline' else 'algorithmic bytes = filter input + output'),
+            'kernels_ms_note': '%s: events inside the timed region; the others: a second loop of the '
+                               'same step' % dom_k,
         }
+        if w.name == 'omnibus':
+            # SURVEY 8(d) / BASELINE.md basis: the planes read once, k * 4 * sizeof(T) bytes per pixel
+            # (384 B at k = 24 float32); the same kernel also zero-fills the change map (k bytes per
+            # pixel more, 408 B in all): that rate is the secondary figure.
+            res['roofline'] = roofline(dom_k, avg[dom_k], w.read_bytes, traffic=traffic, traffic_source=source,
+                                       note='algorithmic bytes = the four planes read once (%d B per pixel); '
+                                            'achieved_read_write adds the change map the same kernel '
+                                            'zero-fills (%d B per pixel in all)'
+                                       % (w.read_bytes // w.npix, w.alg_bytes // w.npix))
+            res['roofline']['achieved_read_write'] = w.alg_bytes / (avg[dom_k] * 1e-3) / 1e9
+            res['roofline']['frac_read_write'] = res['roofline']['achieved_read_write'] / HBM_PEAK_GBS
+        else:
+            res['roofline'] = roofline(dom_k, avg[dom_k], w.alg_bytes, traffic=traffic, traffic_source=source,
+                                       note='algorithmic bytes = planes read once + change map written once'
+                                       if w.name != 'pipeline' else 'algorithmic bytes = filter input + output')
         if world == 1 and w.name == 'omnibus':
-            res['roofline']['achieved_read_only'] = w.read_bytes / (avg[dom_k] * 1e-3) / 1e9
             if args.cpu_rows > 0:
                 res['cpu_baseline'] = cpu_baseline_omnibus(w, out)
             if not args.no_extra:

@@ -287,6 +287,10 @@ int nd_amd_relayout_pixel_major(const void *in, void *out, int dtype,
 int nd_amd_timing_enable(int capacity);
 int nd_amd_timing_collect(int32_t *kernel_ids, float *ms, int max_n, int *n_out);
 int nd_amd_timing_dropped(void);
+/* Restrict the timing to the kernel ids whose bit is set in `id_mask` (bit i = id i; 0 = all, the
+ * default after every enable).  An event pair costs a few microseconds of stream time: a benchmark
+ * that wants the duration of its dominant kernel inside the timed region times only that one. */
+int nd_amd_timing_select(uint64_t id_mask);
 
 /* ------------------------------------------------------------------------
  * Interleaved complex -> real and imaginary arrays of the same contiguous

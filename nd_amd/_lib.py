@@ -27,7 +27,8 @@ SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_correlate1d_yx', 'nd_amd_nlmeans3d',
            'nd_amd_relayout_planar', 'nd_amd_relayout_planar_complex',
            'nd_amd_relayout_pixel_major', 'nd_amd_split_complex', 'nd_amd_merge_complex',
-           'nd_amd_timing_enable', 'nd_amd_timing_collect', 'nd_amd_timing_dropped')
+           'nd_amd_timing_enable', 'nd_amd_timing_collect', 'nd_amd_timing_dropped',
+           'nd_amd_timing_select')
 
 _lib = None
 
@@ -100,6 +101,8 @@ def lib():
                                         C.POINTER(i32)]
     L.nd_amd_timing_dropped.restype = i32
     L.nd_amd_timing_dropped.argtypes = []
+    L.nd_amd_timing_select.restype = i32
+    L.nd_amd_timing_select.argtypes = [C.c_uint64]
     v = L.nd_amd_abi_version()
     if v != 1:
         raise ImportError('nd_amd: libnd_amd.so has ABI version %d, expected 1' % v)
@@ -122,6 +125,16 @@ def u32_array(values):
 
 def timing_enable(capacity):
     check(lib().nd_amd_timing_enable(int(capacity)))
+
+
+def timing_select(names=None):
+    """time only the kernels named (KERNEL_NAMES values); None = all.  Reset by timing_enable."""
+    mask = 0
+    if names:
+        ids = {v: k for k, v in KERNEL_NAMES.items()}
+        for n in names:
+            mask |= 1 << ids[n]
+    check(lib().nd_amd_timing_select(mask))
 
 
 def timing_dropped():

@@ -24,6 +24,7 @@ struct TimingState {
     int capacity = 0;
     int used = 0;
     int dropped = 0;
+    uint64_t select = 0;          // 0 = every kernel id
     std::vector<hipEvent_t> start, stop;
     std::vector<int32_t> ids;
 };
@@ -35,6 +36,7 @@ KernelTimer::KernelTimer(int kernel_id, hipStream_t s) : slot(-1), stream(s)
     if (!t.enabled) return;
     std::lock_guard<std::mutex> lk(t.mu);
     if (!t.enabled) return;
+    if (t.select != 0 && (kernel_id < 0 || kernel_id > 63 || !((t.select >> kernel_id) & 1ull))) return;
     if (t.used >= t.capacity) {
         t.dropped++;
         return;
@@ -73,6 +75,7 @@ extern "C" int nd_amd_timing_enable(int capacity)
     t.dropped = 0;
     t.capacity = 0;
     t.enabled = false;
+    t.select = 0;
     if (capacity <= 0) return ND_AMD_OK;
     t.start.resize(capacity);
     t.stop.resize(capacity);
@@ -100,6 +103,14 @@ extern "C" int nd_amd_timing_collect(int32_t *kernel_ids, float *ms, int max_n, 
     }
     if (n_out) *n_out = n;
     t.used = 0;
+    return ND_AMD_OK;
+}
+
+extern "C" int nd_amd_timing_select(uint64_t id_mask)
+{
+    TimingState &t = g_timing;
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.select = id_mask;
     return ND_AMD_OK;
 }
 
