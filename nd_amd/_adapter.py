@@ -128,6 +128,24 @@ def split_bounds(n, chunks, buffer=0):
     return out
 
 
+def safe_chunks(n, chunks, buffer=0):
+    """The largest chunk count <= `chunks` for which xr_split / xr_merge lose nothing: no empty
+    chunk, and a last chunk at least `buffer` long (its neighbour's extension is clipped at the end
+    of the data, and xr_merge trims a full `buffer` from it).  The split arithmetic itself is the
+    reference's; it has no such guard (nd/utils.py:305-340)."""
+    n, chunks, buffer = int(n), max(1, int(chunks)), int(buffer)
+    while chunks > 1:
+        cs = int(np.ceil(n / chunks))
+        used = int(np.ceil(n / cs))
+        if used < chunks:                 # trailing chunks would be empty
+            chunks = used
+            continue
+        if n - (chunks - 1) * cs >= max(buffer, 1) and cs >= max(buffer, 1):
+            break
+        chunks -= 1
+    return chunks
+
+
 def xr_split(ds, dim, chunks, buffer=0):
     n = ds.sizes[dim]
     for low, high in split_bounds(n, chunks, buffer):

@@ -64,6 +64,12 @@ def resolve_devices(devices=None, njobs=1):
         return devs
     if njobs in (0, 1):
         return None
+    # One process per GPU (torch.distributed, torchrun): the other visible GPUs belong to the other
+    # ranks.  Spreading over them is opt-in through `devices`.
+    import os
+    import torch.distributed as dist
+    if (dist.is_available() and dist.is_initialized()) or 'LOCAL_RANK' in os.environ or 'RANK' in os.environ:
+        return None
     n = torch.cuda.device_count()
     if n <= 1:
         return None
@@ -84,10 +90,18 @@ def parallel(fn, dim=None, chunks=None, buffer=0, devices=None):
     def wrapper(ds, *args, **kwargs):
         if dim not in ds.dims:
             raise ValueError("The dataset has no dimension '{}'.".format(dim))
-        parts = list(_adapter.xr_split(ds, dim=dim, chunks=chunks, buffer=buffer))
+        nchunks = _adapter.safe_chunks(ds.sizes[dim], chunks, buffer)
+        parts = list(_adapter.xr_split(ds, dim=dim, chunks=nchunks, buffer=buffer))
+
+        def merged(output):
+            res = _adapter.xr_merge(output, dim=dim, buffer=buffer)
+            if dim in res.dims and res.sizes[dim] != ds.sizes[dim]:
+                raise RuntimeError('chunked run returned %d samples along %r, the input has %d'
+                                   % (res.sizes[dim], dim, ds.sizes[dim]))
+            return res
+
         if not devices:
-            output = [fn(part, *args, **kwargs) for part in parts]
-            return _adapter.xr_merge(output, dim=dim, buffer=buffer)
+            return merged([fn(part, *args, **kwargs) for part in parts])
         import torch
         from concurrent.futures import ThreadPoolExecutor
         home = _adapter.home_device(ds)
@@ -107,7 +121,7 @@ def parallel(fn, dim=None, chunks=None, buffer=0, devices=None):
         with ThreadPoolExecutor(max_workers=len(devices)) as pool:
             results = sorted((r for lst in pool.map(lane, range(len(devices))) for r in lst),
                              key=lambda ir: ir[0])
-        return _adapter.xr_merge([r for _, r in results], dim=dim, buffer=buffer)
+        return merged([r for _, r in results])
 
     return wrapper
 
@@ -128,8 +142,10 @@ def parallelize(func):
         if chunks > 1:
             dim = self._parallel_dimension(ds)
             halo = int(self._buffer(dim))
-            # never more chunks than the dimension can carry with its halo
+            # never more chunks than the dimension can carry with its halo: no empty chunk, no
+            # last chunk shorter than the halo (xr_merge would trim rows that were never there)
             chunks = max(1, min(chunks, ds.sizes[dim] // (2 * halo + 1)))
+            chunks = _adapter.safe_chunks(ds.sizes[dim], chunks, halo)
             if chunks > 1:
                 return parallel(call, dim=dim, chunks=chunks, buffer=halo,
                                 devices=devs)(ds, *args, **kwargs)

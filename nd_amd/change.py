@@ -224,6 +224,7 @@ class OmnibusTest(ChangeDetection):
             chunks = max(len(devs), int(self.njobs) if self.njobs and self.njobs > 1 else 1)
             chunks -= chunks % len(devs)
             chunks = max(1, min(chunks, ds.sizes['y'] // (2 * halo + 1)))
+            chunks = _adapter.safe_chunks(ds.sizes['y'], chunks, halo)
             if chunks > 1:
                 return parallel(run, dim='y', chunks=chunks, buffer=halo, devices=devs)(ds)
             with torch.cuda.device(devs[0]):

@@ -116,8 +116,10 @@ __device__ __forceinline__ void chisq_pair(const double (&z)[N], int a2, double 
             p2 = 1.0 - (qa + ta[i] + ta[i] * u1[i]);
         }
         if (!ok[i]) {
-            // gsl_cdf_chisq_P: x <= 0 -> 0; NaN stays NaN; +inf -> NaN (inf - inf inside GSL's
-            // large-x branch; DESIGN.md "Residual risks")
+            // gsl_cdf_chisq_P (GSL cdf/gamma.c: gsl_cdf_gamma_P): x <= 0 -> 0 before anything is
+            // evaluated; NaN stays NaN; +inf -> NaN (y > a -> 1 - gsl_sf_gamma_inc_Q, whose
+            // large-x form evaluates exp(a ln x - x - ...) = exp(inf - inf); the branch list is
+            // next to orc_cdf_chisq_P in oracle/nd_oracle.c)
             p1 = p2 = (z[i] <= 0.0) ? 0.0 : NAN;
         }
         P1[i] = p1;

@@ -147,7 +147,10 @@ def change_detection_c3(planes, alpha, n=1, dims=('time', 'y', 'x'), stats=False
     p0 = planes[0]
     for i, t in enumerate(planes):
         _require_cuda(t, 'planes[%d]' % i)
-        if (t.dim() != 3 or t.shape != p0.shape or t.stride() != p0.stride()
+        # strides of length-1 axes address nothing: views of one buffer may carry different ones
+        same_strides = t.dim() == 3 and all(a == b for a, b, n_ in zip(t.stride(), p0.stride(), t.shape)
+                                            if n_ > 1)
+        if (t.dim() != 3 or t.shape != p0.shape or not same_strides
                 or t.dtype != p0.dtype or t.device != p0.device):
             raise ValueError('the nine covariance planes must be 3-D and share shape, strides, '
                              'dtype and device')

@@ -233,11 +233,25 @@ def map_over_tiles(files, fn, args=(), kwargs=None, path=None, suffix='', merge=
         raise ValueError('No files found!')
     if path is not None:
         os.makedirs(path, exist_ok=True)
-    results = []
-    for f in files:
+
+    def result_of(f):
         root, name = os.path.split(f.rstrip('/'))
         stem = name[:-len(EXT)] if name.endswith(EXT) else name
-        out_file = os.path.join(root if path is None else path, stem + suffix + EXT)
+        return os.path.join(root if path is None else path, stem + suffix + EXT)
+
+    # Results written next to the inputs match the same glob on the next call (resuming an
+    # interrupted run, which the skip-existing rule exists for): a file that is itself the result of
+    # another input is a result, not an input.  (The reference never skips, so it never meets this.)
+    for f in files:
+        if os.path.abspath(result_of(f)) == os.path.abspath(f.rstrip('/')):
+            raise ValueError('the result would overwrite its input: give `path` or `suffix`')
+    produced = {os.path.abspath(result_of(f)) for f in files}
+    files = [f for f in files if os.path.abspath(f.rstrip('/')) not in produced]
+    if not files:
+        raise ValueError('No input tiles left: every file is the result of another one')
+    results = []
+    for f in files:
+        out_file = result_of(f)
         if os.path.abspath(out_file) == os.path.abspath(f):
             raise ValueError('the result would overwrite its input: give `path` or `suffix`')
         results.append(out_file)

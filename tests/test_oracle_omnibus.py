@@ -31,6 +31,35 @@ def test_chisq_cdf_against_mpmath(oracle):
         assert abs(oracle.cdf_chisq_P(x, nu) - want) <= 2e-13 * max(want, 1e-300)
 
 
+def test_chisq_gsl_branches(oracle):
+    """One pin per branch of gsl_cdf_gamma_P as restated in oracle/nd_oracle.c (cdf/gamma.c: B1
+    x <= 0, B2 y > a -> 1 - Q, B3 -> P) and per edge value of the call sites nd/_change.pyx:147-148."""
+    from scipy.stats import chi2
+    P = oracle.cdf_chisq_P
+    # B1: x <= 0 returns 0 before anything is evaluated (also for -inf and -0.0)
+    for x in (0.0, -0.0, -1e-300, -3.0, -float('inf')):
+        assert P(x, 4) == 0.0 and P(x, 92) == 0.0
+    # B3: y = x / 2 <= a = nu / 2 (lower tail, the P form), B2: y > a (upper tail, 1 - Q)
+    for nu in (4, 8, 48, 92, 96):                # f = 4 (j - 1) and f + 4 of the dual-pol test
+        a = nu / 2.0
+        for x in (1e-12, 0.5 * nu, nu * (1 - 1e-12)):          # B3, up to the switch point
+            assert 2 * a >= x
+            assert P(x, nu) == pytest.approx(chi2.cdf(x, nu), rel=2e-12, abs=1e-300)
+        for x in (nu * (1 + 1e-12), 2.0 * nu, 10.0 * nu, 1e3 * nu):   # B2
+            assert x / 2 > a
+            assert P(x, nu) == pytest.approx(chi2.cdf(x, nu), rel=2e-12)
+        # continuity across the switch y = a
+        assert abs(P(nu * (1 + 1e-9), nu) - P(nu * (1 - 1e-9), nu)) < 1e-8    # (pdf x 2e-9 nu: no jump)
+    # large finite x: Q underflows smoothly, P -> 1 exactly, never above
+    for x in (1e4, 1e6, 2e6, 1e12, 1e300):
+        assert P(x, 4) == 1.0 and P(x, 92) == 1.0
+    # x = +inf: GSL's large-x form evaluates exp(a ln x - x - ...) = exp(inf - inf): NaN (scipy: 1)
+    assert np.isnan(P(float('inf'), 4)) and np.isnan(P(float('inf'), 92))
+    assert chi2.cdf(float('inf'), 4) == 1.0
+    # NaN stays NaN through every comparison
+    assert np.isnan(P(float('nan'), 4))
+
+
 def test_chisq_edge_semantics(oracle):
     # gsl_cdf_chisq_P: 0 for x <= 0 (GSL cdf/gamma.c); NaN propagates
     assert oracle.cdf_chisq_P(0.0, 4) == 0.0

@@ -123,3 +123,21 @@ def test_tiled_pipeline_on_the_gpu_equals_whole_raster(tmp_path, oracle, device)
     merged = tiling.map_over_tiles(tiles, pipeline, path=str(tmp_path / 'out'))
     np.testing.assert_array_equal(merged['change'].values, want)
     assert want.any()
+
+
+def test_map_over_tiles_twice_next_to_the_inputs(tmp_path, oracle):
+    """Results written beside the inputs (path=None) match the same glob on the next call: they
+    must be recognised as results, not filtered a second time (round-2 advisor finding)."""
+    ds = _dataset(ny=30, nx=21, k=2, seed=5)
+    want = _box(ds)['C11'].values
+    d = str(tmp_path / 'tiles')
+    tiling.tile(ds, d, chunks={'y': 10}, buffer=2)
+    pattern = os.path.join(d, '*.envi')
+    first = tiling.map_over_tiles(pattern, _box, suffix='_f')
+    np.testing.assert_array_equal(first['C11'].values, want)
+    n_after_first = len(os.listdir(d))
+    calls = []
+    second = tiling.map_over_tiles(pattern, lambda t: calls.append(1) or _box(t), suffix='_f')
+    assert calls == []                                        # every result already existed
+    assert len(os.listdir(d)) == n_after_first                # no *_f_f tiles
+    np.testing.assert_array_equal(second['C11'].values, want)
