@@ -213,8 +213,9 @@ int nd_amd_correlate1d_yx(const void *in, void *out, int dtype,
  *                   [tile_off, tile_off + N) of an array of shape global_N
  *                   that carries its halo rows, `out` likewise; only
  *                   [core_lo, core_hi) of axis `N` is written and reflection
- *                   happens at the GLOBAL edges.  Pass global_N = N,
- *                   tile_off = 0, core = [0, N) for the plain call.
+ *                   happens at the GLOBAL edges.  NULL for any of the four means
+ *                   the plain call's value: global_N = N, tile_off = 0,
+ *                   core = [0, N).
  * ---------------------------------------------------------------------- */
 int nd_amd_nlmeans3d(const void *arr, void *out, int dtype,
                      const int64_t N[3], int64_t nvars,

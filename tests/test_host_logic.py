@@ -277,3 +277,18 @@ def test_chunk_count_never_drops_rows():
                 ds['a'] = (('y', 'x'), np.arange(n * 3, dtype=np.float32).reshape(n, 3))
                 out = parallel(lambda part: part, dim='y', chunks=chunks, buffer=halo)(ds)
                 np.testing.assert_array_equal(out['a'].values, ds['a'].values)
+
+
+def test_integration_doc_quotes_the_example():
+    """INTEGRATION.md's binding code IS examples/nd_binding.py: every marked section of the example
+    appears verbatim in the document (tests/test_binding_example_gpu.py executes the example)."""
+    import re
+    ex = open(os.path.join(ROOT, 'examples', 'nd_binding.py')).read()
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    sections = dict(re.findall(r"# --8<-- \[(\w+)\]\n(.*?)\n# --8<-- \[end\]", ex, re.S))
+    assert set(sections) == {'load', 'omnibus', 'convolve', 'nlmeans', 'gaussian'}
+    for name, code in sections.items():
+        assert code.strip('\n') in doc, 'INTEGRATION.md does not quote section [%s] verbatim' % name
+    # the header says what the example does with the optional tile arguments
+    hdr = open(os.path.join(ROOT, 'include', 'nd_amd.h')).read()
+    assert 'NULL for any of the four' in hdr
