@@ -280,13 +280,36 @@ class Pipeline(Workload):
         ext_px = self.shard.ext.shape[2] * self.nx
         self.alg_bytes = ext_px * self.k * 4 * 8
         self.filtered = None
+        import torch
+        # find_weight's 'No solution' flag of n_eff = 50: collected on the device, read once after
+        # the timed region (a step has no host synchronisation)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.status_any = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def step(self):
         from nd_amd import tiles
         self.filtered = tiles.nlmeans_rows(self.shard, self.global_ny, TUT['r'], TUT['f'],
                                            TUT['sigma'], TUT['h'], n_eff=TUT['n_eff'],
-                                           patch_mode=self.a.patch_mode)
+                                           patch_mode=self.a.patch_mode, status=self.status)
+        self.status_any.bitwise_or_(self.status)
         return tiles.omnibus_rows(self.filtered, self.a.alpha, TUT['n'])
+
+    def comm(self, steps=5):
+        """halo bytes this rank sends per step and the duration of the exchange by itself (events on
+        the launch stream around `steps` exchanges with nothing to overlap them)"""
+        import torch
+        from nd_amd import tiles
+        h = tiles.exchange_halo_begin(self.shard)
+        nbytes = h.nbytes
+        h.wait()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            tiles.exchange_halo_(self.shard)
+        e1.record()
+        torch.cuda.synchronize()
+        return {'halo_bytes_sent_per_step': int(nbytes), 'exchange_ms_alone': e0.elapsed_time(e1) / steps}
 
     def metric(self):
         return 'Mpixels/s NLMeans->OmnibusTest %dt x %d x %d' % (self.k, self.a.ny, self.nx)
@@ -302,7 +325,9 @@ class Pipeline(Workload):
                    if self.world > 1 else 'single rank: no exchange'))
 
     def check(self, out, nsample=0):
+        from nd_amd import kernels
         from oracle import checks
+        kernels.raise_if_no_solution(self.status_any)
         crops = [(0, 0), (self.rows, self.nx), (self.rows // 2, self.nx // 3)]
         return checks.nlmeans_crops(self.stack, self.filtered, TUT['r'], TUT['f'], TUT['sigma'],
                                     TUT['h'], TUT['n_eff'], self.a.patch_mode, crops, size=(8, 64),
@@ -638,6 +663,7 @@ def main():
     for name, ms in avg_all.items():
         avg.setdefault(name, ms)
 
+    local_dt = dt
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -649,6 +675,26 @@ def main():
         total_px = float(w.npix)
     value = total_px * args.steps / dt / 1e6
     flagged = float((out.sum(dim=2) > 0).float().mean().item())
+    comm = None
+    if dist is not None:
+        # who took part, over what, and what travelled: gathered from every rank so that the line
+        # carries its own evidence of the N > 1 run
+        mine = {'rank': rank, 'device': torch.cuda.get_device_name(local_rank), 'device_index': local_rank,
+                'rows': [w.r0, w.r1], 'step_ms': local_dt / args.steps * 1e3,
+                'step_ms_median': sorted(per_step)[len(per_step) // 2] if per_step else None}
+        if hasattr(w, 'comm'):
+            mine.update(w.comm())
+            if hasattr(w, 'status_any'):
+                from nd_amd import kernels
+                kernels.raise_if_no_solution(w.status_any)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                'data_path_collective': 'none (per-pixel path: every rank runs its own rows)'
+                if w.name != 'pipeline' else
+                'one point-to-point halo exchange per step (batch_isend_irecv with the row neighbours, '
+                'overlapped with the filter on the rows that need no halo)',
+                'ranks': ranks}
 
     if rank == 0:
         is_default = (w.name == 'omnibus' and (w.k, args.ny, w.nx, args.alpha, args.looks, args.change_frac)
@@ -680,6 +726,7 @@ def main():
                                'no collective' if w.name != 'pipeline' or world == 1 else
                                'one point-to-point halo exchange per step'),
             },
+            'comm': comm,
             'kernels_ms': avg,
             'kernels_ms_note': '%s: events inside the timed region; the others: a second loop of the '
                                'same step' % dom_k,

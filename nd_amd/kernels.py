@@ -563,9 +563,16 @@ def gaussian_filter(inp, sigma, out=None, mode='reflect', cval=0.0, truncate=4.0
 # ---------------------------------------------------------------------------
 # non-local means
 # ---------------------------------------------------------------------------
+def raise_if_no_solution(status):
+    """The deferred half of pixelwise_nlmeans_3d(..., status=t): reads the device flag (this is the
+    host synchronisation) and raises the reference's ValueError('No solution') if it is set."""
+    if status is not None and int(status.item()) != 0:
+        raise ValueError('No solution')
+
+
 def pixelwise_nlmeans_3d(arr, output, r, f, sigma, h, n_eff=-1, patch_mode=0,
                          neff_policy=1, global_shape=None, tile_offset=None,
-                         core=None):
+                         core=None, status=None):
     """In-place into `output` like the reference.  arr/output: CUDA tensors
     (N0, N1, N2, nvars), any strides.
 
@@ -574,6 +581,11 @@ def pixelwise_nlmeans_3d(arr, output, r, f, sigma, h, n_eff=-1, patch_mode=0,
     neff_policy 1 raises ValueError('No solution') like a current build of the
     reference, 0 gives the self weight 0 of the shipped C.
     global_shape/tile_offset/core describe a halo-carrying tile (multi-GPU).
+    status: an int32 device tensor of one element.  Without it (the reference's behaviour) a call
+    with n_eff >= 0 reads the find_weight flag back and raises at once -- one host
+    synchronisation per call.  With it the library writes the flag there (zeroing it first) and
+    the call stays asynchronous: a pipeline step then has no host stall, and the caller checks
+    with raise_if_no_solution(status) when it next needs the host anyway.
     """
     _require_cuda(arr, 'arr')
     _require_cuda(output, 'output')
@@ -591,8 +603,10 @@ def pixelwise_nlmeans_3d(arr, output, r, f, sigma, h, n_eff=-1, patch_mode=0,
     dev = arr.device
     L = _lib.lib()
     with torch.cuda.device(dev):
-        status = None
-        if n_eff >= 0 and neff_policy == 1:
+        deferred = status is not None
+        if deferred and (status.dtype != torch.int32 or status.numel() != 1 or status.device != dev):
+            raise ValueError('status must be one int32 element on the device of arr')
+        if not deferred and n_eff >= 0 and neff_policy == 1:
             status = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.check(L.nd_amd_nlmeans3d(
             _ptr(arr), _ptr(output), _DT[arr.dtype], _lib.i64_array(N), arr.shape[3],
@@ -601,6 +615,6 @@ def pixelwise_nlmeans_3d(arr, output, r, f, sigma, h, n_eff=-1, patch_mode=0,
             int(patch_mode), int(neff_policy), _ptr(status),
             _lib.i64_array(G), _lib.i64_array(toff), _lib.i64_array(clo),
             _lib.i64_array(chi), _stream_ptr(dev)))
-        if status is not None and int(status.item()) != 0:
-            raise ValueError('No solution')
+        if not deferred:
+            raise_if_no_solution(status)
     return output

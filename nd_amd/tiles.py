@@ -80,11 +80,12 @@ class RowShard:
     rows for the neighbours' halos: `ext` = rows [r0 - lo, r1 + hi) of the whole raster once
     `exchange_halo_` has run, `core` = the view of the block's own rows."""
 
-    __slots__ = ('ext', 'dim', 'lo', 'hi', 'r0', 'r1', 'global_n', 'halo')
+    __slots__ = ('ext', 'dim', 'lo', 'hi', 'r0', 'r1', 'global_n', 'halo', 'bufs')
 
     def __init__(self, ext, dim, lo, hi, r0, r1, global_n, halo):
         self.ext, self.dim, self.lo, self.hi = ext, dim, lo, hi
         self.r0, self.r1, self.global_n, self.halo = r0, r1, global_n, halo
+        self.bufs = {}            # packed send / landing buffers of the halo exchange, kept across steps
         if ext.shape[dim] != (r1 - r0) + lo + hi:
             raise ValueError('shard buffer has %d rows, expected %d + %d + %d'
                              % (ext.shape[dim], lo, r1 - r0, hi))
@@ -133,47 +134,83 @@ def shard_of(full, halo, dim, rank, world, device=None):
     return RowShard(ext, dim, lo, hi, r0, r1, n, halo)
 
 
-def exchange_halo_(shard, group=None):
-    """Fill the margins of `shard` with the neighbours' edge rows, in place.  One batched group
-    of point-to-point operations (two sends, two receives at most); only halo-sized pieces are
-    ever packed or unpacked, the block itself stays where it is."""
+class HaloExchange:
+    """A halo exchange in flight (exchange_halo_begin): `wait()` makes the current stream wait for
+    it and unpacks what did not land in place."""
+
+    def __init__(self, shard, reqs, landing, nbytes):
+        self.shard, self.reqs, self.landing, self.nbytes = shard, reqs, landing, nbytes
+
+    def wait(self):
+        for req in self.reqs:
+            req.wait()
+        for view, buf in self.landing:
+            view.copy_(buf, non_blocking=True)
+        self.reqs, self.landing = [], []
+        return self.shard
+
+
+def exchange_halo_begin(shard, group=None):
+    """Post the exchange of `shard`'s halo rows with the neighbouring ranks and return at once:
+    one batched group of point-to-point operations (two sends, two receives at most).  Only
+    halo-sized pieces are ever packed or unpacked, into buffers the shard keeps from step to step;
+    the block itself stays where it is.  With RCCL the transfers run on the communicator's own
+    stream: whatever is launched before `wait()` -- the filter on the rows that need no halo --
+    overlaps them."""
     world, rank = _world_rank(group)
     check_partition(shard.global_n, world, shard.halo)        # identical verdict on every rank
     if world == 1 or shard.halo <= 0:
-        return shard
+        return HaloExchange(shard, [], [], 0)
     ext, dim, lo, hi, n = shard.ext, shard.dim, shard.lo, shard.hi, shard.n_local
     halo = shard.halo
     ops, landing = [], []
+    nbytes = 0
     # RCCL moves device memory itself.  A `gloo` group (CPU tests, or several ranks sharing one
     # GPU, which RCCL refuses) only moves host memory: halo pieces of device shards are staged
     # through host buffers there -- halo-sized copies, the block still never moves.
     via_host = ext.is_cuda and dist.get_backend(group) == 'gloo'
 
-    def send_rows(a, b, peer):
-        piece = _rows(ext, dim, a, b).contiguous()
+    def kept(key, like):
+        buf = shard.bufs.get(key)
+        if buf is None or buf.shape != like.shape or buf.dtype != like.dtype or buf.device != like.device:
+            buf = torch.empty(like.shape, dtype=like.dtype, device=like.device)
+            shard.bufs[key] = buf
+        return buf
+
+    def send_rows(a, b, peer, key):
+        view = _rows(ext, dim, a, b)
+        piece = view if view.is_contiguous() else kept(key, view)
+        if piece is not view:
+            piece.copy_(view, non_blocking=True)
         if via_host:
             piece = piece.cpu()
         ops.append(dist.P2POp(dist.isend, piece, _peer(group, peer), group))
+        return piece.numel() * piece.element_size()
 
-    def recv_into(view, peer):
+    def recv_into(view, peer, key):
         direct = view.is_contiguous() and not via_host
-        buf = view if direct else torch.empty(view.shape, dtype=view.dtype,
-                                              device='cpu' if via_host else view.device)
+        if direct:
+            buf = view
+        elif via_host:
+            buf = torch.empty(view.shape, dtype=view.dtype, device='cpu')
+        else:
+            buf = kept(key, view)
         ops.append(dist.P2POp(dist.irecv, buf, _peer(group, peer), group))
         if buf is not view:
             landing.append((view, buf))
 
     if rank > 0:                                   # my first rows go up, rank-1's last rows come in
-        send_rows(lo, lo + halo, rank - 1)
-        recv_into(_rows(ext, dim, 0, lo), rank - 1)
+        nbytes += send_rows(lo, lo + halo, rank - 1, 'send_up')
+        recv_into(_rows(ext, dim, 0, lo), rank - 1, 'recv_up')
     if rank < world - 1:
-        send_rows(lo + n - halo, lo + n, rank + 1)
-        recv_into(_rows(ext, dim, lo + n, lo + n + hi), rank + 1)
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    for view, buf in landing:
-        view.copy_(buf)
-    return shard
+        nbytes += send_rows(lo + n - halo, lo + n, rank + 1, 'send_down')
+        recv_into(_rows(ext, dim, lo + n, lo + n + hi), rank + 1, 'recv_down')
+    return HaloExchange(shard, dist.batch_isend_irecv(ops), landing, nbytes)
+
+
+def exchange_halo_(shard, group=None):
+    """Fill the margins of `shard` with the neighbours' edge rows, in place (begin + wait)."""
+    return exchange_halo_begin(shard, group).wait()
 
 
 def exchange_halo(core, halo, dim, global_n=None, group=None):
@@ -231,38 +268,73 @@ def boxcar_rows(stack, w, global_ny=None, group=None):
     return filter_rows(lambda e: kernels.convolve(e, k), stack, w // 2, t.dim() - 2, global_ny, group)
 
 
-def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group=None):
+def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group=None, status=None):
     """NLMeansFilter on a row-sharded planar stack (var, time, y_local, x), joint weights over the
     variables.  r, f: (time, y, x) radii like NLMeansFilter(dims=('time', 'y', 'x')).  The halo
     rows (r_y + f_y) are exchanged once for all variables and dates; reflection happens at the
     global edges.  With r_time = 0 every date is filtered on its own by the LDS-tiled kernels.
-    `stack`: a RowShard whose halo is r_y + f_y (nothing is copied), or a plain block."""
+    `stack`: a RowShard whose halo is r_y + f_y (nothing is copied), or a plain block.
+
+    A RowShard with neighbours is filtered in three launches: the rows that need no halo while the
+    exchange is in flight, then the two edge bands (a pixel's value does not depend on how the
+    raster is cut, so the result is the single launch's, bit for bit).
+    status: int32 device tensor of one element that collects the find_weight flag of n_eff >= 0
+    without a host synchronisation (kernels.raise_if_no_solution reads it later)."""
     from . import kernels, synth
     rt, ry, rx = (int(v) for v in r)
     ft, fy, fx = (int(v) for v in f)
     halo = ry + fy
+    pending = None
     if isinstance(stack, RowShard):
         if stack.global_n != global_ny or (stack.halo != halo and _world_rank(group)[0] > 1):
             raise ValueError('the shard was allocated for %d rows / halo %d, the filter needs %d / %d'
                              % (stack.global_n, stack.halo, global_ny, halo))
-        shard = exchange_halo_(stack, group)
-        ext, lo, hi, r0 = shard.ext, shard.lo, shard.hi, shard.r0
+        pending = exchange_halo_begin(stack, group)
+        ext, lo, hi, r0 = stack.ext, stack.lo, stack.hi, stack.r0
     else:
         r0, _ = my_rows(global_ny, group)
         ext, lo, hi = exchange_halo(stack, halo, 2, global_ny, group)
     nvar, k, ny_ext, nx = ext.shape
     out = synth.empty_stack(nvar, k, ny_ext, nx, ext.device, ext.dtype)
-    if rt == 0 and ft == 0:
-        # (y, x, time, var) view of planar memory: x contiguous
-        kernels.pixelwise_nlmeans_3d(
-            ext.permute(2, 3, 1, 0), out.permute(2, 3, 1, 0), (ry, rx, 0), (fy, fx, 0), sigma, h,
-            n_eff, patch_mode=patch_mode, global_shape=(global_ny, nx, k),
-            tile_offset=(r0 - lo, 0, 0), core=((lo, ny_ext - hi), (0, nx), (0, k)))
+    scratch = None
+    if status is not None:
+        status.zero_()
+        scratch = torch.zeros_like(status)
+
+    def run(row_lo, row_hi):
+        """filter the rows [row_lo, row_hi) of the extended tile"""
+        if row_hi <= row_lo:
+            return
+        if rt == 0 and ft == 0:
+            # (y, x, time, var) view of planar memory: x contiguous
+            kernels.pixelwise_nlmeans_3d(
+                ext.permute(2, 3, 1, 0), out.permute(2, 3, 1, 0), (ry, rx, 0), (fy, fx, 0), sigma, h,
+                n_eff, patch_mode=patch_mode, global_shape=(global_ny, nx, k),
+                tile_offset=(r0 - lo, 0, 0), core=((row_lo, row_hi), (0, nx), (0, k)), status=scratch)
+        else:
+            kernels.pixelwise_nlmeans_3d(
+                ext.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), (rt, ry, rx), (ft, fy, fx), sigma, h,
+                n_eff, patch_mode=patch_mode, global_shape=(k, global_ny, nx),
+                tile_offset=(0, r0 - lo, 0), core=((0, k), (row_lo, row_hi), (0, nx)), status=scratch)
+        if status is not None:
+            status.bitwise_or_(scratch)
+
+    first, last = lo, ny_ext - hi                  # the block's own rows inside `ext`
+    if pending is not None and pending.reqs:
+        in_lo = first + (halo if lo else 0)        # rows whose windows stay inside the block
+        in_hi = last - (halo if hi else 0)
+        if in_hi > in_lo:
+            run(in_lo, in_hi)                      # ... while the halo rows travel
+            pending.wait()
+            run(first, in_lo)
+            run(in_hi, last)
+        else:
+            pending.wait()
+            run(first, last)
     else:
-        kernels.pixelwise_nlmeans_3d(
-            ext.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), (rt, ry, rx), (ft, fy, fx), sigma, h,
-            n_eff, patch_mode=patch_mode, global_shape=(k, global_ny, nx),
-            tile_offset=(0, r0 - lo, 0), core=((0, k), (lo, ny_ext - hi), (0, nx)))
+        if pending is not None:
+            pending.wait()
+        run(first, last)
     return trim(out, lo, hi, 2)
 
 

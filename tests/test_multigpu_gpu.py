@@ -231,3 +231,17 @@ def test_bench_launch_line_with_two_ranks(workload, extra, tmp_path):
     want = total_rows * nx / (res['ms_per_step'] * 1e-3) / 1e6
     assert abs(res['value'] - want) <= 1e-6 * want
     assert 'REHEARSAL' in res['data'] and 'roofline' in res
+    # the line carries its own evidence of the N > 1 run
+    comm = res['comm']
+    assert comm['world_size'] == 2 and comm['backend'] == 'gloo' and len(comm['ranks']) == 2
+    assert [r['rank'] for r in comm['ranks']] == [0, 1]
+    assert all(r['device'] and r['step_ms'] > 0 for r in comm['ranks'])
+    rows = [r['rows'] for r in comm['ranks']]
+    assert rows[0][0] == 0 and rows[0][1] == rows[1][0] and rows[1][1] == total_rows
+    if workload == 'pipeline':
+        halo = 4                                            # r_y + f_y of the tutorial's filter
+        assert all(r['halo_bytes_sent_per_step'] == 4 * k * halo * nx * 4 for r in comm['ranks'])
+        assert all(r['exchange_ms_alone'] > 0 for r in comm['ranks'])
+        assert 'point-to-point' in comm['data_path_collective']
+    else:
+        assert comm['data_path_collective'].startswith('none')
