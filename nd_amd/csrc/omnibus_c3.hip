@@ -542,15 +542,32 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
                     }
             }
         }
+        // from memory (no LDS image): date t of this lane's series, with the date most likely to be
+        // asked for next already in flight.  A lane's nine values of a date are nine isolated 4-byte
+        // reads; what hides their latency is occupancy (no 110 KB image: 8+ waves per CU instead of
+        // one) plus this one date of read-ahead.
+        T nxt[9];
+        int nxt_t = -1;
+        auto fetch = [&](int t, T (&v)[9]) {
+            const int64_t o = off + (int64_t)t * s.st;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = s.pl[c][o];
+        };
         auto load_step = [&](Accum3<T> &A, int t) {
             T v[9];
             if (USE_LDS) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c) v[c] = lds[(t * 9 + c) * 64 + lane];
             } else {
-                const int64_t o = off + (int64_t)t * s.st;
+                if (nxt_t == t) {
 #pragma unroll
-                for (int c = 0; c < 9; ++c) v[c] = s.pl[c][o];
+                    for (int c = 0; c < 9; ++c) v[c] = nxt[c];
+                } else {
+                    fetch(t, v);
+                }
+                const int tn = t + 1 < k ? t + 1 : t;
+                fetch(tn, nxt);
+                nxt_t = tn;
             }
             A.step(v);
         };
@@ -724,7 +741,16 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     // beats a dependent, TLB-missing plane access per date and lane)
     const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);
     const size_t lds_bytes = (size_t)k * 9 * 64 * sizeof(T) + scr_bytes;
-    const bool use_lds = lds_bytes <= 150 * 1024;
+    // ND_AMD_C3_SEARCH_MODE=1: always from memory (one date of read-ahead, 8+ waves per CU).
+    // Measured on config 4's share (48 x 1024 x 8192, 2 % of the pixels listed): 2.02 ms against
+    // 1.55 ms with the image at one wave per CU -- of which 1.13 ms is the gather itself: 72 M isolated
+    // 4-byte reads = 4.6 GB of 64-byte sectors at 4.1 TB/s, i.e. the pass is bound by the sector
+    // traffic of its gather, not by the occupancy the image costs.
+    static const int c3_mode = [] {
+        const char *e = getenv("ND_AMD_C3_SEARCH_MODE");
+        return e ? atoi(e) : 0;
+    }();
+    const bool use_lds = c3_mode == 1 ? false : lds_bytes <= 150 * 1024;
     if (use_lds && lds_bytes > 64 * 1024) {
         ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c3_search_kernel<T, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

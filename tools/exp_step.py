@@ -18,8 +18,12 @@ def child(alpha, steps):
     import torch
     from nd_amd import _lib, kernels, synth
     dev = torch.device('cuda:0')
-    st = synth.wishart_c2_stack(24, 4096, 4096, seed=1234, device=dev, change_frac=0.01)
-    fn = lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)   # noqa: E731
+    if os.environ.get('EXP_WORKLOAD') == 'c3':       # one GPU's share of config 4, as bench.py's extra
+        st = synth.wishart_c3_stack(48, 1024, 8192, looks=9, seed=4321, device=dev, change_frac=0.01)
+        fn = lambda: kernels.change_detection_c3([st[c] for c in range(9)], alpha=alpha, n=9)   # noqa: E731
+    else:
+        st = synth.wishart_c2_stack(24, 4096, 4096, seed=1234, device=dev, change_frac=0.01)
+        fn = lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)   # noqa: E731
     for _ in range(5):
         out = fn()
     torch.cuda.synchronize()
