@@ -27,7 +27,13 @@ FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=
 # cross-lane row sums (nlmeans_patch2_kernel) into v_pk_add_f32, which cannot take a DPP operand, so
 # every wave-shifted value then costs a v_mov_b32_dpp of its own; the kernel's packed arithmetic is
 # written with vector types and does not depend on that pass (config 3, signed mode: 54.8 -> 51.7 ms)
-PER_FILE = {'nlmeans.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_NLM_FLAGS', '').split()}
+# omnibus.hip: the same pass packs pairs of the scalar float32 products / sums of the determinants
+# into v_pk_mul_f32 / v_pk_add_f32, whose operands must sit in aligned register pairs: two to four
+# v_mov per packed instruction to assemble and take apart the pairs (45 of the 140 vector
+# instructions of one date of the streaming search were moves).  Without it: streaming search
+# 2.155 -> 2.089 ms, pass A 1.117 -> 1.082 ms (24 x 4096^2, tools/exp_ablate.py noslp).
+PER_FILE = {'nlmeans.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_NLM_FLAGS', '').split(),
+            'omnibus.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_OMNI_FLAGS', '').split()}
 
 
 def sources():

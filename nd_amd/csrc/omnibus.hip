@@ -1589,7 +1589,17 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         S22 += (double)q.d;
         Le += e0;
         Lm += m0;
-        if (t <= k - 2) {                                   // global test of ts[t:], j = k - t
+        // Branch-free: the three tests are evaluated at every date and their bits are kept only
+        // where the test exists (wave-uniform conditions folded into the masks).  A test skipped
+        // under a branch would be a control-flow join inside the date loop; see the loop below.
+        auto decide = [&](const float x, const float m2, const bool sane, const DenseScreenEntry &c,
+                          const bool exists, MT &fbits, MT &ibits) {
+            const bool fires = sane && (x + m2 < c.a);
+            const bool cant = sane && (x - m2 > c.b);
+            mask_set(fbits, t, exists && fires);
+            mask_set(ibits, t, exists && !(fires || cant));
+        };
+        {                                                   // global test of ts[t:], j = k - t >= 2
             const int jj = k - t;
             const double pp = S11 * S22;
             const double dets = pp - ((S12r * S12r) + (S12i * S12i));
@@ -1598,9 +1608,9 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
             const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
             const float qq = (float)pp * __builtin_amdgcn_rcpf((float)dets);
             const float rel = cu * (float)jj * qq;          // 1.46 * 5 n u * s11 s22 / det
-            screen_decide<T, MT>(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t, gF, gI);
+            decide(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t <= k - 2, gF, gI);
         }
-        if (t <= k - 3) {                                   // marginal tests over 2 and 3 dates
+        {                                                   // marginal tests over 2 and 3 dates
             // the reference's sums, in its type and order: (0 + a_t) + a_t+1 (+ a_t+2)
             T s11 = q.a + d1.a, s12r = q.b + d1.b, s12i = q.c + d1.c, s22 = q.d + d1.d;
             {
@@ -1608,9 +1618,9 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
                 const DenseScreenEntry c = screen_entry(scr, 2);
                 const float x = dense_x<T>(dets, oks, e0 + e1, m0 + m1, 2, c);
-                screen_decide<T, MT>(x, 0.f, oks, c, t, m2F, m2I);
+                decide(x, 0.f, oks, c, t <= k - 3, m2F, m2I);
             }
-            if (t <= k - 4) {
+            {
                 s11 = s11 + d2.a;
                 s12r = s12r + d2.b;
                 s12i = s12i + d2.c;
@@ -1619,7 +1629,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
                 const DenseScreenEntry c = screen_entry(scr, 3);
                 const float x = dense_x<T>(dets, oks, (e0 + e1) + e2, (m0 + m1) + m2q, 3, c);
-                screen_decide<T, MT>(x, 0.f, oks, c, t, m3F, m3I);
+                decide(x, 0.f, oks, c, t <= k - 4, m3F, m3I);
             }
         }
         d2 = d1;
@@ -1684,16 +1694,26 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
             }
         }
     } else {
-        for (int tb = k - 1; tb >= 0; tb -= PF) {
+        // Whole groups of PF dates first, with nothing conditional inside a group: a date that is
+        // skipped under a run-time condition is a control-flow join, and at every join the load
+        // ring and the three-date window travel through register moves (45 of the ~160 vector
+        // instructions per date, plus a scalar compare and branch for each condition).  The last
+        // groups re-read date 0 in place of the dates in front of the series (cache hits).
+        int tb = k - 1;
+        for (; tb >= PF - 1; tb -= PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int t = tb - u;
-                if (t >= 0) {
-                    const DateVal<T> q = ring[u];
-                    if (t - PF >= 0) ring[u] = rd.load(t - PF);          // keep PF dates in flight
-                    process(q, t);
-                }
+                const DateVal<T> q = ring[u];
+                ring[u] = rd.load(t >= PF ? t - PF : 0);                 // keep PF dates in flight
+                process(q, t);
             }
+        }
+        // what is left in front: fewer than PF dates
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb - u;
+            if (t >= 0) process(ring[u], t);
         }
     }
     // |log2| of every partial product stays below 900: the reference's double product neither
@@ -3033,6 +3053,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 32>), gridd, blockd, 0, sq,
                                reinterpret_cast<const OmniDenseArgs<float> &>(d), scr);
     };
+    const bool low_threshold = fused || stream_long || (pm_ids != nullptr && alpha < fused_alpha);
     auto launch_search = [&](hipStream_t sq, const uint32_t *count, const uint32_t *idx, const T *dump,
                              uint32_t seg, uint32_t dump_cap, int64_t npix_listed,
                              const unsigned long long *bits, int gate_mode_b,
@@ -3096,7 +3117,11 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             for (int j = 2; j <= (int)k; ++j)
                 if (!(scr.e[j].a > -INFINITY) && !(scr.e[j].b < INFINITY)) regs_ok = false;
         }
-        const bool regs_form = regs_ok && (mode_env < 0 || mode_env == 2);
+        // Where the search was fused into pass A (low thresholds), what reaches pass B are the few
+        // pixels its screen could not decide, and in that regime nearly every date of a pixel is a
+        // change: two dozen short segments, i.e. two dozen rounds of the register form against ~70
+        // date steps of the LDS form (measured at alpha = 0.01: 0.166 against 0.125 ms).
+        const bool regs_form = regs_ok && (mode_env == 2 || (mode_env < 0 && !low_threshold));
         if (regs_form) {
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
             s.hand_bits = hand;
@@ -3273,7 +3298,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             constexpr int PF = sizeof(T) == 4 ? 6 : 4;
             OmniPmDmaArgs<T> nopm;
             memset(&nopm, 0, sizeof(nopm));
-            if (g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0)
+            const bool buf1 = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
+            if (buf1)
                 hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1>), grid, block, 0, stream, g, tab, scr, nopm);
             else
                 hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0>), grid, block, 0, stream, g, tab, scr, nopm);

@@ -20,11 +20,10 @@ def child():
         kernels.change_detection(st[0], st[1], st[2], st[3], alpha=float(os.environ.get('EXP_ALPHA', '0.99')), n=9)
     torch.cuda.synchronize()
     kt = _lib.timing_collect()
-    a = [ms for n, ms in kt if n == 'omnibus_c2_global']
-    b = [ms for n, ms in kt if n == 'omnibus_c2_search']
-    d = [ms for n, ms in kt if n == 'omnibus_c2_dense'] or [0.0]
-    print(json.dumps({'passA_ms': round(sum(a) / len(a), 4), 'passB_ms': round(sum(b) / len(b), 4),
-                      'dense_ms': round(sum(d) / len(d), 4)}))
+    by = {}
+    for n, ms in kt:
+        by.setdefault(n, []).append(ms)
+    print(json.dumps({n: round(sum(v) / len(v), 4) for n, v in by.items()}))
 
 def build_variant(name, patches, extra=()):
     d = os.path.join(OUT, 'src_' + name)
@@ -68,12 +67,16 @@ VARIANTS = {
     't128': [("#define ND_RETAIN_THREADS 256", "#define ND_RETAIN_THREADS 128")],
 }
 
+# name -> extra hipcc flags
+EXTRA = {'noslp': ['-fno-slp-vectorize']}
+VARIANTS['noslp'] = []
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'child':
         child(); sys.exit(0)
     names = sys.argv[1:] or list(VARIANTS)
     for name in names:
-        so = build_variant(name, VARIANTS[name])
+        so = build_variant(name, VARIANTS[name], EXTRA.get(name, ()))
         env = dict(os.environ, ND_AMD_LIB=so)
         r = subprocess.run([sys.executable, __file__, 'child'], env=env, capture_output=True, text=True)
         print(name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-800:])
