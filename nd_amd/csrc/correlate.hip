@@ -154,6 +154,7 @@ struct TiledArgs {
     int64_t nbatch;             // planes
     int ppb;                    // planes one block walks through
     double w[kMaxKH * kMaxKH];  // dense KH x KW weights, row-major (0 = tap absent)
+    double cval;                // mode `constant`: the value of every sample outside the plane
 };
 
 // The block keeps its tile position and walks `ppb` consecutive planes of the batch: the border
@@ -189,12 +190,14 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     for (int i = tid; i < th + TW; i += 256) {
         // (scipy's reflect table yields -1 for offsets that are exact multiples of 2*len beyond
         // -2*len; clamp so that such a degenerate window can never index before the plane)
+        // mode `constant`: -1 marks a sample outside the plane; it is staged as cval (below) and its
+        // load goes to element 0
         if (i < th) {
             const int64_t m = extend_index(y_base + a.oy0 + i, a.ny, a.mode);
-            ymap[i] = m < 0 ? 0 : (int)m;
+            ymap[i] = m < 0 ? (a.mode == ND_AMD_MODE_CONSTANT ? -1 : 0) : (int)m;
         } else {
             const int64_t m = extend_index(x_base + a.ox0 + (i - th), a.nx, a.mode);
-            xmap[i - th] = m < 0 ? 0 : (int)m;
+            xmap[i - th] = m < 0 ? (a.mode == ND_AMD_MODE_CONSTANT ? -1 : 0) : (int)m;
         }
     }
     __syncthreads();
@@ -206,15 +209,22 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     constexpr int NE = ((kTileY + KHB - 1) * (KW - 1) + 255) / 256;
     const int wrow = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int c0 = tid & 127;
-    const int xo = xmap[c0];
+    const bool colok = xmap[c0] >= 0;
+    const int xo = colok ? xmap[c0] : 0;
     const int dlane = (c0 & 3) * TWQ + (c0 >> 2);
     int rowoff[NR];                // source offset of the row inside a plane (fits 31 bits, host)
+    unsigned long long rowok = 0ull;   // bit i: staged row wrow + 2 i lies inside the plane (wave-uniform)
+    static_assert(NR <= 64, "row validity bits");
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int r = wrow + 2 * i;
-        rowoff[i] = __builtin_amdgcn_readfirstlane(r < th ? ymap[r] * (int)a.sin_y : 0);
+        const int m = __builtin_amdgcn_readfirstlane(r < th ? ymap[r] : 0);
+        rowoff[i] = m < 0 ? 0 : m * (int)a.sin_y;
+        rowok |= m < 0 ? 0ull : (1ull << i);
     }
     int soff2[NE > 0 ? NE : 1], doff2[NE > 0 ? NE : 1];
+    unsigned edgeok = 0u;              // bit j: this thread's j-th edge element lies inside the plane
+    static_assert(NE <= 32, "edge validity bits");
     const int n_edge = th * (KW - 1);
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
@@ -223,10 +233,13 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
         doff2[j] = 0;
         if (e < n_edge) {
             const int r = e / (KW > 1 ? KW - 1 : 1), c = kTileX + (e - r * (KW - 1));
-            soff2[j] = ymap[r] * (int)a.sin_y + xmap[c];
+            const bool inside = ymap[r] >= 0 && xmap[c] >= 0;
+            soff2[j] = inside ? ymap[r] * (int)a.sin_y + xmap[c] : 0;
+            edgeok |= inside ? (1u << j) : 0u;
             doff2[j] = (r * 4 + (c & 3)) * TWQ + (c >> 2);
         }
     }
+    const double cval = a.cval;
 
     T buf[NR], buf2[NE > 0 ? NE : 1];
     auto load_plane = [&](int64_t bb) {
@@ -242,13 +255,13 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
 #pragma unroll
         for (int i = 0; i < NR; ++i)
             if (wrow + 2 * i < th) {
-                const double v = (double)buf[i];
+                const double v = (colok && ((rowok >> i) & 1ull)) ? (double)buf[i] : cval;
                 tile[(wrow + 2 * i) * 4 * TWQ + dlane] = BOX ? wbox * v : v;
             }
 #pragma unroll
         for (int j = 0; j < NE; ++j)
             if (tid + 256 * j < n_edge) {
-                const double v = (double)buf2[j];
+                const double v = ((edgeok >> j) & 1u) ? (double)buf2[j] : cval;
                 tile[doff2[j]] = BOX ? wbox * v : v;
             }
     };
@@ -673,10 +686,10 @@ int try_roll<float>(const void *in, void *out, const int64_t dims[4], const int6
 template <typename T>
 static int try_tiled(const void *in, void *out, const int64_t dims[4], const int64_t si[4],
                      const int64_t so[4], int64_t ntaps, const int64_t *offsets,
-                     const double *weights, int mode, hipStream_t stream)
+                     const double *weights, int mode, double cval, hipStream_t stream)
 {
     static const bool disabled = getenv("ND_AMD_NO_TILED") != nullptr;
-    if (disabled || ntaps < 1 || mode == ND_AMD_MODE_CONSTANT) return 0;
+    if (disabled || ntaps < 1) return 0;
     if (si[3] != 1 || so[3] != 1) return 0;
     int64_t ymin = 0, ymax = 0, xmin = 0, xmax = 0;
     for (int64_t t = 0; t < ntaps; ++t) {
@@ -697,10 +710,12 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
             if (oy < py || (oy == py && ox <= px)) return 0;
         }
     }
-    const int64_t kh = ymax - ymin + 1, kw = xmax - xmin + 1;
-    if (kh > kMaxKH || kw > kMaxKH || (kw != 1 && kw != 3 && kw != 5 && kw != 7 && kw != 9 &&
-                                        kw != 11 && kw != 13 && kw != 15))
-        return 0;
+    // An even-width window (scipy shifts its origin, nd_amd.kernels.footprint) runs as the next odd
+    // width with one absent column on the right: absent taps are skipped like scipy's dropped
+    // zero weights, so the sums are the same, term for term.
+    const int64_t kh = ymax - ymin + 1, kw_taps = xmax - xmin + 1;
+    const int64_t kw = (kw_taps & 1) ? kw_taps : kw_taps + 1;
+    if (kh > kMaxKH || kw > kMaxKH) return 0;
     if (dims[2] < 1 || dims[3] < 1 || dims[2] > 0x7fffffffLL || dims[3] > 0x7fffffffLL) return 0;
     // windows reaching farther than twice the plane from it hit the non-periodic corner of
     // scipy's offset table: leave those to the generic kernel, which restates the table as is
@@ -735,6 +750,7 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     a.oy0 = (int)ymin;
     a.ox0 = (int)xmin;
     a.mode = mode;
+    a.cval = cval;
     a.tiles_x = (int)ceil_div(dims[3], kTileX);
     a.tiles_y = (int)ceil_div(dims[2], kTileY);
     for (int i = 0; i < kMaxKH * kMaxKH; ++i) a.w[i] = 0.0;
@@ -810,7 +826,7 @@ static int correlate_impl(const void *in, void *out, const int64_t dims[4], cons
     a.taps_dev = nullptr;
     if (a.total == 0) return ND_AMD_OK;
     if (try_roll<T>(in, out, dims, si, so, ntaps, offsets, weights, mode, stream) ||
-        try_tiled<T>(in, out, dims, si, so, ntaps, offsets, weights, mode, stream)) {
+        try_tiled<T>(in, out, dims, si, so, ntaps, offsets, weights, mode, cval, stream)) {
         ND_HIP_CHECK(hipGetLastError());
         return ND_AMD_OK;
     }

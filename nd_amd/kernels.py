@@ -430,7 +430,7 @@ def convolve(inp, kernel, out=None, mode='reflect', cval=0.0, origin=0):
     nd = inp.dim()
     span = [d for d in range(nd) if kernel.shape[d] > 1]
     tail = list(range(nd - len(span), nd))
-    if (0 < len(span) <= 2 and nd <= 4 and mode != 'constant'
+    if (0 < len(span) <= 2 and nd <= 4
             and (span != tail or inp.stride(-1) != 1 or out.stride(-1) != 1)
             and inp.numel() >= (1 << 16)):
         perm = [d for d in range(nd) if d not in span] + span

@@ -183,3 +183,33 @@ def test_output_may_alias_input(device):
     t = torch.from_numpy(a.copy()).to(device)
     kernels.gaussian_filter(t, (0, 1, 1), out=t)
     np.testing.assert_array_equal(t.cpu().numpy(), ndi.gaussian_filter(a, (0, 1, 1)))
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_even_widths_and_constant_mode_in_the_tiled_kernel(device, dtype):
+    """BoxcarFilter(w=4) / (w=6), even random kernels and mode='constant' (nd/filters.py:226 forwards
+    any scipy keyword) on planes larger than one 128 x 32 tile, with infinities and NaNs in the data:
+    an absent tap must not contribute 0 * inf.  Bit-equal to scipy."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(21)
+    a = rng.gamma(4.0, 0.25, (3, 150, 300)).astype(dtype)
+    a[0, 10, 20] = np.inf
+    a[1, 149, 299] = np.nan
+    a[2, 0, 0] = -np.inf
+    cases = [(np.ones((1, 4, 4)) / 16.0, {}), (np.ones((1, 6, 6)) / 36.0, {}),
+             (rng.normal(size=(1, 4, 6)), {}), (rng.normal(size=(1, 5, 2)), {'mode': 'nearest'}),
+             (np.ones((1, 5, 5)) / 25.0, {'mode': 'constant', 'cval': 0.0}),
+             (rng.normal(size=(1, 3, 3)), {'mode': 'constant', 'cval': 2.5}),
+             (rng.normal(size=(1, 4, 4)), {'mode': 'constant', 'cval': -1.0}),
+             (rng.normal(size=(1, 7, 14)), {'mode': 'wrap'})]
+    with np.errstate(all='ignore'):
+        for k, kw in cases:
+            want = ndi.convolve(a, k, **kw)
+            got = _gpu_convolve(a, k, device, **kw)
+            np.testing.assert_array_equal(got, want)
+    # the reference's own layout: (y, x, time), window over the two leading axes
+    b = np.ascontiguousarray(np.moveaxis(a, 0, -1))
+    with np.errstate(all='ignore'):
+        for k, kw in cases[:2] + cases[4:6]:
+            k3 = np.moveaxis(k, 0, -1)
+            np.testing.assert_array_equal(_gpu_convolve(b, k3, device, **kw), ndi.convolve(b, k3, **kw))
