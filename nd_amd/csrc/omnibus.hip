@@ -535,10 +535,13 @@ __global__ void __launch_bounds__(kRetainThreads) omnibus_c2_sample_kernel(const
     const int64_t off0 = row * a.sy + (in ? x0 : a.nx - 1) * a.sx;
     Accum<T> A;
     A.reset();
-    for (int t0 = 0; t0 < a.k; t0 += 4) {
-        T q[4][4];
+    // (twelve dates = 48 loads in flight per thread: the kernel is a few dependent round trips to
+    // memory and nothing else, and everything behind it waits for its verdict)
+    constexpr int CH = 12;
+    for (int t0 = 0; t0 < a.k; t0 += CH) {
+        T q[CH][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CH; ++u) {
             const int64_t o = off0 + (int64_t)(t0 + u < a.k ? t0 + u : a.k - 1) * a.st;
             q[u][0] = a.c11[o * a.m11];
             q[u][1] = a.c12r[o * a.m12];
@@ -546,12 +549,22 @@ __global__ void __launch_bounds__(kRetainThreads) omnibus_c2_sample_kernel(const
             q[u][3] = a.c22[o * a.m22];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < CH; ++u)
             if (t0 + u < a.k) A.step(q[u][0], q[u][1], q[u][2], q[u][3]);
     }
     const bool flag = in && (z_approx<T>(A, a.k, a.nlooks, a.e) >= a.e.zlo_a);
+    // one atomic per block: all of them hit one address, which serialises them (one per wave: 2048
+    // atomics at ~88 per microsecond were more than half of this kernel's 41 microseconds)
+    __shared__ unsigned wave_hits[kRetainThreads / 64];
     const unsigned long long m = __ballot(flag);
-    if ((tid & 63) == 0 && m != 0ull) atomicAdd(a.gate_out, (unsigned)__popcll(m));
+    if ((tid & 63) == 0) wave_hits[tid >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned hits = 0;
+#pragma unroll
+        for (int w = 0; w < kRetainThreads / 64; ++w) hits += wave_hits[w];
+        if (hits != 0u) atomicAdd(a.gate_out, hits);
+    }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -3139,8 +3152,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }
         // the exact form: every listed pixel, or (behind the register form) the marked ones
         KernelTimer timer(regs_form ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
-        const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : (use_lds ? 0 : 1);
-        // (behind the register form there is usually nothing left: a quarter of the blocks)
+        // (behind the register form there is usually nothing left: the from-memory form, whose
+        // blocks reserve no LDS, and a quarter of the blocks)
+        const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !regs_form) ? 0 : 1);
         const int64_t xblocks = regs_form ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
         if (mode == 0 && use_lds)
             hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0>), dim3((unsigned)xblocks), dim3(64),
