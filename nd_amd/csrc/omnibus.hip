@@ -158,26 +158,7 @@ struct OmniGlobalArgs {
     const uint32_t *gate;
     uint32_t gate_n;
     int gate_mode;
-    // Where the change map is zero-filled (np.zeros at nd/_change.pyx:275).  bits == nullptr: by
-    // this kernel, inside its own HBM-bound stream.  bits != nullptr (flat rasters, the
-    // register-retaining forms): NOT here -- every wave leaves one word of a 1-bit-per-pixel map
-    // instead (bit set <=> the pixel's row is written in full by whoever searches it: pass B for a
-    // listed pixel, the dense kernel for all 64 pixels of a dense wave), and pass B, which is
-    // latency-bound and leaves the memory system idle, zero-fills every other row in the shadow of
-    // its search (fill_unlisted).
-    unsigned long long *bits;
-    // first block of this launch (the row-slab pipeline launches the register-retaining pass A over
-    // one range of blocks at a time, see omni_pipeline)
-    int64_t block_base;
 };
-
-// one word of the listed-pixel map per wave: pixels 64 w .. 64 w + 63 of the flat raster
-__device__ __forceinline__ void store_listed_word(unsigned long long *bits, const int64_t wave_px0,
-                                                  const int64_t npix, const unsigned long long word,
-                                                  const int lane)
-{
-    if (lane == 0 && wave_px0 < npix) bits[wave_px0 >> 6] = word;
-}
 
 // dense <=> at least 1/8 of the sampled pixels pass the global screen (measured break-even of
 // pass A + pass B against the fused kernel: ~10 % candidates)
@@ -369,7 +350,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
     if (omni_gate_skip(g)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int64_t b = g.block_base + blockIdx.x;
+    const int64_t b = blockIdx.x;
     const int64_t row = b / g.blocks_per_row;
     const int64_t bx = b - row * g.blocks_per_row;
     const int64_t bpx0 = bx * (int64_t)kRetainThreads;
@@ -479,11 +460,6 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
         }
     }
 
-    if (g.bits != nullptr) {
-        // the change map is zero-filled by pass B (flat raster: row == 0, g.nx pixels in all)
-        store_listed_word(g.bits, bpx0 + (tid & ~63), g.nx, dense_wave ? ~0ull : m, lane);
-        return;
-    }
     // ---- zero-fill this block's slice of the change map (np.zeros at nd/_change.pyx:275).
     // Issued last so that no wait on the loads or on the atomic above also has to wait for
     // these stores (vmcnt retires in order). ----
@@ -729,10 +705,6 @@ omnibus_c2_retain_pm_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const 
         }
     }
 
-    if (g.bits != nullptr) {
-        store_listed_word(g.bits, bpx0 + (tid & ~63), g.nx, dense_wave ? ~0ull : m, lane);
-        return;
-    }
     // ---- zero-fill this block's slice of the change map (np.zeros at nd/_change.pyx:275).
     // Issued last so that no wait on the loads or on the atomic above also has to wait for
     // these stores (vmcnt retires in order). ----
@@ -915,10 +887,6 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
                 }
             }
         }
-    }
-    if (g.bits != nullptr) {
-        store_listed_word(g.bits, px0, g.nx, m, lane);        // pass B zero-fills the change map
-        return;
     }
     // ---- zero-fill this wave's slice of the change map (np.zeros at nd/_change.pyx:275) ----
     zero_fill_span(g.change + px0 * (int64_t)k, np * k, lane);
@@ -1122,8 +1090,7 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
     handoff_out = handoff;
 }
 
-// One lane's whole row of the change map from its mask: every byte is written (in a dense wave
-// nobody else writes the rows -- pass B's zero-fill skips all 64 pixels, see OmniGlobalArgs::bits).
+// One lane's whole row of the change map from its mask: every byte is written.
 __device__ __forceinline__ void store_change_row(uint8_t *res, const int k, const unsigned long long mask)
 {
     if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {   // rows start on 4-byte boundaries: whole words
@@ -1905,16 +1872,6 @@ struct OmniSearchArgs {
     const OmniTabEntry *tab;
     const T *dump;
     uint32_t dump_cap;
-    // listed-pixel map of pass A (OmniGlobalArgs::bits), or nullptr when the map was zero-filled
-    // upstream.  When pass A ran behind the density gate (gate_mode 2 = "only if the sample is
-    // sparse"), the fused kernel may have run in its place: then there is no bit map and the map is
-    // already filled -- the same test as omni_gate_skip decides it here.
-    const unsigned long long *bits;
-    int64_t npix;
-    unsigned long long magic_k;   // ceil(2^64 / k): byte offset -> pixel without a division
-    const uint32_t *gate;
-    uint32_t gate_n;
-    int gate_mode;
     // Hand-over between the register form and the exact form of pass B: one word per 64 list
     // entries of a shard (bit = the screen could not decide a test of that pixel).  The register
     // form writes every word of the lists it walks; the LDS form, run behind it with the same
@@ -1922,203 +1879,6 @@ struct OmniSearchArgs {
     unsigned long long *hand_bits;
     uint32_t hand_words;          // words per shard
     uint32_t *hand_count;         // number of marked pixels (zeroed with the list counters)
-};
-
-// ---- the zero-fill of the change map, done by pass B --------------------------------------
-// The map is npix * k bytes; the blocks of the search kernel share it in 16-byte pieces.  A piece
-// is stored whole when none of the (one or two, for short series a few more) pixels it touches is
-// listed; otherwise only the bytes of its unlisted pixels are.  A block first fetches the words
-// of the bit map its slice needs into LDS (at most 64 words = 4096 pixels per round), so that no
-// load has to wait behind the stores (vmcnt retires in order): the stores are never waited on.
-__device__ __forceinline__ int64_t fill_pixel_of(const int64_t byte, const unsigned long long magic_k)
-{
-    return (int64_t)__umul64hi((unsigned long long)byte, magic_k);
-}
-
-__device__ __forceinline__ void fill_unlisted(uint8_t *change, const int64_t npix, const int k,
-                                              const unsigned long long magic_k,
-                                              const unsigned long long *bits,
-                                              unsigned long long *sbits /* LDS, 64 words */,
-                                              const int lane, const int64_t block, const int64_t nblocks)
-{
-    const int64_t nbytes = npix * (int64_t)k;
-    int64_t head = (int64_t)((16 - ((uintptr_t)change & 15)) & 15);
-    if (head > nbytes) head = nbytes;
-    const int64_t nvec = (nbytes - head) >> 4;
-    const int64_t tail0 = head + (nvec << 4);
-    const int64_t nwords = (npix + 63) >> 6;
-    // pieces per block, a multiple of 64; pieces per round: their pixels span at most 63 words
-    int64_t cpb = (nvec + nblocks - 1) / nblocks;
-    cpb = (cpb + 63) & ~(int64_t)63;
-    int64_t per_round = ((int64_t)63 * 64 * k / 16) & ~(int64_t)63;
-    if (per_round < 64) per_round = 64;              // k = 1: 64 pieces = 1024 pixels = 17 words
-    const int64_t c_begin = block * cpb;
-    int64_t c_end = c_begin + cpb;
-    if (c_end > nvec) c_end = nvec;
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const u4 zero4 = {0u, 0u, 0u, 0u};
-    for (int64_t r0 = c_begin; r0 < c_end; r0 += per_round) {
-        int64_t r1 = r0 + per_round;
-        if (r1 > c_end) r1 = c_end;
-        const unsigned w0 = (unsigned)(fill_pixel_of(head + (r0 << 4), magic_k) >> 6);
-        {
-            const int64_t w = (int64_t)w0 + lane;
-            const unsigned long long word = w < nwords ? bits[w] : 0ull;
-            sbits[lane] = word;                      // (its vmcnt wait comes after the previous
-        }                                            //  round's stores: one round in all but short series)
-        // (one wave: its LDS write is seen by its own later reads, whichever lane issues them)
-        __builtin_amdgcn_wave_barrier();
-        auto listed = [&](const unsigned q) -> bool {
-            return (sbits[(q >> 6) - w0] >> (q & 63u)) & 1ull;
-        };
-        if (k >= 16) {
-            // a piece touches one or two pixels; (pixel, offset inside its row) advance by a
-            // constant step of 1024 bytes per trip: no division inside the loop
-            int64_t c = r0 + lane;
-            const int64_t o0 = head + (c << 4);
-            unsigned pix = (unsigned)fill_pixel_of(o0, magic_k);
-            unsigned rem = (unsigned)(o0 - (int64_t)pix * k);
-            const unsigned dq = 1024u / (unsigned)k, dr = 1024u % (unsigned)k;
-            uint8_t *dst = change + o0;
-            for (; c < r1; c += 64) {
-                const bool two = rem + 15u >= (unsigned)k && pix + 1u < (unsigned)npix;
-                const bool l0 = listed(pix);
-                const bool l1 = two && listed(pix + 1u);
-                if (!(l0 || l1)) {
-                    __builtin_nontemporal_store(zero4, reinterpret_cast<u4 *>(dst));
-                } else {
-                    const unsigned first = (unsigned)k - rem;      // bytes of this piece in pixel `pix`
-                    if ((k & 3) == 0) {                            // rows are whole words
-                        uint32_t *dw = reinterpret_cast<uint32_t *>(dst);
-#pragma unroll
-                        for (unsigned i = 0; i < 4u; ++i)
-                            if (!(4u * i < first ? l0 : l1)) dw[i] = 0u;
-                    } else {
-                        for (unsigned i = 0; i < 16u; ++i)
-                            if (!(i < first ? l0 : l1)) dst[i] = 0;
-                    }
-                }
-                dst += 1024;
-                pix += dq;
-                rem += dr;
-                if (rem >= (unsigned)k) {
-                    rem -= (unsigned)k;
-                    pix += 1u;
-                }
-            }
-        } else {
-            for (int64_t c = r0 + lane; c < r1; c += 64) {
-                const int64_t o = head + (c << 4);
-                const unsigned p0 = (unsigned)fill_pixel_of(o, magic_k);
-                unsigned p1 = (unsigned)fill_pixel_of(o + 15, magic_k);
-                if (p1 > (unsigned)(npix - 1)) p1 = (unsigned)(npix - 1);
-                bool any = false;
-                for (unsigned q = p0; q <= p1; ++q) any = any || listed(q);
-                if (!any) {
-                    __builtin_nontemporal_store(zero4, reinterpret_cast<u4 *>(change + o));
-                } else {
-                    for (int i = 0; i < 16; ++i)
-                        if (!listed((unsigned)fill_pixel_of(o + i, magic_k))) change[o + i] = 0;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();             // sbits is rewritten by the next round
-    }
-    // unaligned ends of the map (at most 15 bytes each): block 0, bits straight from memory
-    if (block == 0 && lane < 32 && (head > 0 || tail0 < nbytes)) {
-        const int64_t o = lane < 16 ? (int64_t)lane : tail0 + (lane - 16);
-        const bool mine = lane < 16 ? (o < head) : (o < nbytes);
-        if (mine) {
-            const int64_t q = fill_pixel_of(o, magic_k);
-            if (!((bits[q >> 6] >> (q & 63)) & 1ull)) change[o] = 0;
-        }
-    }
-}
-
-// The same fill, paced: one 16-byte piece per lane and call, so that the search loop of pass B can
-// issue it a store at a time (all of a block's pieces at once saturate the write path for as long
-// as the fill takes, and the waves of that round then search behind one another's stores: measured
-// 0.135 -> 0.25 ms; spread over the ~70 trips of the search the memory system takes them as they come).
-// Serves series of at least 16 dates whose slice needs one round of the bit map; the rest is filled
-// up front by fill_unlisted.
-struct FillPaced {
-    uint8_t *dst;
-    unsigned pix, rem, w0, dq, dr, k, npix;
-    int left;
-    const unsigned long long *sb;
-    __device__ __forceinline__ bool init(uint8_t *change, const int64_t npix_, const int k_,
-                                         const unsigned long long magic_k, const unsigned long long *bits,
-                                         unsigned long long *sbits, const int lane, const int64_t block,
-                                         const int64_t nblocks)
-    {
-        left = 0;
-        const int64_t nbytes = npix_ * (int64_t)k_;
-        int64_t head = (int64_t)((16 - ((uintptr_t)change & 15)) & 15);
-        if (head > nbytes) head = nbytes;
-        const int64_t nvec = (nbytes - head) >> 4;
-        int64_t cpb = (nvec + nblocks - 1) / nblocks;
-        cpb = (cpb + 63) & ~(int64_t)63;
-        const int64_t per_round = ((int64_t)63 * 64 * k_ / 16) & ~(int64_t)63;
-        if (k_ < 16 || cpb > per_round || head != 0 || (nbytes & 15) != 0) return false;
-        const int64_t c_begin = block * cpb;
-        int64_t c_end = c_begin + cpb;
-        if (c_end > nvec) c_end = nvec;
-        const int64_t nwords = (npix_ + 63) >> 6;
-        w0 = (unsigned)(fill_pixel_of(c_begin << 4, magic_k) >> 6);
-        const int64_t w = (int64_t)w0 + lane;
-        sbits[lane] = (c_begin < c_end && w < nwords) ? bits[w] : 0ull;
-        __builtin_amdgcn_wave_barrier();
-        sb = sbits;
-        const int64_t c = c_begin + lane;
-        const int64_t o0 = c << 4;
-        k = (unsigned)k_;
-        npix = (unsigned)npix_;
-        pix = (unsigned)fill_pixel_of(o0, magic_k);
-        rem = (unsigned)(o0 - (int64_t)pix * k_);
-        dq = 1024u / k;
-        dr = 1024u % k;
-        dst = change + o0;
-        left = c < c_end ? (int)((c_end - c + 63) >> 6) : 0;
-        return true;
-    }
-    __device__ __forceinline__ bool listed(const unsigned q) const
-    {
-        return (sb[(q >> 6) - w0] >> (q & 63u)) & 1ull;
-    }
-    __device__ __forceinline__ void step()
-    {
-        if (left > 0) {
-            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-            const u4 zero4 = {0u, 0u, 0u, 0u};
-            const bool two = rem + 15u >= k && pix + 1u < npix;
-            const bool l0 = listed(pix);
-            const bool l1 = two && listed(pix + 1u);
-            if (!(l0 || l1)) {
-                __builtin_nontemporal_store(zero4, reinterpret_cast<u4 *>(dst));
-            } else {
-                // (most trips of a wave meet a listed pixel in one of its 64 pieces: this side of
-                // the branch must stay short -- as a loop of 16 byte stores it doubled pass B)
-                const unsigned first = k - rem;            // bytes of this piece in pixel `pix`
-                if ((k & 3u) == 0u) {                      // rows are whole words: four word stores
-                    uint32_t *dw = reinterpret_cast<uint32_t *>(dst);
-#pragma unroll
-                    for (unsigned i = 0; i < 4u; ++i)
-                        if (!(4u * i < first ? l0 : l1)) dw[i] = 0u;
-                } else {
-                    for (unsigned i = 0; i < 16u; ++i)
-                        if (!(i < first ? l0 : l1)) dst[i] = 0;
-                }
-            }
-            dst += 1024;
-            pix += dq;
-            rem += dr;
-            if (rem >= k) {
-                rem -= k;
-                pix += 1u;
-            }
-            left -= 1;
-        }
-    }
 };
 
 // MODE 0: series staged in LDS; MODE 1: no LDS, each date read straight from the dump (or the
@@ -2129,22 +1889,9 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
 {
     constexpr bool USE_LDS = (MODE == 0);
     extern __shared__ __align__(16) unsigned char nd_smem[];
-    __shared__ unsigned long long sbits[64];
     T *lds = reinterpret_cast<T *>(nd_smem);
     const int lane = threadIdx.x;
     const int k = s.k;
-    // does this launch zero-fill the change map (see OmniGlobalArgs::bits)?
-    bool fill = s.bits != nullptr;
-    if (fill && s.gate_mode != 0) {
-        const uint32_t hits = __builtin_nontemporal_load(s.gate);
-        const bool dense = hits * 8u >= s.gate_n;
-        if ((s.gate_mode == 1) != dense) fill = false;     // pass A did not run: nothing to fill
-    }
-    // changes of a listed pixel are collected in a mask and its row is written whole at the end
-    // (k <= 64; longer series are never part of the fill protocol and write their ones directly)
-    const bool row_mask = k <= 64;
-    FillPaced fp;
-    fp.left = 0;
     // Per-j constants of the screen (m2rho, pklogk, zlo_a, zhi_a): every lane looks up its own j
     // in every iteration, so they sit in LDS as four separate arrays of doubles -- consecutive j in
     // consecutive banks (as 64-byte records all j of one parity would share a bank).
@@ -2189,11 +1936,6 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
         const int64_t col = pix - row * s.nx;
         const int64_t off = row * s.sy + col * s.sx;
 
-        if (!USE_LDS && fill) {
-            // (no staging in this mode: the fill goes first, the search's loads wait behind it once)
-            fill_unlisted(s.change, s.npix, k, s.magic_k, s.bits, sbits, lane, blockIdx.x, gridDim.x);
-            fill = false;
-        }
         if (USE_LDS) {
             // stage this lane's series: lds[(t*4+v)*64 + lane]; each lane reads back only its
             // own column, so no barrier is needed.  Source: the dump pass A wrote (one 16/32-byte
@@ -2279,19 +2021,6 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
         // which a marginal test fires, and commits it only if the global test -- known at the end
         // of the sweep -- passes.  Every iteration of the wave is then the same small body (one
         // date + at most one test per lane), whatever segment each lane is in.
-        // Every load issued so far has to be back BEFORE the first store of the fill goes out, on
-        // either side of the branch: the counter of outstanding vector-memory operations retires in
-        // order, so a later wait for an earlier load (the pixel index, say) would be a wait for every
-        // store of the fill as well (measured: pass B 0.14 -> 0.51 ms).
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), gfx9 encoding
-        if (fill) {
-            // The block's share of the zero-fill, behind the staging loads: a store per trip of the
-            // search loop (which otherwise touches LDS only), or -- short series, unaligned maps --
-            // all of it here, to drain while the wave searches.
-            if (!fp.init(s.change, s.npix, k, s.magic_k, s.bits, sbits, lane, blockIdx.x, gridDim.x))
-                fill_unlisted(s.change, s.npix, k, s.magic_k, s.bits, sbits, lane, blockIdx.x, gridDim.x);
-            fill = false;
-        }
         Accum<T> A;
         A.reset();
         int l = 0;                 // segment start
@@ -2299,10 +2028,8 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
         int fire_at = -1;          // first date of this segment whose marginal test fired
         bool done = !active;
         uint8_t *res = s.change + pix * (int64_t)k;
-        unsigned long long cmask = 0ull;
 
         while (__any(!done)) {
-            fp.step();
             if (!done) {
                 load_step(A, t);
                 const int jj = t - l + 1;
@@ -2345,10 +2072,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     // `fires` is the global test of ts[l:] (for jj == 1 there is nothing to test)
                     if (fires && fire_at < 0) fire_at = t;
                     if (fires && jj >= 2) {
-                        if (row_mask)
-                            cmask |= 1ull << fire_at;      // :252, l + r with r = j - 1
-                        else
-                            res[fire_at] = 1;
+                        res[fire_at] = 1;                  // :252, l + r with r = j - 1
                         l = fire_at;                       // :255
                         if (l >= k - 1) {
                             done = true;                   // :256
@@ -2363,16 +2087,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                 }
             }
         }
-        if (row_mask && active) {
-            if (s.bits != nullptr)
-                store_change_row(res, k, cmask);           // nobody else writes this row
-            else
-                for (int u = 1; u < k; ++u)                // the row was zero-filled upstream
-                    if ((cmask >> u) & 1ull) res[u] = 1;
-        }
     }
-    if (fill) fill_unlisted(s.change, s.npix, k, s.magic_k, s.bits, sbits, lane, blockIdx.x, gridDim.x);
-    while (__any(fp.left > 0)) fp.step();
 }
 
 // -----------------------------------------------------------------------------------------
@@ -2636,11 +2351,8 @@ omnibus_c2_search_regs_kernel(const OmniSearchArgs<T> s, const DenseScreen scr_a
         }
         if (active && !handoff) {
             uint8_t *res = s.change + pix * (int64_t)k;
-            if (s.bits != nullptr)
-                store_change_row(res, k, (unsigned long long)cmask);    // nobody else writes this row
-            else
-                for (int u = 1; u < k; ++u)                // the row was zero-filled upstream
-                    if ((cmask >> u) & 1u) res[u] = 1;
+            for (int u = 1; u < k; ++u)                    // the row was zero-filled by pass A
+                if ((cmask >> u) & 1u) res[u] = 1;
         }
     }
 }
@@ -2684,16 +2396,13 @@ std::vector<OmniTabEntry> get_table_impl(int k, uint32_t n_looks, double alpha, 
 // recommended size holds the series of 1/8 of the pixels (a listed pixel beyond the capacity is
 // gathered from the planes by pass B instead: slower, never wrong).
 struct OmniWorkspace {
-    size_t off_count, off_tab, off_idx, off_dense, off_bits, off_hand, off_dump, min_total, recommended;
+    size_t off_count, off_tab, off_idx, off_dense, off_hand, off_dump, min_total, recommended;
     uint32_t segd, hand_words;
 };
 
 constexpr int kRetainMaxF32 = 48, kRetainMaxF64 = 24;
 
 constexpr size_t kCounterBytes = (size_t)kShards * kCounterStride * sizeof(uint32_t);
-// row-slab pipeline (omni_pipeline): every slab has its own counters, list segments and dump part
-constexpr int kMaxSlabs = 8;
-constexpr uint32_t kSlabSegExtra = 1300, kSlabSegdExtra = 32;   // per shard and slab, see omni_layout
 
 // List entries per shard: an upper bound on the pixels of the blocks one shard can receive,
 // valid for both pass-A forms (256-pixel blocks, or 256*VPPT-pixel blocks with VPPT <= 4) and for
@@ -2710,20 +2419,14 @@ static OmniWorkspace omni_layout(int64_t npix, int64_t ny, int64_t k, size_t ele
 {
     OmniWorkspace w;
     w.off_count = 0;
-    w.off_tab = align256(kCounterBytes * kMaxSlabs);
+    w.off_tab = align256(kCounterBytes);
     w.off_idx = w.off_tab + align256((size_t)(k + 1) * sizeof(OmniTabEntry));
-    // S slabs of n_s pixels each need S * omni_seg(n_s, 1) <= omni_seg(npix, ny) + 1292 S entries
-    // per shard (omni_seg is affine in the pixel count), the dense lists S * (seg_s / 64 + 8)
-    w.off_dense = w.off_idx + align256((size_t)(omni_seg(npix, ny) + kMaxSlabs * kSlabSegExtra) *
-                                       kShards * sizeof(uint32_t));
+    w.off_dense = w.off_idx + align256((size_t)omni_seg(npix, ny) * kShards * sizeof(uint32_t));
     // dense-wave list: at most one entry per 64 listed pixels of a shard
     w.segd = omni_seg(npix, ny) / 64 + 8;
-    // listed-pixel map: one bit per pixel (OmniGlobalArgs::bits)
-    w.off_bits = w.off_dense + align256((size_t)(w.segd + kMaxSlabs * kSlabSegdExtra) * kShards *
-                                        sizeof(uint32_t));
-    w.off_hand = w.off_bits + align256((size_t)ceil_div(npix, 64) * sizeof(unsigned long long) + 8);
+    w.off_hand = w.off_dense + align256((size_t)w.segd * kShards * sizeof(uint32_t));
     // hand-over marks of the register form of pass B: one bit per list entry (OmniSearchArgs::hand_bits)
-    w.hand_words = (omni_seg(npix, ny) + kMaxSlabs * kSlabSegExtra) / 64 + kMaxSlabs + 1;
+    w.hand_words = omni_seg(npix, ny) / 64 + 1;
     w.off_dump = w.off_hand + align256((size_t)w.hand_words * kShards * sizeof(unsigned long long));
     w.min_total = w.off_dump;
     const size_t per = (size_t)k * 4 * elem;
@@ -2822,38 +2525,6 @@ static void launch_retain(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_
     }
 }
 
-// ---- row-slab pipeline: pass B of slab s runs beside pass A of slab s + 1 -----------------
-// Pass A is HBM-bound and leaves the vector ALUs idle; pass B is latency-bound (1.5 waves per
-// SIMD around a 24.5 KB LDS image per wave) and leaves the memory system idle.  Run one after
-// the other they cost A + B.  Here the raster is cut into row slabs with their own candidate
-// lists: pass A walks the slabs one launch after the other on the caller's stream, and the
-// search of a finished slab is queued on a second, library-owned stream behind an event, where
-// it shares the device with the next slab's pass A.  The last slab's search runs on the
-// caller's stream, which finally waits for the second stream.  No state survives the call.
-struct OmniAux {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork[kMaxSlabs] = {}, join = nullptr;
-    bool ok = false;
-};
-
-static std::mutex g_aux_mu;       // also keeps each record / wait pair of a call together
-
-static OmniAux *omni_aux()
-{
-    static OmniAux per_device[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    OmniAux &a = per_device[dev];
-    if (!a.ok) {
-        if (hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (int i = 0; i < kMaxSlabs; ++i)
-            if (hipEventCreateWithFlags(&a.fork[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        a.ok = true;
-    }
-    return &a;
-}
-
 template <typename T>
 static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im, const void *c22,
                            int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int64_t st,
@@ -2894,7 +2565,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         ND_HIP_CHECK(e);
     }
 
-    ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes * kMaxSlabs, stream));
+    ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
 
     // ---- pass A ----
     OmniGlobalArgs<T> g;
@@ -2954,7 +2625,6 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     g.gate = flag_count + 2;            // word 2 of shard 0's counter line (zeroed with the counters)
     g.gate_n = 0;
     g.gate_mode = 0;
-    g.block_base = 0;
     {
         const size_t per = (size_t)k * 4 * sizeof(T);
         size_t cap = retain ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
@@ -2973,18 +2643,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     const bool flat = ((sx == 1) && (sy == nx)) || pm_ids != nullptr;
     g.nx = flat ? npix : nx;
     g.nrows = flat ? 1 : ny;
-    // The change map's zero-fill moves from pass A into pass B (OmniGlobalArgs::bits) for flat
-    // rasters in the register-retaining sizes; ND_AMD_FILL_IN_B=0 keeps it in pass A.  Same map.
-    static const bool fill_in_b_env = [] {
-        const char *e = getenv("ND_AMD_FILL_IN_B");
-        return e ? atoi(e) != 0 : false;
-    }();
-    unsigned long long *const bits_ws = reinterpret_cast<unsigned long long *>(ws + w.off_bits);
     unsigned long long *const hand_ws = reinterpret_cast<unsigned long long *>(ws + w.off_hand);
-    const bool bits_ok = fill_in_b_env && retain && flat && k >= 2 && k <= 64;
-    g.bits = bits_ok ? bits_ws : nullptr;
-    bool b_fill = false;          // did a pass A that leaves the fill to pass B feed this call's lists?
-    int b_gate_mode = 0;
     const int ppt = retain ? 1 : (aligned ? VPPT : 1);
     g.blocks_per_row = ceil_div(g.nx, retain ? (int64_t)kRetainThreads : (int64_t)kGlobalThreads * ppt);
     const int64_t nblocks = g.blocks_per_row * g.nrows;
@@ -3069,7 +2728,6 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     const bool low_threshold = fused || stream_long || (pm_ids != nullptr && alpha < fused_alpha);
     auto launch_search = [&](hipStream_t sq, const uint32_t *count, const uint32_t *idx, const T *dump,
                              uint32_t seg, uint32_t dump_cap, int64_t npix_listed,
-                             const unsigned long long *bits, int gate_mode_b,
                              unsigned long long *hand, uint32_t hand_words) -> int {
         OmniSearchArgs<T> s;
         s.c11 = g.c11;
@@ -3093,12 +2751,6 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         s.tab = tab_dev;
         s.dump = dump;
         s.dump_cap = dump_cap;
-        s.bits = bits;
-        s.npix = npix;
-        s.magic_k = ~0ull / (unsigned long long)k + 1ull;
-        s.gate = g.gate;
-        s.gate_n = g.gate_n;
-        s.gate_mode = gate_mode_b;
         s.hand_bits = nullptr;
         s.hand_words = hand_words;
         s.hand_count = const_cast<uint32_t *>(count) + 3;    // word 3 of the lists' first counter line
@@ -3122,8 +2774,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }();
         // The register form serves the series lengths of dense_search, as long as the screen can
         // decide tests at all (it cannot where omega2 leaves [0, 1], e.g. single-look data: every
-        // test would cost a second walk of its segment) and pass B does not also fill the map.
-        bool regs_ok = k >= 2 && k <= (sizeof(T) == 4 ? 32 : 16) && bits == nullptr;
+        // test would cost a second walk of its segment).
+        bool regs_ok = k >= 2 && k <= (sizeof(T) == 4 ? 32 : 16);
         DenseScreen scr;
         if (regs_ok) {
             scr = make_dense_screen<T>(htab, (int)k, n_looks);
@@ -3165,12 +2817,6 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         return ND_AMD_OK;
     };
 
-    // ND_AMD_SLABS: row slabs of the pipeline above (1 = one pass A, one pass B, one stream)
-    static const int n_slabs = [] {
-        const char *e = getenv("ND_AMD_SLABS");
-        const int v = e ? atoi(e) : 1;
-        return v < 1 ? 1 : (v > kMaxSlabs ? kMaxSlabs : v);
-    }();
     bool gated = false;
     if (pm_ids != nullptr) {
         if (!retain || !flat) {
@@ -3258,8 +2904,6 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             else
                 ND_LAUNCH_DMA(24);
 #undef ND_LAUNCH_DMA
-            b_fill = g.bits != nullptr;
-            b_gate_mode = g.gate_mode;
             }
             g.gate_mode = 0;
         } else {
@@ -3289,7 +2933,6 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             return ND_AMD_EUNSUPPORTED;
         }
 #undef ND_LAUNCH_PM
-        b_fill = g.bits != nullptr;
         }
     } else if (fused) {
         gated = take_sample();
@@ -3325,8 +2968,6 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             g.gate_mode = 2;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
             launch_retain<T>(g, tab, nblocks, stats, stream);
-            b_fill = g.bits != nullptr;
-            b_gate_mode = 2;
         }
         g.gate_mode = 0;
     } else if (stream_long) {
@@ -3334,15 +2975,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             g.dense_min = 65;
             {
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-                unsigned long long *const keep = g.bits;
-                g.bits = nullptr;                   // this launch is only here for the rasters
                 if (retain)
                     launch_retain<T>(g, tab, nblocks, true, stream);
                 else if (aligned)
                     launch_global<T, VPPT>(g, tab, nblocks, true, stream);
                 else
                     launch_global<T, 1>(g, tab, nblocks, true, stream);
-                g.bits = keep;
             }
             ND_HIP_CHECK(hipGetLastError());
             // its candidate lists are not used: the search below makes its own
@@ -3382,71 +3020,13 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             g.gate_mode = 2;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
             launch_retain<T>(g, tab, nblocks, stats && !stats_split, stream);
-            b_fill = g.bits != nullptr;
-            b_gate_mode = 2;
         }
         g.gate_mode = 0;
-    } else if (retain && flat && n_slabs > 1 && nblocks >= 4096 * (int64_t)n_slabs) {
-        std::lock_guard<std::mutex> lk(g_aux_mu);
-        OmniAux *aux = omni_aux();
-        if (aux == nullptr) {
-            set_error("nd_amd_omnibus_c2: no second stream for the slab pipeline");
-            return ND_AMD_EHIP;
-        }
-        g.bits = nullptr;                                  // each slab's pass A zero-fills its rows
-        const int S = n_slabs;
-        const int64_t nb_slab = ceil_div(nblocks, (int64_t)S);
-        const uint32_t seg_s = omni_seg(nb_slab * kRetainThreads, 1);
-        const uint32_t segd_s = seg_s / 64 + 8;
-        const uint32_t cap_s = g.dump_cap / (uint32_t)S;
-        for (int si = 0; si < S; ++si) {
-            const int64_t b0 = si * nb_slab;
-            const int64_t nb = (b0 + nb_slab <= nblocks ? nb_slab : nblocks - b0);
-            if (nb <= 0) break;
-            uint32_t *count_s = flag_count + (size_t)si * kShards * kCounterStride;
-            uint32_t *idx_s = flag_idx + (size_t)si * kShards * seg_s;
-            uint32_t *dense_s = reinterpret_cast<uint32_t *>(ws + w.off_dense) + (size_t)si * kShards * segd_s;
-            T *dump_s = reinterpret_cast<T *>(ws + w.off_dump) + (size_t)si * kShards * cap_s * (size_t)(4 * k);
-            g.block_base = b0;
-            g.flag_count = count_s;
-            g.flag_idx = idx_s;
-            g.dense_idx = dense_s;
-            g.dump = dump_s;
-            g.seg = seg_s;
-            g.segd = segd_s;
-            g.dump_cap = cap_s;
-            {
-                KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-                launch_retain<T>(g, tab, nb, stats, stream);
-            }
-            ND_HIP_CHECK(hipGetLastError());
-            const bool last = (b0 + nb >= nblocks);
-            hipStream_t sq = stream;
-            if (!last) {
-                ND_HIP_CHECK(hipEventRecord(aux->fork[si], stream));
-                ND_HIP_CHECK(hipStreamWaitEvent(aux->stream, aux->fork[si], 0));
-                sq = aux->stream;
-            }
-            if (g.dense_min <= 64)
-                launch_dense(sq, count_s, idx_s, dense_s, dump_s, seg_s, segd_s, cap_s, nb * kRetainThreads);
-            {
-                const uint32_t hw_s = seg_s / 64 + 1;
-                const int rc = launch_search(sq, count_s, idx_s, dump_s, seg_s, cap_s, nb * kRetainThreads, nullptr, 0,
-                                             hand_ws + (size_t)si * kShards * hw_s, hw_s);
-                if (rc != ND_AMD_OK) return rc;
-            }
-            ND_HIP_CHECK(hipGetLastError());
-            if (last) break;
-        }
-        ND_HIP_CHECK(hipEventRecord(aux->join, aux->stream));
-        ND_HIP_CHECK(hipStreamWaitEvent(stream, aux->join, 0));
-        return ND_AMD_OK;
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-        if (retain) {
+        if (retain)
             launch_retain<T>(g, tab, nblocks, stats, stream);
-            b_fill = g.bits != nullptr;
-        } else if (aligned)
+        else if (aligned)
             launch_global<T, VPPT>(g, tab, nblocks, stats, stream);
         else
             launch_global<T, 1>(g, tab, nblocks, stats, stream);
@@ -3461,7 +3041,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // ---- pass B ----
     {
         const int rc = launch_search(stream, flag_count, flag_idx, g.dump, g.seg, g.dump_cap, npix,
-                                     b_fill ? g.bits : nullptr, b_gate_mode, hand_ws, g.seg / 64 + 1);
+                                     hand_ws, g.seg / 64 + 1);
         if (rc != ND_AMD_OK) return rc;
     }
     ND_HIP_CHECK(hipGetLastError());
