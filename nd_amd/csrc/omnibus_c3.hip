@@ -492,7 +492,11 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
 }
 
 // ---- pass B ---------------------------------------------------------------------------------
-template <typename T, bool USE_LDS>
+// LANES: listed pixels per wave.  The LDS image of 64 series of 48 dates is 110 KB: one wave per
+// CU, whose gather (1.13 ms of config 4's share, sector-traffic bound) and search (0.42 ms, latency
+// bound) then take turns.  With 32 pixels per wave the image is 55 KB and two waves share a CU: one
+// gathers while the other searches.  (The upper 32 lanes of such a wave only idle along.)
+template <typename T, bool USE_LDS, int LANES = 64>
 __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s)
 {
     extern __shared__ __align__(16) unsigned char nd_smem3[];
@@ -503,11 +507,11 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
     const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
     const uint32_t n = s.flag_count[shard * kC3CounterStride];
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
-    if (lblock * 64u >= n) return;            // nothing for this block
+    if (lblock * (unsigned)LANES >= n) return;            // nothing for this block
     // per-j constants of the screen as four LDS arrays behind the series image (omnibus.hip): every
     // lane looks up its own j in every iteration
     const int kp = k + 1;
-    double *scr = reinterpret_cast<double *>(nd_smem3 + (USE_LDS ? (size_t)k * 9 * 64 * sizeof(T) : 0));
+    double *scr = reinterpret_cast<double *>(nd_smem3 + (USE_LDS ? (size_t)k * 9 * LANES * sizeof(T) : 0));
     for (int j = lane; j <= k; j += 64) {
         const OmniTabEntry e = s.tab_dev[j];
         scr[j] = e.m2rho;
@@ -517,13 +521,14 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
     }
     __syncthreads();
 
-    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+    for (uint32_t base = lblock * (unsigned)LANES; base < n; base += nlblock * (unsigned)LANES) {
+        const bool mylane = lane < LANES;                   // (LANES = 32: the upper half idles)
         const uint32_t idx = base + lane;
-        const bool active = idx < n;
+        const bool active = mylane && idx < n;
         const int64_t pix = active ? (int64_t)list[idx] : 0;
         const int64_t row = pix / s.nx_orig, col = pix - row * s.nx_orig;
         const int64_t off = row * s.sy + col * s.sx;
-        if (USE_LDS) {
+        if (USE_LDS && mylane) {
             // eight dates (72 independent loads per lane) in flight at a time
             for (int t0 = 0; t0 < k; t0 += 8) {
                 T q[8][9];
@@ -538,7 +543,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
                 for (int u = 0; u < 8; ++u)
                     if (t0 + u < k) {
 #pragma unroll
-                        for (int c = 0; c < 9; ++c) lds[((t0 + u) * 9 + c) * 64 + lane] = q[u][c];
+                        for (int c = 0; c < 9; ++c) lds[((t0 + u) * 9 + c) * LANES + lane] = q[u][c];
                     }
             }
         }
@@ -557,7 +562,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
             T v[9];
             if (USE_LDS) {
 #pragma unroll
-                for (int c = 0; c < 9; ++c) v[c] = lds[(t * 9 + c) * 64 + lane];
+                for (int c = 0; c < 9; ++c) v[c] = lds[(t * 9 + c) * LANES + lane];
             } else {
                 if (nxt_t == t) {
 #pragma unroll
@@ -759,9 +764,38 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     if (per_shard > 64) per_shard = 64;
     if (per_shard < 1) per_shard = 1;
     const int64_t sblocks = per_shard * kC3Shards;
+    // Pixels per wave: as many as keep the image at ~32 KB, i.e. five waves per CU taking turns at
+    // gathering and searching.  Config 4's share (k = 48): 64 / 32 / 16 pixels per wave -> pass B
+    // 1.58 / 1.35 / 1.28 ms.  ND_AMD_C3_LANES = 64 / 32 / 16 forces a width.
+    static const int c3_lanes_env = [] {
+        const char *e = getenv("ND_AMD_C3_LANES");
+        return e ? atoi(e) : 0;
+    }();
+    const int c3_lanes = (c3_lanes_env == 64 || c3_lanes_env == 32 || c3_lanes_env == 16)
+                             ? c3_lanes_env
+                             : (lds_bytes <= 33 * 1024 ? 64 : (lds_bytes <= 66 * 1024 ? 32 : 16));
+    const bool halves = use_lds && c3_lanes != 64;
     {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
-        if (use_lds)
+        if (halves) {
+            const int lanes = c3_lanes == 16 ? 16 : 32;
+            const size_t lds_part = (size_t)k * 9 * lanes * sizeof(T) + scr_bytes;
+            int64_t per_shard_h = ceil_div(ceil_div(npix, kC3Shards), lanes);
+            if (per_shard_h > 256) per_shard_h = 256;
+            if (per_shard_h < 1) per_shard_h = 1;
+            const dim3 gridh((unsigned)(per_shard_h * kC3Shards));
+            if (lanes == 16) {
+                if (lds_part > 64 * 1024)
+                    ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c3_search_kernel<T, true, 16>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+                hipLaunchKernelGGL((omnibus_c3_search_kernel<T, true, 16>), gridh, dim3(64), lds_part, stream, g);
+            } else {
+                if (lds_part > 64 * 1024)
+                    ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c3_search_kernel<T, true, 32>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+                hipLaunchKernelGGL((omnibus_c3_search_kernel<T, true, 32>), gridh, dim3(64), lds_part, stream, g);
+            }
+        } else if (use_lds)
             hipLaunchKernelGGL((omnibus_c3_search_kernel<T, true>), dim3((unsigned)sblocks), dim3(64),
                                lds_bytes, stream, g);
         else
