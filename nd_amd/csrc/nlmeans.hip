@@ -206,9 +206,12 @@ __device__ __forceinline__ int nlm_reflect_i(int64_t i, int64_t shape)
 }
 
 // stage (rows x cols) of variable v, slice i2, top-left global coordinate (gy0, gx0), into lds
-__device__ __forceinline__ void nlm_stage(const NlmTiledArgs &a, float *lds, int *ymap, int *xmap,
-                                          int rows, int cols, int64_t gy0, int64_t gx0, int64_t i2,
-                                          int v, int tid, bool *nonfinite = nullptr)
+// (T = double: the float64 window kernel; `arr` / `out` of the arguments are then double arrays and
+// every stride counts doubles)
+template <typename T>
+__device__ __forceinline__ void nlm_stage_t(const NlmTiledArgs &a, T *lds, int *ymap, int *xmap,
+                                            int rows, int cols, int64_t gy0, int64_t gx0, int64_t i2,
+                                            int v, int tid, bool *nonfinite = nullptr)
 {
     for (int i = tid; i < rows + cols; i += 256) {
         // Positions that feed a written pixel reflect into the tile (checked on the host); the
@@ -224,10 +227,10 @@ __device__ __forceinline__ void nlm_stage(const NlmTiledArgs &a, float *lds, int
         }
     }
     __syncthreads();
-    const float *base = a.arr + i2 * a.si2 + (int64_t)v * a.si3;
+    const T *base = reinterpret_cast<const T *>(a.arr) + i2 * a.si2 + (int64_t)v * a.si3;
     const int n = rows * cols;
     for (int e0 = 0; e0 < n; e0 += 256 * 8) {
-        float buf[8];
+        T buf[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * 256 + tid;
@@ -241,11 +244,18 @@ __device__ __forceinline__ void nlm_stage(const NlmTiledArgs &a, float *lds, int
             const int e = e0 + u * 256 + tid;
             if (e < n) {
                 lds[e] = buf[u];
-                if (nonfinite) *nonfinite = *nonfinite || !(fabsf(buf[u]) < INFINITY);
+                if (nonfinite) *nonfinite = *nonfinite || !(fabs((double)buf[u]) < INFINITY);
             }
         }
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ void nlm_stage(const NlmTiledArgs &a, float *lds, int *ymap, int *xmap,
+                                          int rows, int cols, int64_t gy0, int64_t gx0, int64_t i2,
+                                          int v, int tid, bool *nonfinite = nullptr)
+{
+    nlm_stage_t<float>(a, lds, ymap, xmap, rows, cols, gy0, gx0, i2, v, tid, nonfinite);
 }
 
 __device__ __forceinline__ double nlm_self_weight(double total_weight, double total_sq_weight,
@@ -289,7 +299,9 @@ __device__ __forceinline__ bool nlm_neff_ill(double tw, double tsq, double n)
 // ---- patch_mode 0, f > 0: uniform weights ------------------------------------------------
 constexpr int kWinTX = 128, kWinTY = 32;     // 4 px per thread along x, 32 x 8 threads -> 128 x 8 ... x4 rows
 
-template <int R1MAX>
+// T = float, or double for float64 arrays: the running sums are `floating`, as in the reference
+// (nd/_filters.pyx:336,341), the self term and the quotient double
+template <typename T, int R1MAX>
 __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs a)
 {
     extern __shared__ __align__(16) unsigned char nd_smem_n[];
@@ -297,7 +309,7 @@ __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs 
     const int r0 = a.r0, r1 = a.r1, rz = a.rz;
     const int cols = kWinTX + 2 * r1, rows = kWinTY + 2 * r0;
     const int psz = rows * cols, nz = 2 * rz + 1;
-    float *lds = reinterpret_cast<float *>(nd_smem_n);          // [nz][rows][cols]
+    T *lds = reinterpret_cast<T *>(nd_smem_n);                  // [nz][rows][cols]
     int *ymap = reinterpret_cast<int *>(lds + nz * psz);
     int *xmap = ymap + rows;
 
@@ -322,20 +334,20 @@ __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs 
         for (int dz = 0; dz < nz; ++dz) {
             int64_t zz = nlm_reflect_i(a.offz + i2 + dz - rz, a.Gz) - a.offz;
             zz = zz < 0 ? 0 : (zz >= a.N2 ? a.N2 - 1 : zz);
-            nlm_stage(a, lds + dz * psz, ymap, xmap, rows, cols, a.off0 + y0 - r0, a.off1 + x0 - r1,
-                      zz, v, tid);
+            nlm_stage_t<T>(a, lds + dz * psz, ymap, xmap, rows, cols, a.off0 + y0 - r0, a.off1 + x0 - r1,
+                           zz, v, tid);
         }
 #pragma unroll
         for (int py = 0; py < 4; ++py) {
             const int yy = ly + py;
-            float ws[4] = {0.f, 0.f, 0.f, 0.f};
+            T ws[4] = {(T)0, (T)0, (T)0, (T)0};
             // the reference's visiting order: axis-2 offset outermost when it is a window axis
             // (it is then the FIRST filter dimension, see nlm_try_tiled), rows, columns innermost
             for (int dz = 0; dz < nz; ++dz) {
                 for (int dy = 0; dy < 2 * r0 + 1; ++dy) {
-                    const float *row = lds + dz * psz + (yy + dy) * cols + lx;
+                    const T *row = lds + dz * psz + (yy + dy) * cols + lx;
                     // window columns 0 .. 2 r1 for pixel 0, shifted by i for pixel i
-                    float w[2 * R1MAX + 4];
+                    T w[2 * R1MAX + 4];
 #pragma unroll
                     for (int c = 0; c < 2 * R1MAX + 4; ++c)
                         if (c < 2 * r1 + 4) w[c] = row[c];
@@ -351,15 +363,15 @@ __global__ void __launch_bounds__(256) nlmeans_window_kernel(const NlmTiledArgs 
             }
             const int64_t y = y0 + yy;
             if (y < a.chi0 && !fail) {
-                const float *crow = lds + rz * psz + (yy + r0) * cols + lx + r1;
-                float *o = a.out + i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0;
+                const T *crow = lds + rz * psz + (yy + r0) * cols + lx + r1;
+                T *o = reinterpret_cast<T *>(a.out) + i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t x = x0 + lx + i;
                     if (x < a.chi1) {
                         // self term last (nd/_filters.pyx:417-420), weights are exactly 1 / wself
-                        const float s = (float)((double)ws[i] + (wself * (double)crow[i]));
-                        o[x] = (float)((double)s / total);
+                        const T s = (T)((double)ws[i] + (wself * (double)crow[i]));
+                        o[x] = (T)((double)s / total);
                     }
                 }
             }
@@ -1548,7 +1560,11 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
                          hipStream_t stream)
 {
     static const bool disabled = getenv("ND_AMD_NO_TILED") != nullptr;
-    if (disabled || dtype != ND_AMD_F32) return 0;
+    if (disabled) return 0;
+    // float64 arrays: the uniform-weight window kernel only (the reference-compatible mode with
+    // f > 0); everything else of float64 stays in the per-pixel kernel
+    const bool f64 = dtype != ND_AMD_F32;
+    if (f64 && !((patch_mode == 0) && (f[0] > 0 || f[1] > 0 || f[2] > 0))) return 0;
     if (nvars < 1) return 0;
     // Canonical axes of the tiled kernels: rows, contiguous columns, and a third axis that is
     // either a plain slice axis or (window kernel only) a window axis visited OUTERMOST.
@@ -1598,7 +1614,7 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
         a.tiles_y = (int)ceil_div(ey, kWinTY);
         static const bool no_roll = getenv("ND_AMD_NLM_NOROLL") != nullptr;
         static const bool no_stream3 = getenv("ND_AMD_NLM_NOSTREAM3") != nullptr;
-        if (!no_roll && !no_stream3 && rz == 1 && a.r0 == a.r1 && a.r1 >= 1 && a.r1 <= 5 &&
+        if (!f64 && !no_roll && !no_stream3 && rz == 1 && a.r0 == a.r1 && a.r1 >= 1 && a.r1 <= 5 &&
             a.si0 >= 0 && (a.N0 * a.si0 + a.N1) * 4 < 0x7fffffffLL) {
             const int64_t nbr = (int64_t)a.tiles_x * a.tiles_y * nvars;
             if (nbr <= 0x7fffffffLL) {
@@ -1606,7 +1622,7 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
                 if (launch_stream3(a, nbr, stream)) return 1;
             }
         }
-        if (!no_roll && a.r0 <= kRollR0Max && a.r1 <= 10) {
+        if (!f64 && !no_roll && a.r0 <= kRollR0Max && a.r1 <= 10) {
             const size_t nw = ((2 * (size_t)a.r1 + 4) + 3) / 4 * 4;
             const size_t lds_r = (size_t)(2 * rz + 1) * (kWinTY + 2 * a.r0) * (kWinTX - 4 + nw) * sizeof(float);
             const int64_t nbr = (int64_t)a.tiles_x * a.tiles_y * nvars;
@@ -1617,16 +1633,36 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
         }
         const int64_t nb = (int64_t)a.tiles_x * a.tiles_y * nsl;
         const size_t rows = kWinTY + 2 * a.r0, cols = kWinTX + 2 * a.r1;
-        const size_t lds = (size_t)(2 * rz + 1) * rows * cols * sizeof(float) +
+        const size_t lds = (size_t)(2 * rz + 1) * rows * cols * (f64 ? sizeof(double) : sizeof(float)) +
                            (rows + cols) * sizeof(int);
-        if (lds > 64 * 1024 || nb > 0x7fffffffLL) return 0;
+        if (nb > 0x7fffffffLL) return 0;
+        if (f64) {
+            if (lds > kBigLds) return 0;
+            KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
+#define ND_LAUNCH_WIN64(R)                                                                                     \
+    do {                                                                                                      \
+        if (lds > 64 * 1024)                                                                                  \
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&nlmeans_window_kernel<double, R>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL((nlmeans_window_kernel<double, R>), dim3((unsigned)nb), dim3(256), lds, stream, a); \
+    } while (0)
+            if (a.r1 <= 4)
+                ND_LAUNCH_WIN64(4);
+            else if (a.r1 <= 10)
+                ND_LAUNCH_WIN64(10);
+            else
+                ND_LAUNCH_WIN64(16);
+#undef ND_LAUNCH_WIN64
+            return 1;
+        }
+        if (lds > 64 * 1024) return 0;
         KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
         if (a.r1 <= 4)
-            hipLaunchKernelGGL((nlmeans_window_kernel<4>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((nlmeans_window_kernel<float, 4>), dim3((unsigned)nb), dim3(256), lds, stream, a);
         else if (a.r1 <= 10)
-            hipLaunchKernelGGL((nlmeans_window_kernel<10>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((nlmeans_window_kernel<float, 10>), dim3((unsigned)nb), dim3(256), lds, stream, a);
         else
-            hipLaunchKernelGGL((nlmeans_window_kernel<16>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+            hipLaunchKernelGGL((nlmeans_window_kernel<float, 16>), dim3((unsigned)nb), dim3(256), lds, stream, a);
         return 1;
     }
     // true patch distances (patch_mode 1, or f = 0 in either mode: the loops run once); the third
