@@ -38,6 +38,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The CPU baselines run the oracle on every host core (OpenMP).  libgomp's workers spin for a while
+# after a parallel region; on a box whose CPU quota equals its core count they then starve the
+# thread that launches the next workload's kernels (GaussianFilter right behind the boxcar
+# baseline: 3.8 ms per step on the host against 0.73 ms on the device).  Passive waiting puts them
+# to sleep at once.  (Read by libgomp when the oracle library is first loaded.)
+os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
+os.environ.setdefault('GOMP_SPINCOUNT', '0')
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) of every
