@@ -246,8 +246,11 @@ class OmnibusC3(Workload):
     def __init__(self, a, rank, world, dev):
         super().__init__(a, rank, world, dev)
         from nd_amd import synth
+        # (under the profiler's counter pass only six dates are drawn and repeated: the full synthesis is
+        # 17 000 small launches, at which rocprofv3 --pmc segfaults; the kernels' traffic is the same)
         self.stack = synth.wishart_c3_stack(self.k, self.rows, self.nx, looks=a.looks,
-                                            seed=4321 + rank, device=dev, change_frac=a.change_frac)
+                                            seed=4321 + rank, device=dev, change_frac=a.change_frac,
+                                            cycle=6 if TRAFFIC_MODE else 0)
         self.alg_bytes = self.npix * self.k * (9 * self.stack.element_size() + 1)
 
     def step(self):

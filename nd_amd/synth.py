@@ -70,10 +70,13 @@ C3_PLANES = ('C11', 'C22', 'C33', 'C12re', 'C12im', 'C13re', 'C13im', 'C23re', '
 
 
 def wishart_c3_stack(k, ny, nx, looks=9, seed=1234, device='cuda', dtype=torch.float32,
-                     change_frac=0.01, factor=4.0, corr=0.3, date_pad=DATE_PAD):
+                     change_frac=0.01, factor=4.0, corr=0.3, date_pad=DATE_PAD, cycle=0):
     """n-look complex-Wishart full-pol samples, planar (9, time, y, x) in the order C3_PLANES:
     s1, s2, s3 ~ CN(0, 1) per look with s2, s3 correlated to s1 by `corr`; C_ab = mean(s_a conj(s_b)).
-    A fraction of the pixels gets a x`factor` power step at a random date."""
+    A fraction of the pixels gets a x`factor` power step at a random date.
+    cycle > 0: only the first `cycle` dates are drawn and the others repeat them (the step still
+    applies per date) -- a tenth of the device launches, for runs under a profiler's counter pass,
+    which gives up beyond some ten thousand dispatches."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
     gen.manual_seed(int(seed))
@@ -82,7 +85,15 @@ def wishart_c3_stack(k, ny, nx, looks=9, seed=1234, device='cuda', dtype=torch.f
         mask = torch.rand((ny, nx), generator=gen, device=dev) < change_frac
         t0 = torch.randint(1, max(k, 2), (ny, nx), generator=gen, device=dev)
     c = (1.0 - corr * corr) ** 0.5
+    drawn = {}
     for t in range(k):
+        if cycle > 0 and t >= cycle:
+            for v in range(9):
+                p = drawn[(v, t % cycle)]
+                if change_frac > 0:
+                    p = torch.where(mask & (t0 <= t), p * factor, p)
+                out[v, t] = p.to(dtype)
+            continue
         acc = [torch.zeros((ny, nx), dtype=torch.float32, device=dev) for _ in range(9)]
         for _ in range(looks):
             a = torch.randn((6, ny, nx), generator=gen, device=dev) * (0.5 ** 0.5)
@@ -100,6 +111,8 @@ def wishart_c3_stack(k, ny, nx, looks=9, seed=1234, device='cuda', dtype=torch.f
             acc[8] += s2i * s3r - s2r * s3i
         for v in range(9):
             p = acc[v] / looks
+            if cycle > 0:
+                drawn[(v, t)] = p
             if change_frac > 0:
                 p = torch.where(mask & (t0 <= t), p * factor, p)
             out[v, t] = p.to(dtype)
