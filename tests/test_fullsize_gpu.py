@@ -196,12 +196,16 @@ def test_dense_thresholds_whole_raster_equals_oracle(oracle, stack, alpha):
                                  {'ND_AMD_FUSED_ALPHA': '0'}, {'ND_AMD_PM_FORM': '1'},
                                  {'ND_AMD_GATE': '0'}, {'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '1'},
                                  {'ND_AMD_PM_STREAM_LDS': '1'}, {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_GATE': '0'},
-                                 {'ND_AMD_PM_STREAM_SECTOR': '0'}, {'ND_AMD_PM_STREAM_SECTOR': '1'}])
+                                 {'ND_AMD_PM_STREAM_SECTOR': '0'}, {'ND_AMD_PM_STREAM_SECTOR': '1'},
+                                 {'ND_AMD_SEARCH_MODE': '0'}, {'ND_AMD_SEARCH_MODE': '1'},
+                                 {'ND_AMD_SEARCH_MODE': '2'}, {'ND_AMD_SEARCH_MODE': '2', 'ND_AMD_FUSED_ALPHA': '0'}])
 def test_every_kernel_form_gives_the_same_map(env):
     """The library picks among several forms of the low-threshold search by alpha and by a sample of
     the data (streaming fused, register fused, separate dense kernel, gate on / off; LDS-DMA or
     register-staged pixel-major pass A; pixel-major streaming search from memory or from LDS images).  The choice is about speed only: force each form in a
-    fresh process and compare with the oracle."""
+    fresh process and compare with the oracle.  ND_AMD_SEARCH_MODE: pass B from its LDS image / from
+    memory / from registers (with the exact form behind it), also with every pixel of a
+    low-threshold run going through pass B (ND_AMD_FUSED_ALPHA=0)."""
     import json
     import os
     import subprocess

@@ -149,3 +149,30 @@ def test_c3_nodata_margins(oracle, device):
         ch, _, _ = _run(planes, alpha, 9, device)
         assert int((ch != want).sum()) == 0, alpha
         assert not ch[:, 0:140].any() and ch[:, 140:].any()
+
+
+@pytest.mark.parametrize('lanes', ['64', '32', '16'])
+def test_c3_pass_b_pixels_per_wave(lanes):
+    """ND_AMD_C3_LANES: 64 / 32 / 16 listed pixels per wave of the full-pol pass B (image size against
+    waves per CU): same map as the generic-p oracle, in a fresh process per width."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from nd_amd import kernels, synth\n"
+        "from oracle import oracle as O\n"
+        "O.build()\n"
+        "for k, alpha in ((48, 0.99), (20, 0.9), (9, 0.99)):\n"
+        "    st = synth.wishart_c3_stack(k, 40, 333, looks=9, seed=k, device='cuda', change_frac=0.2)\n"
+        "    got = kernels.change_detection_c3([st[c] for c in range(9)], alpha=alpha, n=9).cpu().numpy()\n"
+        "    host = st.cpu().numpy()\n"
+        "    want = O.change_detection_pol([np.moveaxis(host[c], 0, -1) for c in range(9)], 3, alpha, 9, njobs=8)\n"
+        "    assert np.array_equal(got, want), (k, alpha, int((got != want).sum()))\n"
+        "    assert want.sum() > 0\n"
+        "print('ok')\n" % root)
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, ND_AMD_C3_LANES=lanes),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
