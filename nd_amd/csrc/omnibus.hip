@@ -1386,6 +1386,20 @@ struct PlaneReader {
         }
         return q;
     }
+    // the same with a date index of the lane's own (the deep marginal searches)
+    __device__ __forceinline__ DateVal<T> load_lane(const int t) const
+    {
+        if (MODE == 1) {
+            DateVal<T> q;
+            const unsigned vo = voff + (unsigned)t * sstep;
+            q.a = buffer_load<T>(r11, vo, 0u);
+            q.b = buffer_load<T>(r12r, vo, 0u);
+            q.c = buffer_load<T>(r12i, vo, 0u);
+            q.d = buffer_load<T>(r22, vo, 0u);
+            return q;
+        }
+        return load(t);
+    }
     // MODE 2: the VE = 16 / sizeof(T) dates t0 .. t0 + VE - 1 (t0 a multiple of VE) with 16-byte LDS
     // reads where the variable's dates are adjacent (a lane's series is k * ids elements from the
     // next lane's: single-element reads of one date collide 8-way on the 32 banks, 16-byte reads 2-way)
@@ -1428,10 +1442,12 @@ struct PlaneReader {
 // MW: width of the six test masks and of the change mask -- 0: 32 bits (k <= 32), 1: 64 bits
 // (k <= 64), 2: two 64-bit words (k <= 128; the screen's entries 65 .. 128 then sit in a second
 // set of registers, the sum of the mantissa logs is 64 bits wide)
+constexpr int stream_nj(const int MW) { return MW == 0 ? 32 : (MW == 1 ? 64 : kDenseMax); }
+
 template <typename T, int PF, int MODE, int MW = 0>
 __global__ void __launch_bounds__(MODE == 2 ? 64 : kRetainThreads)
 omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg,
-                         const OmniPmDmaArgs<T> pm)
+                         const OmniPmDmaArgs<T> pm, const StreamScreen<stream_nj(MW)> ss)
 {
     if (omni_gate_skip(g)) return;
     constexpr int kThreads = MODE == 2 ? 64 : kRetainThreads;
@@ -1527,13 +1543,6 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         for (int j = tid; j <= k; j += kThreads) g.tab_dev[j] = tab.e[j];
     }
     __syncthreads();
-    const ScreenRegs scr = screen_regs_load(scr_lds, lane);
-    ScreenRegs scr_hi = scr;
-    if (MW == 2) scr_hi = screen_regs_load(scr_lds + 64, lane);          // entries 65 .. 128
-    auto entry_of = [&](const int jj) -> DenseScreenEntry {
-        if (MW == 2 && jj > 64) return screen_entry(scr_hi, jj - 64);
-        return screen_entry(scr, jj);
-    };
 
     // ---- phase 1 ----
     typedef typename std::conditional<MW == 2, Bits128,
@@ -1543,62 +1552,79 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
        m3F = mask_zero<MT>(), m3I = mask_zero<MT>();
     bool bad = false;
     bool dead = false;       // a date whose determinant is NaN or exactly 0: see below
-    int eabs = 0;
     double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0;
-    int Le = 0;
-    LmT Lm = 0;
+    // The product of the determinants of ts[t:] in double, as the reference forms it (its own runs
+    // forward from each segment start; the two differ by rounding errors of 1e-16 per factor).  One
+    // logarithm of its mantissa per date serves the global test; emin / emax are the extreme binary
+    // exponents it passes through (1 = the empty product behind the last date).
+    double PP = 1.0;
+    int emin = 1, emax = 1;
     DateVal<T> d1, d2;                         // dates t + 1, t + 2
     d1.a = d1.d = d2.a = d2.d = (T)1;
     d1.b = d1.c = d2.b = d2.c = (T)0;
-    int e1 = 0, m1 = 0, e2 = 0, m2q = 0;       // their logarithms
-    const float cu = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 7.5f;   // 1.46 * 5 u, rounded up
+    T det1 = (T)1, prod12 = (T)1;              // det(t + 1);  det(t + 1) * det(t + 2)
+    const T dlo = (T)ss.dlo, dhi = (T)ss.dhi, slo = (T)ss.slo, shi = (T)ss.shi;
+    const T ca2 = (T)ss.ca2, cb2 = (T)ss.cb2, ca3 = (T)ss.ca3, cb3 = (T)ss.cb3;
 
+    // Every date pushes one bit into each of the six masks (m = 2 m + bit): dates arrive last to
+    // first, so the bit of date t ends at position t.  Tests that do not exist (the global test of the
+    // last date alone, marginal tests reaching behind the series) are cleared behind the loop.
     auto process = [&](const DateVal<T> &q, const int t) {
         const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
-        const bool ok = (det > (T)0) && (det < (T)INFINITY) && (q.a > (T)0);
+        const bool ok = (det > dlo) && (det < dhi) && (q.a > (T)0);
         bad = bad || !ok;
         dead = dead || !((det > (T)0) || (det < (T)0));
-        int e0;
-        float mf;
-        log2_parts(ok ? det : (T)1, e0, mf);
-        const int m0 = (int)rintf(mf * kLogFix);
-        eabs += e0 < 0 ? -e0 : e0;
+        const T ds = ok ? det : (T)1;
+        PP = PP * (double)ds;
         S11 += (double)q.a;
         S12r += (double)q.b;
         S12i += (double)q.c;
         S22 += (double)q.d;
-        Le += e0;
-        Lm += m0;
-        // Branch-free: the three tests are evaluated at every date and their bits are kept only
-        // where the test exists (wave-uniform conditions folded into the masks).  A test skipped
-        // under a branch would be a control-flow join inside the date loop; see the loop below.
-        auto decide = [&](const float x, const float m2, const bool sane, const DenseScreenEntry &c,
-                          const bool exists, MT &fbits, MT &ibits) {
-            const bool fires = sane && (x + m2 < c.a);
-            const bool cant = sane && (x - m2 > c.b);
-            mask_set(fbits, t, exists && fires);
-            mask_set(ibits, t, exists && !(fires || cant));
-        };
-        {                                                   // global test of ts[t:], j = k - t >= 2
+        {                                                   // global test of ts[t:], j = k - t
             const int jj = k - t;
+            const StreamEntry c = ss.e[jj];                 // wave-uniform: one scalar load
             const double pp = S11 * S22;
             const double dets = pp - ((S12r * S12r) + (S12i * S12i));
-            const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
-            const DenseScreenEntry c = entry_of(jj);
-            const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
-            const float qq = (float)pp * __builtin_amdgcn_rcpf((float)dets);
-            const float rel = cu * (float)jj * qq;          // 1.46 * 5 n u * s11 s22 / det
-            decide(x, (float)jj * rel * 1.01f, okd && (rel < 0.01f), c, t <= k - 2, gF, gI);
+            const float df = (float)dets;
+            bool okd;
+            int es, eP;
+            float ms, mP;
+            if (sizeof(T) == 4) {
+                // sums of float32 data: their determinant in float32 (relative rounding 6e-8, i.e.
+                // jj * 8.6e-8 in x, inside the screen's margin) -- single-precision frexp and compares
+                okd = (df > 7.888609052210118e-31f) && (df < (float)INFINITY);
+                log2_parts(okd ? df : 1.f, es, ms);
+            } else {
+                okd = (dets > 0.0) && (dets < (double)INFINITY);
+                log2_parts(okd ? dets : 1.0, es, ms);
+            }
+            log2_parts(PP, eP, mP);
+            emin = eP < emin ? eP : emin;
+            emax = eP > emax ? eP : emax;
+            const int E = (eP - c.re) - __mul24(jj, es);
+            const float x = (float)E + __builtin_fmaf(-c.jf, ms, mP - c.rf);
+            const float qq = (float)pp * __builtin_amdgcn_rcpf(df);
+            const float rel = c.cj * qq;                    // 1.46 * 5 n u * s11 s22 / det
+            const float m2 = c.mj * rel;
+            const bool sane = okd && (rel < 0.01f);
+            const bool fires = sane && (x + m2 < c.a);
+            const bool cant = sane && (x - m2 > c.b);
+            mask_push(gF, fires);
+            mask_push(gI, !(fires || cant));
         }
         {                                                   // marginal tests over 2 and 3 dates
-            // the reference's sums, in its type and order: (0 + a_t) + a_t+1 (+ a_t+2)
+            // the reference's sums, in its type and order: (0 + a_t) + a_t+1 (+ a_t+2); decided from
+            // products of determinants against powers of the sum's determinant (StreamScreen)
             T s11 = q.a + d1.a, s12r = q.b + d1.b, s12i = q.c + d1.c, s22 = q.d + d1.d;
+            const T prod2 = ds * det1;
             {
                 const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
-                const DenseScreenEntry c = screen_entry(scr, 2);
-                const float x = dense_x<T>(dets, oks, e0 + e1, m0 + m1, 2, c);
-                decide(x, 0.f, oks, c, t <= k - 3, m2F, m2I);
+                const bool oks = (dets > slo) && (dets < shi);
+                const T r = dets * dets;
+                const bool fires = oks && (prod2 < ca2 * r);
+                const bool cant = oks && (prod2 > cb2 * r);
+                mask_push(m2F, fires);
+                mask_push(m2I, !(fires || cant));
             }
             {
                 s11 = s11 + d2.a;
@@ -1606,18 +1632,19 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
                 s12i = s12i + d2.c;
                 s22 = s22 + d2.d;
                 const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
-                const DenseScreenEntry c = screen_entry(scr, 3);
-                const float x = dense_x<T>(dets, oks, (e0 + e1) + e2, (m0 + m1) + m2q, 3, c);
-                decide(x, 0.f, oks, c, t <= k - 4, m3F, m3I);
+                const bool oks = (dets > slo) && (dets < shi);
+                const T r = (dets * dets) * dets;
+                const T prod3 = ds * prod12;
+                const bool fires = oks && (prod3 < ca3 * r);
+                const bool cant = oks && (prod3 > cb3 * r);
+                mask_push(m3F, fires);
+                mask_push(m3I, !(fires || cant));
             }
+            prod12 = prod2;
+            det1 = ds;
         }
         d2 = d1;
-        e2 = e1;
-        m2q = m1;
         d1 = q;
-        e1 = e0;
-        m1 = m0;
     };
     if (MODE >= 2) {
         // LDS-resident (or pixel-major) series: groups of VE dates, one group of 16-byte reads ahead
@@ -1696,9 +1723,19 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
             if (t >= 0) process(ring[u], t);
         }
     }
-    // |log2| of every partial product stays below 900: the reference's double product neither
-    // overflows nor loses precision to subnormals, so its logarithm is what the sums here model
-    bad = bad || (eabs > 900);
+    // Every product the reference forms is PP(l) / PP(l + m): with the exponents of PP within 900
+    // of each other none of them overflows or loses precision to subnormals, so its logarithm is what
+    // the screen models.  (PP moves by at most 36 -- float64 data: 100 -- binary orders per date, so it
+    // is still a normal number, with a true exponent, at the first date that breaks the bound.)
+    bad = bad || (emax - emin > 900);
+    // tests that do not exist: the global test of the last date alone, the 2- / 3-date marginal tests
+    // reaching behind the series
+    mask_keep_low(gF, k - 1);
+    mask_keep_low(gI, k - 1);
+    mask_keep_low(m2F, k - 2);
+    mask_keep_low(m2I, k - 2);
+    mask_keep_low(m3F, k >= 3 ? k - 3 : 0);
+    mask_keep_low(m3I, k >= 3 ? k - 3 : 0);
     // Nodata pixels need no exact pass.  A NaN determinant at any date makes the product of
     // determinants NaN, an exactly zero one makes it 0 (or NaN): ln Q of the test over the whole
     // series is then NaN or -inf, z is NaN or +-inf, and P is NaN or 0 -- never above alpha
@@ -1724,94 +1761,153 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Den
         bool handoff = in && bad;
         bool done = !in || bad;
         int cur = 0;
-        for (int l = 0; l < k - 1; ++l) {
-            bool act = !done && (cur == l);
-            if (!__any(act)) continue;
-            const bool gi = mask_bit(gI, l), gf = mask_bit(gF, l);
-            const bool i2 = mask_bit(m2I, l), f2 = mask_bit(m2F, l);
-            const bool i3 = mask_bit(m3I, l), f3 = mask_bit(m3F, l);
-            int fire = -1;
-            bool deep = false;
-            if (act) {
-                if (gi) {                                     // global test undecided
-                    handoff = true;
-                    done = true;
-                } else if (!gf) {                             // :241-242
-                    done = true;
-                } else if (l + 1 == k - 1) {
-                    fire = l + 1;                             // the 2-date marginal IS the global test
-                } else if (i2) {
-                    handoff = true;
-                    done = true;
-                } else if (f2) {
-                    fire = l + 1;
-                } else if (l + 2 == k - 1) {
-                    fire = l + 2;
-                } else if (i3) {
-                    handoff = true;
-                    done = true;
-                } else if (f3) {
-                    fire = l + 2;
-                } else {
-                    deep = true;
-                }
-            }
-            if (__any(deep)) {
-                // marginal tests over 4 and more dates: the dates of ts[l:] once more, from memory
-                if (deep) {
-                    T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
-                    int Ld = 0;
-                    LmT Lmd = 0;
-                    bool searching = true;
-                    // four dates in flight per round trip (most searches end at j = 4 or 5)
-                    for (int t0 = l; t0 < k && searching; t0 += 4) {
-                        DateVal<T> qb[4];
+        // marginal tests over 4 and more dates of the segment starting at l (the lane's own): the
+        // dates of ts[l:] once more, from memory.  Sets `fire` (the date of the change) or hands over.
+        auto deep_search = [&](const int l, int &fire) {
+            T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
+            int Ld = 0;
+            LmT Lmd = 0;
+            bool searching = true;
+            // four dates in flight per round trip (most searches end at j = 4 or 5)
+            for (int t0 = l; t0 < k && searching; t0 += 4) {
+                DateVal<T> qb[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) qb[u] = rd.load(t0 + u < k ? t0 + u : k - 1);
+                for (int u = 0; u < 4; ++u) qb[u] = rd.load_lane(t0 + u < k ? t0 + u : k - 1);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int t = t0 + u;
-                            if (searching && t < k) {
-                                const DateVal<T> q = qb[u];
-                                s11 = s11 + q.a;
-                                s12r = s12r + q.b;
-                                s12i = s12i + q.c;
-                                s22 = s22 + q.d;
-                                const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
-                                int e0;
-                                float mf;
-                                log2_parts(det, e0, mf);          // the pixel is not `bad`: det > 0
-                                Ld += e0;
-                                Lmd += (int)rintf(mf * kLogFix);
-                                if (t >= l + 3) {                 // j = 2, 3 are decided: they do not fire
-                                    if (t == k - 1) {
-                                        fire = t;                 // the marginal over ts[l:] IS the global test
-                                        searching = false;
-                                    } else {
-                                        const int jj = t - l + 1;
-                                        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                                        const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
-                                        const DenseScreenEntry c = scr_lds[jj];
-                                        const float x = dense_x<T>(dets, oks, Ld, Lmd, jj, c);
-                                        if (oks && (x < c.a)) {
-                                            fire = t;
-                                            searching = false;
-                                        } else if (!(oks && (x > c.b))) {      // undecided
-                                            handoff = true;
-                                            done = true;
-                                            searching = false;
-                                        }
-                                    }
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u;
+                    if (searching && t < k) {
+                        const DateVal<T> q = qb[u];
+                        s11 = s11 + q.a;
+                        s12r = s12r + q.b;
+                        s12i = s12i + q.c;
+                        s22 = s22 + q.d;
+                        const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+                        int e0;
+                        float mf;
+                        log2_parts(det, e0, mf);          // the pixel is not `bad`: det > 0
+                        Ld += e0;
+                        Lmd += (int)rintf(mf * kLogFix);
+                        if (t >= l + 3) {                 // j = 2, 3 are decided: they do not fire
+                            if (t == k - 1) {
+                                fire = t;                 // the marginal over ts[l:] IS the global test
+                                searching = false;
+                            } else {
+                                const int jj = t - l + 1;
+                                const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+                                const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                                const DenseScreenEntry c = scr_lds[jj];
+                                const float x = dense_x<T>(dets, oks, Ld, Lmd, jj, c);
+                                if (oks && (x < c.a)) {
+                                    fire = t;
+                                    searching = false;
+                                } else if (!(oks && (x > c.b))) {      // undecided
+                                    handoff = true;
+                                    done = true;
+                                    searching = false;
                                 }
                             }
                         }
                     }
                 }
             }
-            if (fire >= 0) {
-                mask_set(mask, fire, true);                   // :252, l + r with r = j - 1
-                cur = fire;                                   // :255
-                if (cur >= k - 1) done = true;                // :256
+        };
+        if constexpr (MW < 2) {
+            // The walk of single_pixel_change_detection (nd/_change.pyx:224-257) over the test bits,
+            // whole runs at a time.  At a segment start l (bit l of each mask):
+            //   A1  the global test fires and the 2-date marginal fires (or l + 1 is the last date,
+            //       where it IS the global test)                        -> change at l + 1, go on there
+            //   A2  ... 2 dates do not fire, 3 dates do (or l + 2 is the last date) -> change at l + 2
+            //   HO  a test the walk needs is undecided                  -> exact pass
+            //   DP  2 and 3 dates decidedly do not fire                 -> deeper marginals from memory
+            //   otherwise the global test decidedly does not fire       -> the search ends (:241-242)
+            // A run of A1 bits is a run of changes at consecutive dates: one count-trailing-zeros.
+            const MT one = (MT)1;
+            const MT LA = one << (k - 2);
+            const MT LB = k >= 3 ? one << (k - 3) : (MT)0;
+            const MT gOK = gF & ~gI;
+            const MT A1 = gOK & (LA | m2F);
+            const MT n2 = gOK & ~A1 & ~m2I;
+            const MT A2 = n2 & (LB | m3F);
+            const MT HO = gI | (gOK & ~A1 & m2I) | (n2 & ~A2 & m3I);
+            const MT DP = n2 & ~A2 & ~m3I;
+            while (__any(!done)) {
+                bool deep = false;
+                if (!done) {
+                    const int z = mask_ctz((MT)~(A1 >> cur));          // A1 has no bit at k - 1 or above
+                    mask |= ((one << z) - one) << (cur + 1);           // :252, l + r with r = j - 1
+                    cur += z;                                          // :255
+                    if (cur >= k - 1) {
+                        done = true;                                   // :256
+                    } else {
+                        const MT bit = one << cur;
+                        if (A2 & bit) {
+                            mask |= bit << 2;
+                            cur += 2;
+                            if (cur >= k - 1) done = true;
+                        } else if (HO & bit) {
+                            handoff = true;
+                            done = true;
+                        } else if (DP & bit) {
+                            deep = true;
+                        } else {
+                            done = true;
+                        }
+                    }
+                }
+                if (__any(deep)) {
+                    if (deep) {
+                        int fire = -1;
+                        deep_search(cur, fire);
+                        if (fire >= 0) {
+                            mask_set(mask, fire, true);
+                            cur = fire;
+                            if (cur >= k - 1) done = true;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int l = 0; l < k - 1; ++l) {
+                bool act = !done && (cur == l);
+                if (!__any(act)) continue;
+                const bool gi = mask_bit(gI, l), gf = mask_bit(gF, l);
+                const bool i2 = mask_bit(m2I, l), f2 = mask_bit(m2F, l);
+                const bool i3 = mask_bit(m3I, l), f3 = mask_bit(m3F, l);
+                int fire = -1;
+                bool deep = false;
+                if (act) {
+                    if (gi) {                                     // global test undecided
+                        handoff = true;
+                        done = true;
+                    } else if (!gf) {                             // :241-242
+                        done = true;
+                    } else if (l + 1 == k - 1) {
+                        fire = l + 1;                             // the 2-date marginal IS the global test
+                    } else if (i2) {
+                        handoff = true;
+                        done = true;
+                    } else if (f2) {
+                        fire = l + 1;
+                    } else if (l + 2 == k - 1) {
+                        fire = l + 2;
+                    } else if (i3) {
+                        handoff = true;
+                        done = true;
+                    } else if (f3) {
+                        fire = l + 2;
+                    } else {
+                        deep = true;
+                    }
+                }
+                if (__any(deep)) {
+                    if (deep) deep_search(l, fire);
+                }
+                if (fire >= 0) {
+                    mask_set(mask, fire, true);                   // :252, l + r with r = j - 1
+                    cur = fire;                                   // :255
+                    if (cur >= k - 1) done = true;                // :256
+                }
             }
         }
         if (handoff) mask = mask_zero<MT>();                  // pass B writes that pixel's changes
@@ -2862,6 +2958,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 // if the sample confirms that the raster is dense
                 gated = take_sample();
                 const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+                const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
                 g.gate_mode = gated ? 1 : 0;
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
                 static const bool pm_lds = getenv("ND_AMD_PM_STREAM_LDS") != nullptr;
@@ -2878,13 +2975,13 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 }();
                 const bool pm_direct4 = pm_sector_env >= 0 ? pm_sector_env != 0 : alpha <= 1e-3;
                 if (pm_lds)
-                    hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 2>), gridw, blockw, lds_dma, stream, g, tab, scr, dm);
+                    hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 2>), gridw, blockw, lds_dma, stream, g, tab, scr, dm, ss0);
                 else if (pm_direct4 && (k % (2 * VE)) == 0)
                     hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 4>), dim3((unsigned)ceil_div(npix, (int64_t)kRetainThreads)),
-                                       dim3(kRetainThreads), 0, stream, g, tab, scr, dm);
+                                       dim3(kRetainThreads), 0, stream, g, tab, scr, dm, ss0);
                 else
                     hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 3>), dim3((unsigned)ceil_div(npix, (int64_t)kRetainThreads)),
-                                       dim3(kRetainThreads), 0, stream, g, tab, scr, dm);
+                                       dim3(kRetainThreads), 0, stream, g, tab, scr, dm, ss0);
                 g.gate_mode = gated ? 2 : 0;
                 g.dense_min = 65;                            // the sparse form lists pixel by pixel
             }
@@ -2955,11 +3052,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             constexpr int PF = sizeof(T) == 4 ? 6 : 4;
             OmniPmDmaArgs<T> nopm;
             memset(&nopm, 0, sizeof(nopm));
+            const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
             const bool buf1 = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
             if (buf1)
-                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1>), grid, block, 0, stream, g, tab, scr, nopm);
+                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1>), grid, block, 0, stream, g, tab, scr, nopm, ss0);
             else
-                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0>), grid, block, 0, stream, g, tab, scr, nopm);
+                hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0>), grid, block, 0, stream, g, tab, scr, nopm, ss0);
         }
         }
         if (gated) {
@@ -3004,14 +3102,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             memset(&nopm, 0, sizeof(nopm));
             const bool buf = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
             if (k <= 32) {
-                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, scr, nopm);
-                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 0>), grid, block, 0, stream, g, tab, scr, nopm);
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, scr, nopm, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 0>), grid, block, 0, stream, g, tab, scr, nopm, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));
             } else if (k <= 64) {
-                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 1>), grid, block, 0, stream, g, tab, scr, nopm);
-                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 1>), grid, block, 0, stream, g, tab, scr, nopm);
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 1>), grid, block, 0, stream, g, tab, scr, nopm, make_stream_screen<T, 64>(htab, scr, (int)k, n_looks));
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 1>), grid, block, 0, stream, g, tab, scr, nopm, make_stream_screen<T, 64>(htab, scr, (int)k, n_looks));
             } else {
-                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 2>), grid, block, 0, stream, g, tab, scr, nopm);
-                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 2>), grid, block, 0, stream, g, tab, scr, nopm);
+                if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 2>), grid, block, 0, stream, g, tab, scr, nopm, make_stream_screen<T, 128>(htab, scr, (int)k, n_looks));
+                else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 2>), grid, block, 0, stream, g, tab, scr, nopm, make_stream_screen<T, 128>(htab, scr, (int)k, n_looks));
             }
             g.blocks_per_row = bpr_keep;
         }

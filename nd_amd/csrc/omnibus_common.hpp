@@ -373,6 +373,117 @@ static DenseScreen make_dense_screen(const std::vector<OmniTabEntry> &tab, int k
     return s;
 }
 
+// ---- constants of the streaming search (omnibus.hip: omnibus_c2_stream_kernel) -----------------
+// The kernel walks the dates last to first, so the global test it meets at step jj = 1, 2, ... is
+// the one over jj dates whatever k is: entry jj is read with one scalar load from the kernel's
+// argument segment (a wave-uniform index into a by-value argument compiles to s_load_dwordx8), no
+// vector instruction, no LDS.  jf / cj / mj are the wave-uniform factors of the rounding band of
+// that test (see the kernel), precomputed so that they cost no conversions on the device.
+struct StreamEntry {
+    int re;
+    float rf, a, b;     // as DenseScreenEntry
+    float jf;           // (float) jj
+    float cj;           // 1.46 * 5 u * jj:  rel = cj * s11 s22 / det
+    float mj;           // 1.01 * jj:        band = mj * rel
+    float pad;
+};
+// The 2- and 3-date marginal tests are decided without logarithms: with L2 = log2(prod det_t) -
+// j log2 det(sum),  L2 < Lhi  <=>  prod det_t < 2^Lhi det(sum)^j.  The products of two or three
+// determinants are formed in `floating` (each determinant inside [dlo, dhi], so the product is a
+// normal number with j - 1 roundings), det(sum)^j with j - 1 roundings, the constant with one:
+// <= 6 half-ulps, 4.3e-7 in log2 units at float32; the constants carry a margin of 4e-6.
+//   prod < ca_j * det(sum)^j  =>  the test fires for certain;  prod > cb_j * det(sum)^j  =>  it cannot.
+// A right-hand side that underflows is harmless (the product is a normal number, larger than
+// anything that underflows: both verdicts are then true statements); overflow is excluded by
+// det(sum) < dhi_s and ca, cb <= 64.
+template <int NJ>
+struct StreamScreen {
+    StreamEntry e[NJ + 1];
+    float ca2, cb2, ca3, cb3;
+    float dlo, dhi;       // a date's determinant must lie strictly inside (dlo, dhi)
+    float slo, shi;       // ... and a 2- / 3-date sum's determinant inside (slo, shi)
+};
+
+template <typename T>
+static void stream_marginal_bounds(const OmniTabEntry &t, int j, uint32_t n_looks, float *ca, float *cb)
+{
+    *ca = 0.f;            // never "fires for certain"
+    *cb = INFINITY;       // never "cannot fire"
+    const double c = t.m2rho * (double)n_looks * 0.6931471805599453;
+    const double z0 = t.m2rho * (double)n_looks * t.pklogk;
+    if (j < 2 || !(c < 0.0) || !(c > -INFINITY) || !(z0 == z0) || !(fabs(z0) < INFINITY)) return;
+    if (t.zlo == INFINITY) {          // P <= 1 < alpha: nothing can fire
+        *cb = 0.f;
+        return;
+    }
+    const double eps = sizeof(T) == 4 ? 1.1920928955078125e-07 : 2.220446049250313e-16;
+    const double mgp = 4e-6;
+    if (t.zhi < INFINITY && t.zhi > -INFINITY) {
+        const double zr = 2.0 * eps * fabs(t.zhi);
+        double L = (t.zhi + zr - z0) / c;
+        L -= mgp + 1e-12 * fabs(L);
+        if (L == L && L > -100.0) {
+            if (L > 6.0) L = 6.0;                                // a weaker claim, still true
+            float v = (float)exp2(L);
+            if ((double)v > exp2(L)) v = nextafterf(v, 0.f);     // rounded down
+            *ca = v;
+        }
+    }
+    if (t.zlo > -INFINITY && t.zlo < INFINITY) {
+        const double zr = 2.0 * eps * fabs(t.zlo);
+        double L = (t.zlo - zr - z0) / c;
+        L += mgp + 1e-12 * fabs(L);
+        if (L == L && L <= 6.0) {
+            if (L < -100.0) L = -100.0;                          // a weaker claim, still true
+            float v = (float)exp2(L);
+            if ((double)v < exp2(L)) v = nextafterf(v, INFINITY);   // rounded up
+            *cb = v;
+        }
+    }
+    if (!(*ca <= *cb)) {              // cannot happen (zlo <= zhi); be safe: exact only
+        *ca = 0.f;
+        *cb = INFINITY;
+    }
+}
+
+template <typename T, int NJ>
+static StreamScreen<NJ> make_stream_screen(const std::vector<OmniTabEntry> &tab, const DenseScreen &scr,
+                                           int k, uint32_t n_looks)
+{
+    StreamScreen<NJ> s;
+    memset(&s, 0, sizeof(s));
+    const float cu = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 7.5f;   // 1.46 * 5 u, rounded up
+    for (int j = 0; j <= NJ; ++j) {
+        s.e[j].re = scr.e[j].re;
+        s.e[j].rf = scr.e[j].rf;
+        s.e[j].a = scr.e[j].a;
+        s.e[j].b = scr.e[j].b;
+        s.e[j].jf = (float)j;
+        s.e[j].cj = cu * (float)j;
+        s.e[j].mj = (float)j * 1.01f;
+    }
+    s.ca2 = s.ca3 = 0.f;
+    s.cb2 = s.cb3 = INFINITY;
+    if (k >= 2) stream_marginal_bounds<T>(tab[2], 2, n_looks, &s.ca2, &s.cb2);
+    if (k >= 3) stream_marginal_bounds<T>(tab[3], 3, n_looks, &s.ca3, &s.cb3);
+    // float32: determinants of a date inside 2^+-36 (products of three stay normal numbers: 2^+-108),
+    // of a sum below 2^40 (its cube, times a constant <= 64, stays finite); float64: 2^+-100, 2^110.
+    // Pixels outside go to the exact pass.  The running double product of the determinants then moves
+    // by at most 36 (100) binary orders per date: see the kernel's range check.
+    if (sizeof(T) == 4) {
+        s.dlo = 1.4551915228366852e-11f;     // 2^-36
+        s.dhi = 68719476736.f;               // 2^36
+        s.slo = 1.4551915228366852e-11f;
+        s.shi = 1099511627776.f;             // 2^40
+    } else {
+        s.dlo = 7.888609052210118e-31f;      // 2^-100
+        s.dhi = 1.2676506002282294e30f;      // 2^100
+        s.slo = 7.888609052210118e-31f;
+        s.shi = 1.298074214633707e33f;       // 2^110
+    }
+    return s;
+}
+
 // ---- device side of the screen (shared by the dual-pol and the full-pol kernels) ---------------
 // log2 of a positive finite x as (exponent, log2 of the mantissa in [0.5, 1)): the mantissa's
 // log2 comes from the hardware v_log_f32 (<= 1 ulp of a value in [-1, 0], i.e. <= 6e-8 absolute).
@@ -462,6 +573,46 @@ __device__ __forceinline__ bool mask_bit(const Bits128 &m, const int i)
 {
     return (((i < 64 ? m.lo : m.hi) >> (i & 63)) & 1ull) != 0ull;
 }
+// m = 2 m + bit: the streaming search meets the dates last to first, so after the last push the
+// bit of date t sits at position t
+template <typename M>
+__device__ __forceinline__ void mask_push(M &m, const bool bit)
+{
+    m = (m + m) + (M)(bit ? 1 : 0);
+}
+// 32 bits: one add-with-carry whose carry-in is the condition's lane mask (the compiler's own
+// selection is v_cndmask + v_lshl_or).  The carry-out lands in a scalar pair nobody reads.
+__device__ __forceinline__ void mask_push(unsigned &m, const bool bit)
+{
+    const unsigned long long cin = __builtin_amdgcn_ballot_w64(bit);
+    unsigned long long cout;
+    unsigned r;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(cout) : "v"(m), "s"(cin));
+    m = r;
+}
+__device__ __forceinline__ void mask_push(Bits128 &m, const bool bit)
+{
+    m.hi = (m.hi + m.hi) + (m.lo >> 63);
+    m.lo = (m.lo + m.lo) + (bit ? 1ull : 0ull);
+}
+// bits 0 .. n - 1 (0 <= n <= width)
+template <typename M>
+__device__ __forceinline__ M mask_low(const int n)
+{
+    return n >= (int)(8 * sizeof(M)) ? ~(M)0 : (((M)1 << n) - (M)1);
+}
+template <typename M>
+__device__ __forceinline__ void mask_keep_low(M &m, const int n)
+{
+    m &= mask_low<M>(n);
+}
+__device__ __forceinline__ void mask_keep_low(Bits128 &m, const int n)
+{
+    m.lo &= mask_low<unsigned long long>(n < 64 ? n : 64);
+    m.hi &= mask_low<unsigned long long>(n < 64 ? 0 : n - 64);
+}
+__device__ __forceinline__ int mask_ctz(const unsigned m) { return __builtin_ctz(m); }
+__device__ __forceinline__ int mask_ctz(const unsigned long long m) { return __builtin_ctzll(m); }
 // bits 4 q .. 4 q + 3
 template <typename M>
 __device__ __forceinline__ unsigned mask_nibble(const M &m, const int q)
