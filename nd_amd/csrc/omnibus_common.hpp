@@ -373,6 +373,8 @@ static DenseScreen make_dense_screen(const std::vector<OmniTabEntry> &tab, int k
     return s;
 }
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
 // ---- constants of the streaming search (omnibus.hip: omnibus_c2_stream_kernel) -----------------
 // The kernel walks the dates last to first, so the global test it meets at step jj = 1, 2, ... is
 // the one over jj dates whatever k is: entry jj is read with one scalar load from the kernel's
@@ -395,13 +397,12 @@ struct StreamEntry {
 //   prod < ca_j * det(sum)^j  =>  the test fires for certain;  prod > cb_j * det(sum)^j  =>  it cannot.
 // A right-hand side that underflows is harmless (the product is a normal number, larger than
 // anything that underflows: both verdicts are then true statements); overflow is excluded by
-// det(sum) < dhi_s and ca, cb <= 64.
+// det(sum) < dhi and ca, cb <= 64.
 template <int NJ>
 struct StreamScreen {
     StreamEntry e[NJ + 1];
-    float ca2, cb2, ca3, cb3;
-    float dlo, dhi;       // a date's determinant must lie strictly inside (dlo, dhi)
-    float slo, shi;       // ... and a 2- / 3-date sum's determinant inside (slo, shi)
+    f2_t ca, cb;          // .x: the 2-date test, .y: the 3-date test (pairs: operands of packed multiplications)
+    float dlo, dhi;       // a date's determinant and those of the 2- / 3-date sums: strictly inside (dlo, dhi)
 };
 
 template <typename T>
@@ -462,24 +463,23 @@ static StreamScreen<NJ> make_stream_screen(const std::vector<OmniTabEntry> &tab,
         s.e[j].cj = cu * (float)j;
         s.e[j].mj = (float)j * 1.01f;
     }
-    s.ca2 = s.ca3 = 0.f;
-    s.cb2 = s.cb3 = INFINITY;
-    if (k >= 2) stream_marginal_bounds<T>(tab[2], 2, n_looks, &s.ca2, &s.cb2);
-    if (k >= 3) stream_marginal_bounds<T>(tab[3], 3, n_looks, &s.ca3, &s.cb3);
-    // float32: determinants of a date inside 2^+-36 (products of three stay normal numbers: 2^+-108),
-    // of a sum below 2^40 (its cube, times a constant <= 64, stays finite); float64: 2^+-100, 2^110.
-    // Pixels outside go to the exact pass.  The running double product of the determinants then moves
-    // by at most 36 (100) binary orders per date: see the kernel's range check.
+    float ca2 = 0.f, ca3 = 0.f, cb2 = INFINITY, cb3 = INFINITY;
+    if (k >= 2) stream_marginal_bounds<T>(tab[2], 2, n_looks, &ca2, &cb2);
+    if (k >= 3) stream_marginal_bounds<T>(tab[3], 3, n_looks, &ca3, &cb3);
+    s.ca.x = ca2;
+    s.ca.y = ca3;
+    s.cb.x = cb2;
+    s.cb.y = cb3;
+    // float32: the determinants of a date and of the 2- / 3-date sums inside 2^+-36 (a product of
+    // three stays a normal number, 2^+-108; a cube times a constant <= 64 stays finite); float64:
+    // 2^+-100.  Pixels outside go to the exact pass.  The running double product of the determinants
+    // then moves by at most 36 (100) binary orders per date: see the kernel's range check.
     if (sizeof(T) == 4) {
         s.dlo = 1.4551915228366852e-11f;     // 2^-36
         s.dhi = 68719476736.f;               // 2^36
-        s.slo = 1.4551915228366852e-11f;
-        s.shi = 1099511627776.f;             // 2^40
     } else {
         s.dlo = 7.888609052210118e-31f;      // 2^-100
         s.dhi = 1.2676506002282294e30f;      // 2^100
-        s.slo = 7.888609052210118e-31f;
-        s.shi = 1.298074214633707e33f;       // 2^110
     }
     return s;
 }
@@ -610,6 +610,16 @@ __device__ __forceinline__ void mask_keep_low(Bits128 &m, const int n)
 {
     m.lo &= mask_low<unsigned long long>(n < 64 ? n : 64);
     m.hi &= mask_low<unsigned long long>(n < 64 ? 0 : n - 64);
+}
+// bits where neither "fires" nor "cannot fire" is set
+template <typename M>
+__device__ __forceinline__ M mask_undecided(const M &f, const M &c)
+{
+    return (M) ~(f | c);
+}
+__device__ __forceinline__ Bits128 mask_undecided(const Bits128 &f, const Bits128 &c)
+{
+    return Bits128{~(f.lo | c.lo), ~(f.hi | c.hi)};
 }
 __device__ __forceinline__ int mask_ctz(const unsigned m) { return __builtin_ctz(m); }
 __device__ __forceinline__ int mask_ctz(const unsigned long long m) { return __builtin_ctzll(m); }
