@@ -1205,6 +1205,7 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
 {
     if (omni_gate_skip(g)) return;
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    __shared__ __align__(16) uint32_t out_img[(kRetainThreads / 64) * 16 * KMAX];   // store_change_rows_wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t b = blockIdx.x;
@@ -1282,7 +1283,9 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
         const ScreenRegs scr = screen_regs_load(scr_lds, lane);
         dense_search<T, KMAX>(v, ks, in, scr, mask, handoff);
         if (handoff) mask = 0u;                               // pass B writes that pixel's changes
-        if (in) {
+        if (change_rows_wave_ok(wob, k, wnp)) {
+            store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * KMAX), k, mask, lane);
+        } else if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
             if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
                 uint32_t *w = reinterpret_cast<uint32_t *>(res);
@@ -1948,20 +1951,8 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
             }
         }
         if (handoff) mask = mask_zero<MT>();                  // pass B writes that pixel's changes
-        if (wnp == 64 && (k & 3) == 0 && ((uintptr_t)wob & 15) == 0) {
-            // The wave's 64 rows are 64 k contiguous bytes.  A lane storing its own row writes 4-byte
-            // pieces k bytes apart -- k / 4 store instructions that each touch every line of the
-            // span (0.24 ms of a 1.3 ms launch for 0.4 GB).  Through a wave-private LDS image the
-            // same bytes leave as 16-byte pieces of consecutive lanes.
-            uint32_t *img = out_img + (tid >> 6) * (16 * kMaxDates);
-            const int kq = k >> 2;
-            for (int q = 0; q < kq; ++q)
-                img[lane * kq + q] = (mask_nibble(mask, q) * 0x00204081u) & 0x01010101u;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS operations complete in order
-            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-            const u4 *src = reinterpret_cast<const u4 *>(img);
-            u4 *dst = reinterpret_cast<u4 *>(wob);
-            for (int c = lane; c < 4 * k; c += 64) __builtin_nontemporal_store(src[c], dst + c);
+        if (change_rows_wave_ok(wob, k, wnp)) {
+            store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * kMaxDates), k, mask, lane);
         } else if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
             if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
@@ -2026,6 +2017,9 @@ struct OmniSearchArgs {
     unsigned long long *hand_bits;
     uint32_t hand_words;          // words per shard
     uint32_t *hand_count;         // number of marked pixels (zeroed with the list counters)
+    // Shards whose list holds at most this many pixels are searched by omnibus_c2_search_starts_kernel
+    // (one lane per segment start), the longer ones by the LDS form; 0: the LDS form takes everything.
+    uint32_t starts_max;
 };
 
 // MODE 0: series staged in LDS; MODE 1: no LDS, each date read straight from the dump (or the
@@ -2067,6 +2061,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     const unsigned nlblock = gridDim.x / kShards;
     const uint32_t n = s.flag_count[shard * kCounterStride];
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+    if (n <= s.starts_max) return;             // omnibus_c2_search_starts_kernel searches this shard
 
     for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
         const uint32_t idx = base + lane;
@@ -2231,6 +2226,119 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     } else {
                         done = true;                       // :241-242
                     }
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// pass B, one lane per SEGMENT START (short lists; 3 <= k <= 65).  Behind the fused search the list
+// holds the few pixels its screen could not decide (a few thousand of 16.7 M), and nearly every
+// date of such a pixel is a change: the LDS form walks two dozen segments one after the other,
+// each to the end of the series (the global test) -- ~300 dependent date steps, 0.13 - 0.17 ms
+// for 5 000 pixels, the time of ONE wave.  Here lane l of a pixel's group sweeps ts[l:] once, on its
+// own: nxt(l) = the date of the first firing marginal test if the global test over ts[l:] fires,
+// "stop" otherwise -- the same evaluations, in the same order and arithmetic, as the sweep of
+// the LDS form started at l.  The pixel's changes are then the chain 0 -> nxt(0) -> nxt(nxt(0)) ...
+// (nd/_change.pyx:235-257), followed by the group's first lane through wave shuffles.  The work is
+// the same k^2 / 2 date steps per pixel as the LDS form's in this regime; the dependent chain is k.
+// -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const OmniSearchArgs<T> s)
+{
+    const int lane = threadIdx.x;
+    const int k = s.k;
+    const int ns = k - 1;                       // segment starts per pixel: 0 .. k - 2
+    const int ppw = 64 / ns;                    // pixels per wave
+    const int grp = lane / ns;
+    const int l = lane - grp * ns;
+    const unsigned shard = blockIdx.x % kShards;
+    const unsigned lblock = blockIdx.x / kShards;
+    const unsigned nlblock = gridDim.x / kShards;
+    const uint32_t n = s.flag_count[shard * kCounterStride];
+    if (n > s.starts_max) return;               // a long list: the LDS form
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+    const OmniTabEntry *tabp = s.tab;
+
+    for (uint32_t base = lblock * (uint32_t)ppw; base < n; base += nlblock * (uint32_t)ppw) {
+        const uint32_t idx = base + (uint32_t)grp;
+        const bool active = (grp < ppw) && (idx < n);
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+        const int64_t row = pix / s.nx;
+        const int64_t col = pix - row * s.nx;
+        const int64_t off = row * s.sy + col * s.sx;
+        const bool from_dump = active && idx < s.dump_cap;
+        const T *dsrc = s.dump + ((int64_t)shard * s.dump_cap + (from_dump ? idx : 0)) * (int64_t)(4 * k);
+        auto fetch = [&](int t) -> Pack<T, 4> {
+            Pack<T, 4> q;
+            if (from_dump) {
+                q = *reinterpret_cast<const Pack<T, 4> *>(dsrc + 4 * t);
+            } else {
+                const int64_t o = off + (int64_t)t * s.st;
+                q.v[0] = s.c11[o * s.m11];
+                q.v[1] = s.c12r[o * s.m12];
+                q.v[2] = s.c12i[o * s.m12];
+                q.v[3] = s.c22[o * s.m22];
+            }
+            return q;
+        };
+        Accum<T> A;
+        A.reset();
+        int fire_at = -1;
+        int nxt = -1;                           // stop
+        // (idle lanes load nothing: a stand-in read of pixel 0 from 4 x k planes far apart would put
+        // its address translations on every step's critical path)
+        Pack<T, 4> cur;
+        cur.v[0] = cur.v[1] = cur.v[2] = cur.v[3] = (T)0;
+        if (active) cur = fetch(l);
+        for (int i = 0; i < k; ++i) {           // the lane's date is l + i
+            const int t = l + i;
+            const bool on = active && t < k;
+            if (!__any(on)) break;
+            Pack<T, 4> ahead = cur;
+            if (on && t + 1 < k) ahead = fetch(t + 1);        // in flight while this date is evaluated
+            if (on) A.step(cur.v[0], cur.v[1], cur.v[2], cur.v[3]);
+            cur = ahead;
+            const int jj = i + 1;
+            const bool last = (t == k - 1);
+            const bool need = on && (jj >= 2) && (fire_at < 0 || last);
+            bool fires = false, inband = false;
+            if (need) {
+                const OmniTabEntry &e = tabp[jj];
+                const double za = z_approx<T>(A, jj, s.nlooks, e.m2rho, e.pklogk);
+                fires = (za > e.zhi_a) && (za < INFINITY);
+                inband = (za >= e.zlo_a) && !fires;
+            }
+            if (__any(inband)) {
+                if (inband) {
+                    const OmniTabEntry e = tabp[jj];
+                    const T zp = z_stat<T>(A, jj, s.nlooks, e);
+                    const double zd = (double)zp;
+                    int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                    if (verdict == 2) {
+                        double zv[1] = {zd}, P1[1], P2[1];
+                        chisq_pair<1>(zv, 4 * (jj - 1), e.lgam, P1, P2);
+                        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                        verdict = ((double)P > s.alpha) ? 1 : 0;
+                    }
+                    fires = (verdict == 1);
+                }
+            }
+            if (on && fires && fire_at < 0) fire_at = t;
+            if (on && last && fires) nxt = fire_at;          // the global test of ts[l:] fired (jj >= 2 here)
+        }
+        // follow the chain from l = 0; the group's first lane writes the changes
+        int at = 0;
+        for (int step = 0; step < ns; ++step) {
+            const int src = grp * ns + (at >= 0 && at < ns ? at : 0);
+            const int n1 = __shfl(nxt, src);
+            if (at >= 0 && at < ns) {
+                if (n1 < 0) {
+                    at = -1;                                   // :241-242
+                } else {
+                    if (active && l == 0) s.change[pix * (int64_t)k + n1] = 1;   // :252 (the row was zero-filled)
+                    at = n1;                                   // :255; n1 = k - 1 ends the search (:256)
                 }
             }
         }
@@ -2901,6 +3009,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         s.hand_bits = nullptr;
         s.hand_words = hand_words;
         s.hand_count = const_cast<uint32_t *>(count) + 3;    // word 3 of the lists' first counter line
+        s.starts_max = 0;
         const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);      // screen constants
         const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T) + scr_bytes;
         // the LDS image of 64 series may take up to 150 KB of the CU's 160 KB: for long series that is
@@ -2949,8 +3058,22 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<float, 32>), gr, bl, 0, sq,
                                    reinterpret_cast<const OmniSearchArgs<float> &>(s), scr);
         }
+        // Behind the fused search: short lists (what its screen could not decide) one lane per
+        // segment start, long ones (a raster the sample found sparse after all: many candidates
+        // with few changes each) in the LDS form.  The choice is made per shard, on the device.
+        static const int starts_env = [] {
+            const char *e = getenv("ND_AMD_SEARCH_STARTS");      // list length per shard up to which ...; 0 = off
+            return e ? atoi(e) : 512;
+        }();
+        const bool starts_form = low_threshold && !regs_form && k >= 2 && k <= 65 && starts_env > 0 &&
+                                 mode_env < 0;
+        if (starts_form) {
+            s.starts_max = (uint32_t)starts_env;
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+            hipLaunchKernelGGL((omnibus_c2_search_starts_kernel<T>), dim3((unsigned)sblocks), dim3(64), 0, sq, s);
+        }
         // the exact form: every listed pixel, or (behind the register form) the marked ones
-        KernelTimer timer(regs_form ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+        KernelTimer timer((regs_form || starts_form) ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
         // (behind the register form there is usually nothing left: the from-memory form, whose
         // blocks reserve no LDS, and a quarter of the blocks)
         const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !regs_form) ? 0 : 1);
@@ -3012,14 +3135,21 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
                 g.gate_mode = gated ? 1 : 0;
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
-                static const bool pm_lds = getenv("ND_AMD_PM_STREAM_LDS") != nullptr;
-                // Two forms of the from-memory search, same map.  Measured on 24 x 4096^2 (alpha = 0.01 /
-                // 1e-4): one 16-byte piece per variable and step, two steps ahead, 104 VGPRs: 3.23 /
-                // 3.77 ms; two adjacent pieces per variable and step (a sector is fetched by two steps
-                // instead of four, interleaved C12 once), 144 VGPRs: 3.52 / 3.12 ms; LDS images:
-                // 4.34 / 3.95 ms.  At very low thresholds every marginal test fires at once, the
-                // waves run in lockstep and the sector form wins; with the ~1 % of deep searches of
-                // alpha = 0.01 the waves drift apart and the lighter form wins.
+                // Three forms of the search on pixel-major data, same map.  LDS images (each sector
+                // of the input fetched once; 24.6 KB per wave, six waves per CU) and two from-memory
+                // forms (no LDS, full occupancy, but a lane's 16-byte pieces make every sector of
+                // C11 / C22 cross the L2 two to four times: 23.8 GB of traffic for 6.4 GB of data).
+                // Round 2 (140 vector instructions per date): images 4.34 / 3.95 ms at alpha = 0.01 /
+                // 1e-4, one piece per step 3.23 / 3.77, sector pairs 3.52 / 3.12.  Round 3 (86 per
+                // date, no table in LDS): images 2.39 / 2.05 ms, from memory 3.00 / 3.35 -- with less
+                // to issue per date six waves per CU keep up and the single fetch wins.
+                // ND_AMD_PM_STREAM_LDS=0 selects the from-memory forms, ND_AMD_PM_STREAM_SECTOR=0/1
+                // one of the two.
+                static const bool pm_lds = [] {
+                    const char *e = getenv("ND_AMD_PM_STREAM_LDS");
+                    if (e) return atoi(e) != 0;
+                    return getenv("ND_AMD_PM_STREAM_SECTOR") == nullptr;
+                }();
                 static const int pm_sector_env = [] {
                     const char *e = getenv("ND_AMD_PM_STREAM_SECTOR");
                     return e ? atoi(e) : -1;

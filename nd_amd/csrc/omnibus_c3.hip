@@ -218,6 +218,8 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
     typedef typename std::conditional<MW == 2, Bits128, unsigned long long>::type MT;
     typedef typename std::conditional<MW == 2, long long, int>::type LmT;
     __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    constexpr int kMaxDates = MW == 2 ? 128 : 64;
+    __shared__ __align__(16) uint32_t out_img[(kC3Threads / 64) * 16 * kMaxDates];   // store_change_rows_wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t b = blockIdx.x;
     const int64_t row = b / g.blocks_per_row;
@@ -453,7 +455,9 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
             }
         }
         if (handoff) mask = mask_zero<MT>();                  // pass B writes that pixel's changes
-        if (in) {
+        if (change_rows_wave_ok(wob, k, wnp)) {
+            store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * kMaxDates), k, mask, lane);
+        } else if (in) {
             uint8_t *res = wob + (int64_t)lane * k;
             if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
                 uint32_t *w = reinterpret_cast<uint32_t *>(res);

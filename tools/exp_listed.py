@@ -17,5 +17,6 @@ for alpha in [float(x) for x in os.environ.get('ALPHAS', '1e-4,0.01,0.05').split
                                    kernels._DT[st.dtype], ny, nx, k, p.stride(1), p.stride(2), p.stride(0), 9, alpha,
                                    kernels._ptr(change), None, None, kernels._ptr(ws), nbytes, kernels._stream_ptr(dev)))
     torch.cuda.synchronize()
-    cnt = ws[:128 * 32 * 4].view(torch.int32).view(128, 32)[:, 0].sum().item()
-    print(json.dumps({'alpha': alpha, 'listed': int(cnt), 'fraction': cnt / (ny * nx)}))
+    per = ws[:128 * 32 * 4].view(torch.int32).view(128, 32)[:, 0]
+    cnt = per.sum().item()
+    print(json.dumps({'alpha': alpha, 'listed': int(cnt), 'fraction': cnt / (ny * nx), 'shard_max': int(per.max().item()), 'shard_min': int(per.min().item())}))
