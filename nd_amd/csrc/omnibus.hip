@@ -1090,6 +1090,153 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
     handoff_out = handoff;
 }
 
+// -----------------------------------------------------------------------------------------
+// The same search in two passes over the registers, linear in k (round 3).
+//
+// dense_search above walks a triangle: one row per segment start, each row re-adding its dates.
+// But single_pixel_change_detection consumes every date ONCE: within a segment the marginal tests
+// j = 2, 3, ... extend one running sum date by date, and where one fires the next segment starts at
+// that very date (nd/_change.pyx:247-256).  The only thing that looks ahead is the global test of
+// ts[l:], asked at each segment start.  So:
+//   pass 1 (dates last to first, as in omnibus_c2_stream_kernel): the global test of EVERY start
+//           from suffix sums in double, with the rounding band of the reference's forward float
+//           sums; two bits per date (fires / cannot fire).
+//   pass 2 (dates first to last, date index wave-uniform, every lane busy at every date): each lane
+//           carries the reference's own running state of its CURRENT segment -- the four sums in
+//           `floating`, started as 0 + a_l, and the double product of the determinants -- adds date
+//           t, and decides the marginal test over its j = t - l + 1 dates (bit-identical
+//           determinants, tight band; the constants of the lane's own j come from an LDS table).
+//           Where it fires: change at t, and if the global test of ts[t:] (pass 1) fires too the
+//           state restarts as date t alone; if that test cannot fire the lane is finished; an
+//           undecided test of either kind hands the pixel to the exact pass.  At the last date the
+//           marginal test IS the global test of the segment, which fired.
+// ~105 vector instructions per date in all, whatever the threshold: no rows, no deep searches,
+// no divergence.
+// -----------------------------------------------------------------------------------------
+template <typename T, int KMAX, int NJ>
+__device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, const bool active,
+                                            const StreamScreen<NJ> &ss, const StreamEntry *tab_lds,
+                                            unsigned &mask_out, bool &handoff_out, bool &cand_out)
+{
+    static_assert(KMAX <= 32 && KMAX <= NJ, "32-bit masks");
+    constexpr int kmin = KMAX == 8 ? 2 : KMAX - 7;      // the instantiation serves kmin <= k <= KMAX
+    const T dlo = (T)ss.dlo, dhi = (T)ss.dhi;
+    unsigned gF = 0u, gC = 0u;
+    bool bad = false, dead = false;
+    {
+        double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0, PP = 1.0;
+        int emin = 1, emax = 1;
+#pragma unroll
+        for (int t = KMAX - 1; t >= 0; --t) {
+            // branch-free: elements beyond k hold a copy of a valid date and are masked out
+            const bool live = (t < kmin) || (t < k);
+            const T a = v[t][0], b = v[t][1], c = v[t][2], d = v[t][3];
+            const T det = (a * d) - ((b * b) + (c * c));
+            bad = bad | (live & !((a > (T)0) & (det > dlo) & (det < dhi)));
+            dead = dead | (live & !((det > (T)0) | (det < (T)0)));
+            PP = PP * (live ? (double)det : 1.0);
+            S11 += live ? (double)a : 0.0;
+            S12r += live ? (double)b : 0.0;
+            S12i += live ? (double)c : 0.0;
+            S22 += live ? (double)d : 0.0;
+            const int jr = k - t;
+            const int jj = jr > 0 ? jr : 0;
+            const StreamEntry e = ss.e[jj];                  // wave-uniform: one scalar load
+            const double pp = S11 * S22;
+            const double dets = pp - ((S12r * S12r) + (S12i * S12i));
+            const float df = (float)dets;
+            bool okd;
+            int es, eP;
+            float ms, mP;
+            if (sizeof(T) == 4) {
+                okd = df > 7.888609052210118e-31f;
+                log2_parts(df, es, ms);
+            } else {
+                okd = (dets > 0.0) & (dets < (double)INFINITY);
+                log2_parts(dets, es, ms);
+            }
+            log2_parts(PP, eP, mP);
+            emin = eP < emin ? eP : emin;
+            emax = eP > emax ? eP : emax;
+            const int E = (eP - e.re) - __mul24(jj, es);
+            const float x = (float)E + __builtin_fmaf(-e.jf, ms, mP - e.rf);
+            const float qq = (float)pp * __builtin_amdgcn_rcpf(df);
+            const float rel = e.cj * qq;                     // 1.46 * 5 n u * s11 s22 / det
+            const float m2 = e.mj * rel;
+            bad = bad | (live & !(okd & (rel < 0.01f)));
+            mask_push(gF, x + m2 < e.a);
+            mask_push(gC, x - m2 > e.b);
+            __builtin_amdgcn_sched_barrier(0);               // one date at a time (registers)
+        }
+        bad = bad | (emax - emin > 900);
+    }
+    // KMAX pushes: the bit of date t sits at position t
+    unsigned gI = ~(gF | gC);
+    mask_keep_low(gF, k - 1);
+    mask_keep_low(gI, k - 1);
+    if (dead) {                                 // a NaN or zero determinant: no change anywhere, no exact pass
+        bad = false;
+        gF = 0u;
+        gI = 0u;
+    }
+    cand_out = active && (bad || ((gF | gI) & 1u));
+    bool handoff = active && (bad || (gI & 1u));
+    bool done = !active || bad || !(gF & 1u) || (gI & 1u);
+    unsigned mask = 0u;
+    // the running state of the segment that starts at date 0 (0 + a_0 = a_0)
+    T s11 = v[0][0], s12r = v[0][1], s12i = v[0][2], s22 = v[0][3];
+    double PP = (double)((v[0][0] * v[0][3]) - ((v[0][1] * v[0][1]) + (v[0][2] * v[0][2])));
+    int j = 1;
+#pragma unroll
+    for (int t = 1; t < KMAX; ++t) {
+        const bool live = (t < kmin) || (t < k);
+        const bool last = (t == k - 1);
+        T a = v[t][0];
+        const T b = v[t][1], c = v[t][2], d = v[t][3];
+        // (opaque to the optimiser: it would otherwise keep the 24 determinants of pass 1, and their
+        // conversions to double, alive in 72 registers instead of recomputing them here)
+        asm volatile("" : "+v"(a));
+        const T det = (a * d) - ((b * b) + (c * c));
+        s11 = s11 + a;
+        s12r = s12r + b;
+        s12i = s12i + c;
+        s22 = s22 + d;
+        PP = PP * (double)det;
+        j = j + 1;
+        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+        const bool oks = (dets > (T)0) & (dets < (T)INFINITY);
+        const StreamEntry *ep = tab_lds + j;                 // the lane's own j
+        const int re = ep->re;
+        const float rf = ep->rf, ca = ep->a, cb = ep->b;
+        int es, eP;
+        float ms, mP;
+        log2_parts(dets, es, ms);
+        log2_parts(PP, eP, mP);
+        const int E = (eP - re) - __mul24(j, es);
+        const float x = (float)E + __builtin_fmaf(-(float)j, ms, mP - rf);
+        const bool fires = last | (oks & (x < ca));
+        const bool cant = !last & oks & (x > cb);
+        const bool act = !done & live;
+        const bool und = act & !(fires | cant);
+        const bool f = act & fires;
+        handoff = handoff | und;
+        mask |= f ? (1u << t) : 0u;                          // :252
+        // the segment that starts at t (:255): its global test was decided in pass 1
+        const bool gi = (gI >> t) & 1u, gf = (gF >> t) & 1u;
+        handoff = handoff | (f & !last & gi);
+        done = done | und | (f & (last | gi | !gf));         // :256, :241-242
+        s11 = f ? a : s11;
+        s12r = f ? b : s12r;
+        s12i = f ? c : s12i;
+        s22 = f ? d : s22;
+        PP = f ? (double)det : PP;
+        j = f ? 1 : j;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mask_out = mask;
+    handoff_out = handoff;
+}
+
 // One lane's whole row of the change map from its mask: every byte is written.
 __device__ __forceinline__ void store_change_row(uint8_t *res, const int k, const unsigned long long mask)
 {
@@ -1282,6 +1429,128 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
         asm volatile("" : "+s"(ks));
         const ScreenRegs scr = screen_regs_load(scr_lds, lane);
         dense_search<T, KMAX>(v, ks, in, scr, mask, handoff);
+        if (handoff) mask = 0u;                               // pass B writes that pixel's changes
+        if (change_rows_wave_ok(wob, k, wnp)) {
+            store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * KMAX), k, mask, lane);
+        } else if (in) {
+            uint8_t *res = wob + (int64_t)lane * k;
+            if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
+                uint32_t *w = reinterpret_cast<uint32_t *>(res);
+#pragma unroll
+                for (int q = 0; q < KMAX / 4; ++q)
+                    if (q < (k >> 2)) w[q] = (((mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+            } else {
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & 1u);
+            }
+        }
+        listed = handoff;
+    }
+    if (__any(listed)) {
+        const unsigned long long lm_ = __ballot(listed);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(lm_));
+        base = __shfl(base, 0);
+        if (listed) {
+            const unsigned slot = base + (unsigned)__popcll(lm_ & ((1ull << lane) - 1ull));
+            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
+            if (slot < g.dump_cap) {
+                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t) {
+                    if (EXACT || t < k) {
+                        Pack<T, 4> q;
+                        q.v[0] = v[t][0];
+                        q.v[1] = v[t][1];
+                        q.v[2] = v[t][2];
+                        q.v[3] = v[t][3];
+                        *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
+                    }
+                }
+            }
+        }
+    }
+    // ---- a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275)
+    if (!dense && wnp > 0) zero_fill_span(wob, wnp * k, lane);
+}
+
+// -----------------------------------------------------------------------------------------
+// pass A with the search fused in, two linear passes over the retained series (dense_chain): the
+// form for thresholds at which marginal tests beyond three dates are common (everything between
+// the reference's default 0.01 and the sparse regime).  Same loads as omnibus_c2_retain_kernel.
+// -----------------------------------------------------------------------------------------
+template <typename T, int KMAX, bool EXACT>
+__global__ void __launch_bounds__(kRetainThreads, 3)
+omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const StreamScreen<32> ss)
+{
+    if (omni_gate_skip(g)) return;
+    __shared__ StreamEntry tab_lds[33];       // the marginal tests' constants: a lane reads those of its own j
+    __shared__ __align__(16) uint32_t out_img[(kRetainThreads / 64) * 16 * KMAX];   // store_change_rows_wave
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kRetainThreads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = EXACT ? KMAX : g.k;
+    const bool in = x0 < g.nx;
+
+    // ---- issue every load of the series (as in omnibus_c2_retain_kernel) ----
+    T v[KMAX][4];
+    if (EXACT) {
+        const int64_t ub = row * g.sy + bpx0;
+        const unsigned lx = in ? (unsigned)tid : (unsigned)(g.nx - 1 - bpx0);   // idle lanes re-read the last pixel
+        const unsigned voff = lx * (unsigned)sizeof(T);
+        const auto r11 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c11 + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r12r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12r + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r12i = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12i + ub), 0, 0x7fffffff, 0x00020000);
+        const auto r22 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c22 + ub), 0, 0x7fffffff, 0x00020000);
+        const unsigned sstep = (unsigned)g.st * (unsigned)sizeof(T);   // host guarantees k * st * sizeof(T) < 2^31
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const unsigned soff = (unsigned)t * sstep;
+            v[t][0] = buffer_load<T>(r11, voff, soff);
+            v[t][1] = buffer_load<T>(r12r, voff, soff);
+            v[t][2] = buffer_load<T>(r12i, voff, soff);
+            v[t][3] = buffer_load<T>(r22, voff, soff);
+        }
+    } else {
+        const int64_t xc = in ? x0 : g.nx - 1;
+        const int64_t off0 = row * g.sy + xc * g.sx;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const int64_t off = off0 + (int64_t)(t < k ? t : k - 1) * g.st;    // no per-date branch
+            v[t][0] = __builtin_nontemporal_load(g.c11 + off);
+            v[t][1] = __builtin_nontemporal_load(g.c12r + off);
+            v[t][2] = __builtin_nontemporal_load(g.c12i + off);
+            v[t][3] = __builtin_nontemporal_load(g.c22 + off);
+        }
+    }
+    if (tid <= 32) tab_lds[tid] = ss.e[tid];
+    if (g.write_tab && b == 0) {
+        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads together, ahead of every use
+
+    const unsigned shard = (unsigned)(b % kShards);
+    const int64_t wpx0 = bpx0 + (tid & ~63);                  // first pixel of this wave in its row
+    const int64_t wleft = g.nx - wpx0;
+    const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
+    uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
+
+    // ---- the search; a wave with few candidates lists them for pass B instead of using it ----
+    unsigned mask;
+    bool handoff, cand;
+    // (k as a run-time value even when it is known to equal KMAX: with every guard folded away the
+    // two passes become one straight block for the scheduler)
+    int ks = g.k;
+    asm volatile("" : "+s"(ks));
+    dense_chain<T, KMAX, 32>(v, ks, in, ss, tab_lds, mask, handoff, cand);
+    bool listed = cand;                                       // pixels that go to pass B
+    const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
+    if (dense) {
         if (handoff) mask = 0u;                               // pass B writes that pixel's changes
         if (change_rows_wave_ok(wob, k, wnp)) {
             store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * KMAX), k, mask, lane);
@@ -2257,13 +2526,39 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
     const unsigned lblock = blockIdx.x / kShards;
     const unsigned nlblock = gridDim.x / kShards;
     const uint32_t n = s.flag_count[shard * kCounterStride];
-    if (n > s.starts_max) return;               // a long list: the LDS form
+    // Two uses.  hand_bits == nullptr: every pixel of a SHORT list (n <= starts_max; the long ones
+    // belong to the register forms).  hand_bits != nullptr: behind a register form, the pixels of
+    // a long list that it marked (its screen could not decide one of their tests) -- a few hundred
+    // of 3e5, again a job whose time is the dependent chain of one wave.
+    const bool marked_mode = s.hand_bits != nullptr;
+    if (marked_mode ? (n <= s.starts_max) : (n > s.starts_max)) return;
+    if (marked_mode && __builtin_nontemporal_load(s.hand_count) == 0u) return;
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
     const OmniTabEntry *tabp = s.tab;
 
-    for (uint32_t base = lblock * (uint32_t)ppw; base < n; base += nlblock * (uint32_t)ppw) {
-        const uint32_t idx = base + (uint32_t)grp;
-        const bool active = (grp < ppw) && (idx < n);
+    // marked mode: the list in words of 64 entries, `todo` = the marks of the current word
+    uint32_t word = lblock;
+    unsigned long long todo = 0ull;
+    for (uint32_t base = lblock * (uint32_t)ppw;; base += nlblock * (uint32_t)ppw) {
+        uint32_t idx;
+        bool active;
+        if (marked_mode) {
+            while (todo == 0ull && (uint64_t)word * 64u < n) {
+                todo = s.hand_bits[(size_t)shard * s.hand_words + word];
+                if (todo == 0ull) word += nlblock;
+            }
+            if (todo == 0ull) break;
+            unsigned long long m = todo;            // the grp-th lowest mark is this group's pixel
+            for (int i = 0; i < grp; ++i) m &= m - 1ull;
+            active = (grp < ppw) && (m != 0ull);
+            idx = word * 64u + (uint32_t)(m != 0ull ? __builtin_ctzll(m) : 0);
+            for (int i = 0; i < ppw; ++i) todo &= todo - 1ull;
+            if (todo == 0ull) word += nlblock;
+        } else {
+            if (base >= n) break;
+            idx = base + (uint32_t)grp;
+            active = (grp < ppw) && (idx < n);
+        }
         const int64_t pix = active ? (int64_t)list[idx] : 0;
         const int64_t row = pix / s.nx;
         const int64_t col = pix - row * s.nx;
@@ -2424,6 +2719,7 @@ omnibus_c2_search_regs_kernel(const OmniSearchArgs<T> s, const DenseScreen scr_a
     const unsigned lblock = blockIdx.x / kShards;
     const unsigned nlblock = gridDim.x / kShards;
     const uint32_t n = s.flag_count[shard * kCounterStride];
+    if (n <= s.starts_max) return;             // omnibus_c2_search_starts_kernel searches this shard
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
 
     for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
@@ -2612,6 +2908,86 @@ omnibus_c2_search_regs_kernel(const OmniSearchArgs<T> s, const DenseScreen scr_a
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// pass B, chain form (k <= 32 float / 16 double; round 3): dense_chain on the listed pixel's
+// series -- one backward pass for the global tests, one forward pass for the marginal tests and
+// the restarts, ~105 vector instructions per date, against one round of the register form above
+// PER SEGMENT (a wave lives as long as its lane with the most changes).  The screen only decides
+// what is certain; a pixel with a test it cannot decide (or outside its domain) is marked in
+// hand_bits and searched exactly by omnibus_c2_search_starts_kernel behind this kernel.
+// -----------------------------------------------------------------------------------------
+template <typename T, int KMAX>
+__global__ void __launch_bounds__(64, 3)
+omnibus_c2_search_chain_kernel(const OmniSearchArgs<T> s, const StreamScreen<32> ss)
+{
+    __shared__ StreamEntry tab_lds[33];
+    const int lane = threadIdx.x;
+    if (lane <= 32) tab_lds[lane] = ss.e[lane];
+    __syncthreads();
+    int k = s.k;
+    asm volatile("" : "+s"(k));
+    const unsigned shard = blockIdx.x % kShards;
+    const unsigned lblock = blockIdx.x / kShards;
+    const unsigned nlblock = gridDim.x / kShards;
+    const uint32_t n = s.flag_count[shard * kCounterStride];
+    if (n <= s.starts_max) return;             // omnibus_c2_search_starts_kernel searches this shard
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+
+    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < n;
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+        T v[KMAX][4];
+        if (idx < s.dump_cap) {
+            const T *d = s.dump + ((int64_t)shard * s.dump_cap + idx) * (int64_t)(4 * k);
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                // (dates behind the series: a copy of the last one, masked out by the search)
+                const Pack<T, 4> q = *reinterpret_cast<const Pack<T, 4> *>(d + 4 * (t < k ? t : k - 1));
+                v[t][0] = q.v[0];
+                v[t][1] = q.v[1];
+                v[t][2] = q.v[2];
+                v[t][3] = q.v[3];
+            }
+        } else {
+            const int64_t row = pix / s.nx;
+            const int64_t col = pix - row * s.nx;
+            const int64_t off = row * s.sy + col * s.sx;
+            const T *p11 = s.c11 + off * s.m11, *p12r = s.c12r + off * s.m12;
+            const T *p12i = s.c12i + off * s.m12, *p22 = s.c22 + off * s.m22;
+            const int64_t d11 = s.st * s.m11, d12 = s.st * s.m12, d22 = s.st * s.m22;
+#pragma unroll
+            for (int t = 0; t < KMAX; ++t) {
+                v[t][0] = *p11;
+                v[t][1] = *p12r;
+                v[t][2] = *p12i;
+                v[t][3] = *p22;
+                if (t < k - 1) {
+                    p11 += d11;
+                    p12r += d12;
+                    p12i += d12;
+                    p22 += d22;
+                }
+            }
+        }
+        unsigned cmask;
+        bool handoff, cand;
+        dense_chain<T, KMAX, 32>(v, k, active, ss, tab_lds, cmask, handoff, cand);
+        {
+            const unsigned long long hm = __ballot(handoff);
+            if (lane == 0) {
+                s.hand_bits[(size_t)shard * s.hand_words + (base >> 6)] = hm;
+                if (hm != 0ull) atomicAdd(s.hand_count, (unsigned)__popcll(hm));
+            }
+        }
+        if (active && !handoff) {
+            uint8_t *res = s.change + pix * (int64_t)k;
+            for (int u = 1; u < k; ++u)                    // the row was zero-filled by pass A
+                if ((cmask >> u) & 1u) res[u] = 1;
+        }
+    }
+}
+
 // =========================================================================================
 // host side
 // =========================================================================================
@@ -2756,6 +3132,34 @@ static void launch_fused(const OmniGlobalArgs<T> &g, const OmniTab &tab, const D
         else
             launch_fused_k<float, 32>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, scr,
                                       nblocks, stream);
+    }
+}
+
+template <typename T, int KMAX>
+static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const StreamScreen<32> &ss,
+                           int64_t nblocks, hipStream_t stream)
+{
+    const dim3 grid((unsigned)nblocks), block(kRetainThreads);
+    if (g.k == KMAX && g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0)
+        hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, true>), grid, block, 0, stream, g, tab, ss);
+    else
+        hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, false>), grid, block, 0, stream, g, tab, ss);
+}
+
+template <typename T>
+static void launch_chain(const OmniGlobalArgs<T> &g, const OmniTab &tab, const StreamScreen<32> &ss,
+                         int64_t nblocks, hipStream_t stream)
+{
+    const int k = g.k;
+    if (k <= 8)
+        launch_chain_k<T, 8>(g, tab, ss, nblocks, stream);
+    else if (k <= 16)
+        launch_chain_k<T, 16>(g, tab, ss, nblocks, stream);
+    else if (sizeof(T) == 4) {
+        if (k <= 24)
+            launch_chain_k<float, 24>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream);
+        else
+            launch_chain_k<float, 32>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream);
     }
 }
 
@@ -3042,7 +3446,39 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // pixels its screen could not decide, and in that regime nearly every date of a pixel is a
         // change: two dozen short segments, i.e. two dozen rounds of the register form against ~70
         // date steps of the LDS form (measured at alpha = 0.01: 0.166 against 0.125 ms).
-        const bool regs_form = regs_ok && (mode_env == 2 || (mode_env < 0 && !low_threshold));
+        // Behind the fused search: short lists (what its screen could not decide: a few thousand
+        // pixels, nearly every date of them a change) one lane per segment start; long ones (the
+        // candidates of sparse waves, few changes each) in the register form.  The choice is made
+        // per shard, on the device.
+        static const int starts_env = [] {
+            const char *e = getenv("ND_AMD_SEARCH_STARTS");      // list length per shard up to which ...; 0 = off
+            return e ? atoi(e) : 512;
+        }();
+        const bool starts_form = low_threshold && k >= 2 && k <= 65 && starts_env > 0 && mode_env < 0;
+        if (starts_form) {
+            s.starts_max = (uint32_t)starts_env;
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+            hipLaunchKernelGGL((omnibus_c2_search_starts_kernel<T>), dim3((unsigned)sblocks), dim3(64), 0, sq, s);
+        }
+        // ND_AMD_SEARCH_MODE: 0 LDS image, 1 from memory, 2 register form (rounds), 3 chain form
+        const bool chain_form = regs_ok && (mode_env == 3 || mode_env < 0);
+        const bool regs_form = regs_ok && mode_env == 2;
+        if (chain_form) {
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+            s.hand_bits = hand;
+            const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
+            const dim3 gr((unsigned)sblocks), bl(64);
+            if (k <= 8)
+                hipLaunchKernelGGL((omnibus_c2_search_chain_kernel<T, 8>), gr, bl, 0, sq, s, ss0);
+            else if (k <= 16)
+                hipLaunchKernelGGL((omnibus_c2_search_chain_kernel<T, 16>), gr, bl, 0, sq, s, ss0);
+            else if (sizeof(T) == 4 && k <= 24)
+                hipLaunchKernelGGL((omnibus_c2_search_chain_kernel<float, 24>), gr, bl, 0, sq,
+                                   reinterpret_cast<const OmniSearchArgs<float> &>(s), ss0);
+            else if (sizeof(T) == 4)
+                hipLaunchKernelGGL((omnibus_c2_search_chain_kernel<float, 32>), gr, bl, 0, sq,
+                                   reinterpret_cast<const OmniSearchArgs<float> &>(s), ss0);
+        }
         if (regs_form) {
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
             s.hand_bits = hand;
@@ -3058,26 +3494,20 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<float, 32>), gr, bl, 0, sq,
                                    reinterpret_cast<const OmniSearchArgs<float> &>(s), scr);
         }
-        // Behind the fused search: short lists (what its screen could not decide) one lane per
-        // segment start, long ones (a raster the sample found sparse after all: many candidates
-        // with few changes each) in the LDS form.  The choice is made per shard, on the device.
-        static const int starts_env = [] {
-            const char *e = getenv("ND_AMD_SEARCH_STARTS");      // list length per shard up to which ...; 0 = off
-            return e ? atoi(e) : 512;
-        }();
-        const bool starts_form = low_threshold && !regs_form && k >= 2 && k <= 65 && starts_env > 0 &&
-                                 mode_env < 0;
-        if (starts_form) {
-            s.starts_max = (uint32_t)starts_env;
-            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
-            hipLaunchKernelGGL((omnibus_c2_search_starts_kernel<T>), dim3((unsigned)sblocks), dim3(64), 0, sq, s);
+        // the exact form: every listed pixel, or (behind a register form) the marked ones
+        KernelTimer timer((chain_form || regs_form || starts_form) ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+        if (chain_form && k <= 65) {
+            // the marked pixels one lane per segment start: their number is small, the time of
+            // this step is the dependent chain of one wave
+            const int64_t xb = (per_shard > 16 ? 16 : per_shard) * kShards;
+            hipLaunchKernelGGL((omnibus_c2_search_starts_kernel<T>), dim3((unsigned)xb), dim3(64), 0, sq, s);
+            return ND_AMD_OK;
         }
-        // the exact form: every listed pixel, or (behind the register form) the marked ones
-        KernelTimer timer((regs_form || starts_form) ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
         // (behind the register form there is usually nothing left: the from-memory form, whose
         // blocks reserve no LDS, and a quarter of the blocks)
-        const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !regs_form) ? 0 : 1);
-        const int64_t xblocks = regs_form ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
+        const bool behind = chain_form || regs_form;
+        const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !behind) ? 0 : 1);
+        const int64_t xblocks = behind ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
         if (mode == 0 && use_lds)
             hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0>), dim3((unsigned)xblocks), dim3(64),
                                lds_bytes, sq, s);
@@ -3222,10 +3652,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // three dates are rare (a row needs one with probability ~ alpha per pixel): measured
         // 2.3 vs 3.1 ms at alpha = 0.01, break-even at 0.05, 6.3 vs 5.1 ms at 0.2 (24 x 4096^2).
         static const int fused_form = [] {
-            const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 1 = registers, else by alpha
+            const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 1 = triangle in registers, 2 = chain; else by alpha
             return e ? atoi(e) : -1;
         }();
-        const bool regs_form = fused_form == 1 || (fused_form != 0 && alpha > 0.05);
+        const bool regs_form = fused_form == 1;
+        const bool chain_form = fused_form == 2 || (fused_form < 0 && alpha > 0.02);
+        if (chain_form) {
+            const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
+            launch_chain<T>(g, tab, ss0, nblocks, stream);
+        } else
         if (regs_form) {
             launch_fused<T>(g, tab, scr, nblocks, stream);
         } else {

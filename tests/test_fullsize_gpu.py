@@ -192,7 +192,8 @@ def test_dense_thresholds_whole_raster_equals_oracle(oracle, stack, alpha):
     assert (want.sum(axis=2) > 0).mean() > 0.4
 
 
-@pytest.mark.parametrize('env', [{'ND_AMD_FUSED_FORM': '0'}, {'ND_AMD_FUSED_FORM': '1'},
+@pytest.mark.parametrize('env', [{'ND_AMD_FUSED_FORM': '0'}, {'ND_AMD_FUSED_FORM': '1'}, {'ND_AMD_FUSED_FORM': '2'},
+                                 {'ND_AMD_SEARCH_STARTS': '0'}, {'ND_AMD_PM_STREAM_LDS': '0'},
                                  {'ND_AMD_FUSED_ALPHA': '0'}, {'ND_AMD_PM_FORM': '1'},
                                  {'ND_AMD_GATE': '0'}, {'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '1'},
                                  {'ND_AMD_PM_STREAM_LDS': '1'}, {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_GATE': '0'},
