@@ -2582,46 +2582,60 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
         A.reset();
         int fire_at = -1;
         int nxt = -1;                           // stop
-        // (idle lanes load nothing: a stand-in read of pixel 0 from 4 x k planes far apart would put
-        // its address translations on every step's critical path)
-        Pack<T, 4> cur;
-        cur.v[0] = cur.v[1] = cur.v[2] = cur.v[3] = (T)0;
-        if (active) cur = fetch(l);
-        for (int i = 0; i < k; ++i) {           // the lane's date is l + i
-            const int t = l + i;
-            const bool on = active && t < k;
-            if (!__any(on)) break;
-            Pack<T, 4> ahead = cur;
-            if (on && t + 1 < k) ahead = fetch(t + 1);        // in flight while this date is evaluated
-            if (on) A.step(cur.v[0], cur.v[1], cur.v[2], cur.v[3]);
-            cur = ahead;
-            const int jj = i + 1;
-            const bool last = (t == k - 1);
-            const bool need = on && (jj >= 2) && (fire_at < 0 || last);
-            bool fires = false, inband = false;
-            if (need) {
-                const OmniTabEntry &e = tabp[jj];
-                const double za = z_approx<T>(A, jj, s.nlooks, e.m2rho, e.pklogk);
-                fires = (za > e.zhi_a) && (za < INFINITY);
-                inband = (za >= e.zlo_a) && !fires;
+        // Four dates per trip, the next four in flight meanwhile: the kernel's time is the dependent
+        // chain of one wave, and a load per date (even one date ahead) was most of it.  (Idle lanes
+        // load nothing: a stand-in read of pixel 0 from 4 x k planes far apart would put its address
+        // translations on every trip's critical path.)
+        auto fetch4 = [&](const int i0, Pack<T, 4> (&q)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = l + i0 + u;
+                q[u].v[0] = q[u].v[1] = q[u].v[2] = q[u].v[3] = (T)0;
+                if (active && t < k) q[u] = fetch(t);
             }
-            if (__any(inband)) {
-                if (inband) {
-                    const OmniTabEntry e = tabp[jj];
-                    const T zp = z_stat<T>(A, jj, s.nlooks, e);
-                    const double zd = (double)zp;
-                    int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
-                    if (verdict == 2) {
-                        double zv[1] = {zd}, P1[1], P2[1];
-                        chisq_pair<1>(zv, 4 * (jj - 1), e.lgam, P1, P2);
-                        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
-                        verdict = ((double)P > s.alpha) ? 1 : 0;
-                    }
-                    fires = (verdict == 1);
+        };
+        Pack<T, 4> qn[4];
+        fetch4(0, qn);
+        for (int i0 = 0; i0 < k; i0 += 4) {     // the lane's dates are l + i0 .. l + i0 + 3
+            if (!__any(active && l + i0 < k)) break;
+            Pack<T, 4> q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = qn[u];
+            fetch4(i0 + 4, qn);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                const int t = l + i;
+                const bool on = active && t < k;
+                if (on) A.step(q[u].v[0], q[u].v[1], q[u].v[2], q[u].v[3]);
+                const int jj = i + 1;
+                const bool last = (t == k - 1);
+                const bool need = on && (jj >= 2) && (fire_at < 0 || last);
+                bool fires = false, inband = false;
+                if (need) {
+                    const OmniTabEntry &e = tabp[jj];
+                    const double za = z_approx<T>(A, jj, s.nlooks, e.m2rho, e.pklogk);
+                    fires = (za > e.zhi_a) && (za < INFINITY);
+                    inband = (za >= e.zlo_a) && !fires;
                 }
+                if (__any(inband)) {
+                    if (inband) {
+                        const OmniTabEntry e = tabp[jj];
+                        const T zp = z_stat<T>(A, jj, s.nlooks, e);
+                        const double zd = (double)zp;
+                        int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                        if (verdict == 2) {
+                            double zv[1] = {zd}, P1[1], P2[1];
+                            chisq_pair<1>(zv, 4 * (jj - 1), e.lgam, P1, P2);
+                            const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                            verdict = ((double)P > s.alpha) ? 1 : 0;
+                        }
+                        fires = (verdict == 1);
+                    }
+                }
+                if (on && fires && fire_at < 0) fire_at = t;
+                if (on && last && fires) nxt = fire_at;      // the global test of ts[l:] fired (jj >= 2 here)
             }
-            if (on && fires && fire_at < 0) fire_at = t;
-            if (on && last && fires) nxt = fire_at;          // the global test of ts[l:] fired (jj >= 2 here)
         }
         // follow the chain from l = 0; the group's first lane writes the changes
         int at = 0;
@@ -3499,8 +3513,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         if (chain_form && k <= 65) {
             // the marked pixels one lane per segment start: their number is small, the time of
             // this step is the dependent chain of one wave
-            const int64_t xb = (per_shard > 16 ? 16 : per_shard) * kShards;
-            hipLaunchKernelGGL((omnibus_c2_search_starts_kernel<T>), dim3((unsigned)xb), dim3(64), 0, sq, s);
+            hipLaunchKernelGGL((omnibus_c2_search_starts_kernel<T>), dim3((unsigned)sblocks), dim3(64), 0, sq, s);
             return ND_AMD_OK;
         }
         // (behind the register form there is usually nothing left: the from-memory form, whose

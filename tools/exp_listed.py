@@ -19,4 +19,5 @@ for alpha in [float(x) for x in os.environ.get('ALPHAS', '1e-4,0.01,0.05').split
     torch.cuda.synchronize()
     per = ws[:128 * 32 * 4].view(torch.int32).view(128, 32)[:, 0]
     cnt = per.sum().item()
-    print(json.dumps({'alpha': alpha, 'listed': int(cnt), 'fraction': cnt / (ny * nx), 'shard_max': int(per.max().item()), 'shard_min': int(per.min().item())}))
+    print(json.dumps({'alpha': alpha, 'listed': int(cnt), 'fraction': cnt / (ny * nx), 'shard_max': int(per.max().item()), 'shard_min': int(per.min().item()),
+                      'marked_for_exact': int(ws[:128 * 32 * 4].view(torch.int32)[3].item())}))
