@@ -790,11 +790,16 @@ __device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int 
     }
 }
 
-template <typename T, int KMAX, bool STATS>
+// CHAIN: the search fused in (dense_chain on the registers the series was picked into), for
+// thresholds between the streaming search's and the sparse regime; `ss` is only read then.
+template <typename T, int KMAX, bool STATS, bool CHAIN = false>
 __global__ void __launch_bounds__(64)
-omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const OmniPmDmaArgs<T> pm)
+omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const OmniPmDmaArgs<T> pm,
+                         const StreamScreen<32> ss)
 {
     if (omni_gate_skip(g)) return;
+    __shared__ StreamEntry tab_lds[CHAIN ? 33 : 1];
+    __shared__ __align__(16) uint32_t out_img[CHAIN ? 16 * KMAX : 4];
     extern __shared__ __align__(16) unsigned char nd_smem_dma[];
     T *img = reinterpret_cast<T *>(nd_smem_dma);
     const int lane = threadIdx.x;
@@ -830,6 +835,12 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
 
     // ---- this lane's series out of the images (idle lanes copy the last pixel) ----
     T v[KMAX][4];
+    if (CHAIN) {
+        if (lane <= 32) tab_lds[lane] = ss.e[lane];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) v[t][0] = v[t][1] = v[t][2] = v[t][3] = (T)1;   // dates behind k: masked
+        __syncthreads();
+    }
     const int own = in ? lane : np - 1;
     pm_pick<T, KMAX, 0, false>(v, img + pm.img_off[0] + own * k * pm.ids[0], k, pm.ids[0]);
     pm_pick<T, KMAX, 3, false>(v, img + pm.img_off[3] + own * k * pm.ids[3], k, pm.ids[3]);
@@ -840,6 +851,29 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         pm_pick<T, KMAX, 2, false>(v, img + pm.img_off[2] + own * k * pm.ids[2], k, pm.ids[2]);
     }
 
+    bool flag;
+    bool dense = false;
+    if (CHAIN) {
+        // ---- the search; a wave with few candidates lists them for pass B instead of using it ----
+        unsigned mask;
+        bool handoff, cand;
+        int ks = g.k;
+        asm volatile("" : "+s"(ks));
+        dense_chain<T, KMAX, 32>(v, ks, in, ss, tab_lds, mask, handoff, cand);
+        dense = __popcll(__ballot(cand)) >= g.dense_min;
+        flag = cand;
+        if (dense) {
+            if (handoff) mask = 0u;                           // pass B writes that pixel's changes
+            uint8_t *wob = g.change + px0 * (int64_t)k;
+            if (change_rows_wave_ok(wob, k, np)) {
+                store_change_rows_wave(wob, out_img, k, mask, lane);
+            } else if (in) {
+                uint8_t *res = wob + (int64_t)lane * k;
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & 1u);
+            }
+            flag = handoff;
+        }
+    } else {
     // ---- fold in time order ----
     Accum<T> A;
     A.reset();
@@ -847,7 +881,6 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     for (int t = 0; t < KMAX; ++t)
         if (t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
 
-    bool flag;
     if (STATS) {
         const T z = z_stat<T>(A, k, g.nlooks, g.e);
         double zd[1] = {(double)z}, P1[1], P2[1];
@@ -860,6 +893,7 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         }
     } else {
         flag = in && (z_approx<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
+    }
     }
 
     // ---- list + dump ----
@@ -889,7 +923,7 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         }
     }
     // ---- zero-fill this wave's slice of the change map (np.zeros at nd/_change.pyx:275) ----
-    zero_fill_span(g.change + px0 * (int64_t)k, np * k, lane);
+    if (!dense) zero_fill_span(g.change + px0 * (int64_t)k, np * k, lane);
 }
 
 // =========================================================================================
@@ -3598,6 +3632,19 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                     return e ? atoi(e) : -1;
                 }();
                 const bool pm_direct4 = pm_sector_env >= 0 ? pm_sector_env != 0 : alpha <= 1e-3;
+                static const int fused_form_pm = [] {
+                    const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 2 = chain; else by alpha
+                    return e ? atoi(e) : -1;
+                }();
+                if ((fused_form_pm == 2 || (fused_form_pm != 0 && alpha > 0.02)) && k <= 24) {
+                    // dense_chain behind the LDS-DMA staging: the form for the thresholds in between
+                    if (k <= 8)
+                        hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 8, false, true>), gridw, blockw, lds_dma, stream, g, tab, dm, ss0);
+                    else if (k <= 16)
+                        hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 16, false, true>), gridw, blockw, lds_dma, stream, g, tab, dm, ss0);
+                    else
+                        hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 24, false, true>), gridw, blockw, lds_dma, stream, g, tab, dm, ss0);
+                } else
                 if (pm_lds)
                     hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, 2, 2>), gridw, blockw, lds_dma, stream, g, tab, dm, ss0);
                 else if (pm_direct4 && (k % (2 * VE)) == 0)
@@ -3611,12 +3658,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             }
             if (!fused_pm || gated) {
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+            StreamScreen<32> ss_unused;
+            memset(&ss_unused, 0, sizeof(ss_unused));
 #define ND_LAUNCH_DMA(KM)                                                                              \
     do {                                                                                              \
         if (stats)                                                                                    \
-            hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, true>), gridw, blockw, lds_dma, stream, g, tab, dm);  \
+            hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, true>), gridw, blockw, lds_dma, stream, g, tab, dm, ss_unused);  \
         else                                                                                          \
-            hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, false>), gridw, blockw, lds_dma, stream, g, tab, dm); \
+            hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, false>), gridw, blockw, lds_dma, stream, g, tab, dm, ss_unused); \
     } while (0)
             if (k <= 8)
                 ND_LAUNCH_DMA(8);
