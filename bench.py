@@ -395,7 +395,7 @@ def _free():
     torch.cuda.empty_cache()
 
 
-EXTRA_KEYS = ('omnibus_a0.01', 'omnibus_a0.0001', 'pm_a0.99', 'pm_a0.01', 'c3_a0.99', 'c3_a0.01',
+EXTRA_KEYS = ('omnibus_a0.01', 'omnibus_a0.0001', 'omnibus_a0.2', 'pm_a0.99', 'pm_a0.01', 'c3_a0.99', 'c3_a0.01',
               'boxcar3', 'boxcar5', 'gauss1', 'nlm_pm0', 'nlm_pm1', 'pipeline')
 
 
@@ -425,7 +425,7 @@ def extras(main, barrier, dev, only=None):
 
     a = main.a
     # -- OmnibusTest at the thresholds users actually pass: the reference default and the tutorial's
-    for alpha in (0.01, 1e-4):
+    for alpha in (0.01, 1e-4, 0.2):
         key = 'omnibus_a%g' % alpha
         if not want(key):
             continue
@@ -437,9 +437,11 @@ def extras(main, barrier, dev, only=None):
         dom = max(km, key=km.get)
         entry(key, 'OmnibusTest C2 %dt x %d x %d f32, alpha=%g (dense regime: %.3f of pixels change)'
               % (main.k, main.rows, main.nx, alpha, res['flagged_fraction']), dt, 10, main.npix, km,
-              roof(key, 'stream_kernel', dom, km, main.alg_bytes,
-                   note='search fused into the streaming pass over the planes (VALU-issue bound); '
-                        'bytes = planes read once + change map written once'),
+              roof(key, 'chain_kernel' if alpha > 0.02 else 'stream_kernel', dom, km, main.alg_bytes,
+                   note=('search fused into pass A, two linear passes over the retained series (dense_chain)'
+                         if alpha > 0.02 else
+                         'search fused into the streaming pass over the planes (vector issue and HBM both '
+                         'near their floors)') + '; bytes = planes read once + change map written once'),
               res['bad'] == 0, sample=res)
         del ch
 
@@ -466,8 +468,8 @@ def extras(main, barrier, dev, only=None):
                   'alpha=%g' % (main.k, main.rows, main.nx, alpha), dt, 10, main.npix, km,
                   roof(key, 'pm_dma' if alpha > 0.5 else 'stream_kernel', dom, km, main.alg_bytes,
                        note='LDS-DMA staging of pixel-major spans (global_load_lds_dwordx4)' if alpha > 0.5 else
-                       'streaming search, every lane reading its own pixel-major series from memory '
-                       'in 16-byte pieces (no LDS images)'),
+                       'streaming search on the wave\'s LDS-DMA images of the pixel-major series '
+                       '(24.6 KB per wave, six waves per CU)'),
                   res['bad'] == 0 and same, sample=res, equal_to_planar_map=same)
             del ch, ref
         del c12, pmv

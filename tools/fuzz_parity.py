@@ -34,10 +34,14 @@ def case_omnibus(rng):
     ny, nx = int(rng.integers(1, 40)), int(rng.integers(1, 300))
     looks = int(rng.choice([1, 2, 4, 9, 20]))
     dtype = rng.choice([np.float32, np.float64])
-    alpha = float(rng.choice([0.01, 0.5, 0.9, 0.99, 0.999, 0.9999, 1e-4]))
+    alpha = float(rng.choice([0.01, 0.05, 0.2, 0.5, 0.7, 0.9, 0.99, 0.999, 0.9999, 1e-4]))
     n = int(rng.choice([looks, 1, 3]))
     w = wishart(rng, k, ny, nx, looks, dtype)
     planes = [w['C11'], w['C12re'], w['C12im'], w['C22']]
+    # magnitudes: the fast forms take determinants inside 2^+-36 (float32) and hand the rest to the exact pass
+    scale = float(rng.choice([1.0, 1.0, 1.0, 1e-3, 1e-6, 1e4, 1e6]))
+    if scale != 1.0:
+        planes = [(p * scale).astype(dtype) for p in planes]
     # step changes, zeros, NaNs, infinities, negative determinants
     if rng.random() < 0.7:
         m = rng.random((ny, nx)) < 0.3
