@@ -790,6 +790,12 @@ __device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int 
     }
 }
 
+// (defined with the dense-wave searches below)
+template <typename T, int KMAX, int NJ>
+__device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, const bool active,
+                                            const StreamScreen<NJ> &ss, const StreamEntry *tab_lds,
+                                            unsigned &mask_out, bool &handoff_out, bool &cand_out);
+
 // CHAIN: the search fused in (dense_chain on the registers the series was picked into), for
 // thresholds between the streaming search's and the sparse regime; `ss` is only read then.
 template <typename T, int KMAX, bool STATS, bool CHAIN = false>
