@@ -791,10 +791,10 @@ __device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int 
 }
 
 // (defined with the dense-wave searches below)
-template <typename T, int KMAX, int NJ>
+template <typename T, int KMAX, int NJ, typename MT>
 __device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, const bool active,
                                             const StreamScreen<NJ> &ss, const StreamEntry *tab_lds,
-                                            unsigned &mask_out, bool &handoff_out, bool &cand_out);
+                                            MT &mask_out, bool &handoff_out, bool &cand_out);
 
 // CHAIN: the search fused in (dense_chain on the registers the series was picked into), for
 // thresholds between the streaming search's and the sparse regime; `ss` is only read then.
@@ -1153,15 +1153,17 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
 // ~105 vector instructions per date in all, whatever the threshold: no rows, no deep searches,
 // no divergence.
 // -----------------------------------------------------------------------------------------
-template <typename T, int KMAX, int NJ>
+// MT: unsigned for KMAX <= 32, unsigned long long up to 64 dates
+template <typename T, int KMAX, int NJ, typename MT>
 __device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, const bool active,
                                             const StreamScreen<NJ> &ss, const StreamEntry *tab_lds,
-                                            unsigned &mask_out, bool &handoff_out, bool &cand_out)
+                                            MT &mask_out, bool &handoff_out, bool &cand_out)
 {
-    static_assert(KMAX <= 32 && KMAX <= NJ, "32-bit masks");
-    constexpr int kmin = KMAX == 8 ? 2 : KMAX - 7;      // the instantiation serves kmin <= k <= KMAX
+    static_assert(KMAX <= (int)(8 * sizeof(MT)) && KMAX <= NJ, "mask width");
+    // the instantiation serves kmin <= k <= KMAX (8, 16, 24, 32 dates; 48 takes 33 .. 48)
+    constexpr int kmin = KMAX == 8 ? 2 : (KMAX == 48 ? 33 : KMAX - 7);
     const T dlo = (T)ss.dlo, dhi = (T)ss.dhi;
-    unsigned gF = 0u, gC = 0u;
+    MT gF = 0, gC = 0;
     bool bad = false, dead = false;
     {
         double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0, PP = 1.0;
@@ -1211,18 +1213,18 @@ __device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, 
         bad = bad | (emax - emin > 900);
     }
     // KMAX pushes: the bit of date t sits at position t
-    unsigned gI = ~(gF | gC);
+    MT gI = (MT) ~(gF | gC);
     mask_keep_low(gF, k - 1);
     mask_keep_low(gI, k - 1);
     if (dead) {                                 // a NaN or zero determinant: no change anywhere, no exact pass
         bad = false;
-        gF = 0u;
-        gI = 0u;
+        gF = 0;
+        gI = 0;
     }
-    cand_out = active && (bad || ((gF | gI) & 1u));
-    bool handoff = active && (bad || (gI & 1u));
-    bool done = !active || bad || !(gF & 1u) || (gI & 1u);
-    unsigned mask = 0u;
+    cand_out = active && (bad || ((gF | gI) & (MT)1));
+    bool handoff = active && (bad || (gI & (MT)1));
+    bool done = !active || bad || !(gF & (MT)1) || (gI & (MT)1);
+    MT mask = 0;
     // the running state of the segment that starts at date 0 (0 + a_0 = a_0)
     T s11 = v[0][0], s12r = v[0][1], s12i = v[0][2], s22 = v[0][3];
     double PP = (double)((v[0][0] * v[0][3]) - ((v[0][1] * v[0][1]) + (v[0][2] * v[0][2])));
@@ -1231,11 +1233,13 @@ __device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, 
     for (int t = 1; t < KMAX; ++t) {
         const bool live = (t < kmin) || (t < k);
         const bool last = (t == k - 1);
-        T a = v[t][0];
-        const T b = v[t][1], c = v[t][2], d = v[t][3];
+        T a = v[t][0], b = v[t][1];
+        const T c = v[t][2], d = v[t][3];
         // (opaque to the optimiser: it would otherwise keep the 24 determinants of pass 1, and their
-        // conversions to double, alive in 72 registers instead of recomputing them here)
+        // conversions to double, alive in 72 registers instead of recomputing them here; for the long
+        // series also b^2 + c^2, one register per date)
         asm volatile("" : "+v"(a));
+        if (KMAX * sizeof(T) > 96) asm volatile("" : "+v"(b));
         const T det = (a * d) - ((b * b) + (c * c));
         s11 = s11 + a;
         s12r = s12r + b;
@@ -1260,9 +1264,9 @@ __device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, 
         const bool und = act & !(fires | cant);
         const bool f = act & fires;
         handoff = handoff | und;
-        mask |= f ? (1u << t) : 0u;                          // :252
+        mask |= f ? ((MT)1 << t) : (MT)0;                    // :252
         // the segment that starts at t (:255): its global test was decided in pass 1
-        const bool gi = (gI >> t) & 1u, gf = (gF >> t) & 1u;
+        const bool gi = (gI >> t) & (MT)1, gf = (gF >> t) & (MT)1;
         handoff = handoff | (f & !last & gi);
         done = done | und | (f & (last | gi | !gf));         // :256, :241-242
         s11 = f ? a : s11;
@@ -1519,12 +1523,19 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
 // form for thresholds at which marginal tests beyond three dates are common (everything between
 // the reference's default 0.01 and the sparse regime).  Same loads as omnibus_c2_retain_kernel.
 // -----------------------------------------------------------------------------------------
+// (series of up to 96 registers: three waves per SIMD; beyond -- 32 float32 / 16 float64 dates and
+// more -- two: under the cap of three the search spilled 150 - 230 bytes per lane)
+constexpr int chain_waves(const int kmax, const size_t elem) { return kmax * (int)elem <= 96 ? 3 : 2; }
+constexpr int chain_nj(const int kmax) { return kmax > 32 ? 64 : 32; }
+
 template <typename T, int KMAX, bool EXACT>
-__global__ void __launch_bounds__(kRetainThreads, 3)
-omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const StreamScreen<32> ss)
+__global__ void __launch_bounds__(kRetainThreads, chain_waves(KMAX, sizeof(T)))
+omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const StreamScreen<chain_nj(KMAX)> ss)
 {
+    constexpr int NJ = chain_nj(KMAX);
+    typedef typename std::conditional<(KMAX > 32), unsigned long long, unsigned>::type MT;
     if (omni_gate_skip(g)) return;
-    __shared__ StreamEntry tab_lds[33];       // the marginal tests' constants: a lane reads those of its own j
+    __shared__ StreamEntry tab_lds[NJ + 1];   // the marginal tests' constants: a lane reads those of its own j
     __shared__ __align__(16) uint32_t out_img[(kRetainThreads / 64) * 16 * KMAX];   // store_change_rows_wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1567,7 +1578,7 @@ omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Stre
             v[t][3] = __builtin_nontemporal_load(g.c22 + off);
         }
     }
-    if (tid <= 32) tab_lds[tid] = ss.e[tid];
+    if (tid <= NJ) tab_lds[tid] = ss.e[tid];
     if (g.write_tab && b == 0) {
         for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
     }
@@ -1581,17 +1592,17 @@ omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Stre
     uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
 
     // ---- the search; a wave with few candidates lists them for pass B instead of using it ----
-    unsigned mask;
+    MT mask;
     bool handoff, cand;
     // (k as a run-time value even when it is known to equal KMAX: with every guard folded away the
     // two passes become one straight block for the scheduler)
     int ks = g.k;
     asm volatile("" : "+s"(ks));
-    dense_chain<T, KMAX, 32>(v, ks, in, ss, tab_lds, mask, handoff, cand);
+    dense_chain<T, KMAX, NJ>(v, ks, in, ss, tab_lds, mask, handoff, cand);
     bool listed = cand;                                       // pixels that go to pass B
     const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
     if (dense) {
-        if (handoff) mask = 0u;                               // pass B writes that pixel's changes
+        if (handoff) mask = 0;                                // pass B writes that pixel's changes
         if (change_rows_wave_ok(wob, k, wnp)) {
             store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * KMAX), k, mask, lane);
         } else if (in) {
@@ -1600,9 +1611,9 @@ omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Stre
                 uint32_t *w = reinterpret_cast<uint32_t *>(res);
 #pragma unroll
                 for (int q = 0; q < KMAX / 4; ++q)
-                    if (q < (k >> 2)) w[q] = (((mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    if (q < (k >> 2)) w[q] = (mask_nibble(mask, q) * 0x00204081u) & 0x01010101u;
             } else {
-                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & 1u);
+                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & (MT)1);
             }
         }
         listed = handoff;
@@ -1883,7 +1894,9 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     // first, so the bit of date t ends at position t.  Tests that do not exist (the global test of the
     // last date alone, marginal tests reaching behind the series) are cleared behind the loop.
     // q: date t;  d1, d2: dates t + 1, t + 2 (the unit matrix behind the series)
-    auto process = [&](const DateVal<T> &q, const DateVal<T> &d1, const DateVal<T> &d2, const int t) {
+    // c: the constants of the global test over k - t dates (ss.e[k - t])
+    auto process = [&](const DateVal<T> &q, const DateVal<T> &d1, const DateVal<T> &d2, const int t,
+                       const StreamEntry &c) {
         const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
         // (the range of the determinant is checked together with those of the 2- and 3-date sums)
         bad = bad | !(q.a > (T)0);
@@ -1896,7 +1909,6 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         S22 += (double)q.d;
         {                                                   // global test of ts[t:], j = k - t
             const int jj = k - t;
-            const StreamEntry c = ss.e[jj];                 // wave-uniform: one scalar load
             const double pp = S11 * S22;
             const double dets = pp - ((S12r * S12r) + (S12i * S12i));
             const float df = (float)dets;
@@ -1989,8 +2001,13 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         DateVal<T> w1, w2;                                     // dates t + 1, t + 2
         w1.a = w1.d = w2.a = w2.d = (T)1;
         w1.b = w1.c = w2.b = w2.c = (T)0;
+        // The entry of the NEXT date is requested before this date is worked on: at one or two
+        // waves per SIMD (LDS images) nothing else hides the scalar load's latency, 24 times per wave.
+        StreamEntry enext = ss.e[1];
         auto process_w = [&](const DateVal<T> &q, const int t) {
-            process(q, w1, w2, t);
+            const StreamEntry ecur = enext;
+            enext = ss.e[t > 0 ? k - t + 1 : 1];
+            process(q, w1, w2, t, ecur);
             w2 = w1;
             w1 = q;
         };
@@ -2054,7 +2071,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
 #pragma unroll
             for (int u = 0; u < NS; ++u) {
                 const int t = tb - u;
-                process(ring[u], ring[(u + NS - 1) % NS], ring[(u + NS - 2) % NS], t);
+                process(ring[u], ring[(u + NS - 1) % NS], ring[(u + NS - 2) % NS], t, ss.e[k - t]);   // wave-uniform: one scalar load
                 ring[(u + NS - 2) % NS] = rd.load(t >= PF ? t - PF : 0);     // PF dates in flight
             }
         }
@@ -2063,7 +2080,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         for (int u = 0; u < NS; ++u) {
             const int t = tb - u;
             if (t >= 0) {
-                process(ring[u], ring[(u + NS - 1) % NS], ring[(u + NS - 2) % NS], t);
+                process(ring[u], ring[(u + NS - 1) % NS], ring[(u + NS - 2) % NS], t, ss.e[k - t]);   // wave-uniform: one scalar load
                 if (u < 2) ring[(u + NS - 2) % NS] = rd.load(t >= PF ? t - PF : 0);
             }
         }
@@ -3190,7 +3207,7 @@ static void launch_fused(const OmniGlobalArgs<T> &g, const OmniTab &tab, const D
 }
 
 template <typename T, int KMAX>
-static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const StreamScreen<32> &ss,
+static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const StreamScreen<chain_nj(KMAX)> &ss,
                            int64_t nblocks, hipStream_t stream)
 {
     const dim3 grid((unsigned)nblocks), block(kRetainThreads);
@@ -3200,11 +3217,23 @@ static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const
         hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, false>), grid, block, 0, stream, g, tab, ss);
 }
 
+// k <= 48 (float) / 24 (double): the series lengths pass A retains in registers
 template <typename T>
-static void launch_chain(const OmniGlobalArgs<T> &g, const OmniTab &tab, const StreamScreen<32> &ss,
-                         int64_t nblocks, hipStream_t stream)
+static void launch_chain(const OmniGlobalArgs<T> &g, const OmniTab &tab, const std::vector<OmniTabEntry> &htab,
+                         const DenseScreen &scr, uint32_t n_looks, int64_t nblocks, hipStream_t stream)
 {
     const int k = g.k;
+    if (sizeof(T) == 8 && k > 16) {
+        const StreamScreen<32> ss = make_stream_screen<T, 32>(htab, scr, k, n_looks);
+        launch_chain_k<double, 24>(reinterpret_cast<const OmniGlobalArgs<double> &>(g), tab, ss, nblocks, stream);
+        return;
+    }
+    if (k > 32) {
+        const StreamScreen<64> ss = make_stream_screen<T, 64>(htab, scr, k, n_looks);
+        launch_chain_k<float, 48>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream);
+        return;
+    }
+    const StreamScreen<32> ss = make_stream_screen<T, 32>(htab, scr, k, n_looks);
     if (k <= 8)
         launch_chain_k<T, 8>(g, tab, ss, nblocks, stream);
     else if (k <= 16)
@@ -3726,8 +3755,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const bool regs_form = fused_form == 1;
         const bool chain_form = fused_form == 2 || (fused_form < 0 && alpha > 0.02);
         if (chain_form) {
-            const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
-            launch_chain<T>(g, tab, ss0, nblocks, stream);
+            launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream);
         } else
         if (regs_form) {
             launch_fused<T>(g, tab, scr, nblocks, stream);
@@ -3785,6 +3813,18 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             OmniPmDmaArgs<T> nopm;
             memset(&nopm, 0, sizeof(nopm));
             const bool buf = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
+            static const int fused_form_long = [] {
+                const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 2 = chain; else by alpha
+                return e ? atoi(e) : -1;
+            }();
+            // float64 series of 17 .. 24 dates still fit the registers (as 32 float32 dates do): the
+            // chain form.  (33 .. 48 float32 dates: the instantiation exists -- ND_AMD_FUSED_FORM=2 --
+            // but spills 2 KB per lane under the 256-register cap of two waves per SIMD and is no
+            // faster than the streaming search with its deep searches: 6.9 against 6.6 ms at alpha = 0.2
+            // on 48 x 2048 x 4096.)
+            if (retain && (fused_form_long == 2 || (fused_form_long < 0 && alpha > 0.02 && sizeof(T) == 8))) {
+                launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream);
+            } else
             if (k <= 32) {
                 if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, nopm, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));
                 else hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 0, 0>), grid, block, 0, stream, g, tab, nopm, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));

@@ -225,6 +225,32 @@ def test_every_kernel_form_gives_the_same_map(env):
         assert r['bytes_differing'] == 0, r
 
 
+@pytest.mark.parametrize('k,dtype,env', [(20, 'f64', {}), (24, 'f64', {}), (40, 'f32', {'ND_AMD_FUSED_FORM': '2'}),
+                                         (33, 'f32', {'ND_AMD_FUSED_FORM': '2'}), (32, 'f32', {}), (12, 'f64', {})])
+def test_chain_form_series_lengths(k, dtype, env):
+    """dense_chain beyond the 24 float32 dates of the benchmark: 32 float32 / 16 float64 dates (two
+    waves per SIMD), the 64-bit-mask instantiations for 17 .. 24 float64 dates (default between the
+    streaming search's thresholds and the sparse regime) and 33 .. 48 float32 dates (forced; a series
+    shorter than the instantiation's 48 dates exercises the masked tail), each against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py'), '--k', str(k), '--dtype', dtype,
+                          '--ny', '512', '--nx', '2048', '--alphas', '0.05,0.3,0.6', '--steps', '1',
+                          '--cpu-rows', '256', '--layouts', 'planar'],
+                         env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 3, out.stdout[-2000:]
+    for r in lines:
+        assert r['bytes_differing'] == 0, r
+        assert 'omnibus_c2_fused' in r['kernels_ms'], r
+
+
 @pytest.mark.parametrize('dtype,k', [('float32', 40), ('float64', 24), ('float32', 80)])
 def test_long_series_statistics_at_scale(oracle, dtype, k):
     """Series beyond the register forms on a raster large enough for the device-side density gate:
