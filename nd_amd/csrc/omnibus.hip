@@ -2319,6 +2319,285 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     if (!dense && wnp > 0) zero_fill_span(wob, wnp * k, lane);
 }
 
+// -----------------------------------------------------------------------------------------
+// The chain search for series that do not fit the registers (33 .. 128 dates; float64: 25 .. 128), in
+// TWO STREAMING PASSES over the planes: pass 1 as omnibus_c2_stream_kernel's global tests (dates last
+// to first, suffix sums, two mask bits per date), pass 2 as dense_chain's forward pass with the dates
+// read again, first to last (the wave's 4 k lines are re-read a few microseconds after pass 1
+// touched them).  ~110 vector instructions per date whatever the threshold, against the streaming
+// search's deep searches from memory, which at thresholds between 0.02 and the sparse regime take
+// several times the streaming pass itself (48 x 2048 x 4096, alpha = 0.2: 6.6 ms).  Twice the
+// traffic of the one-pass forms: the choice for these thresholds only.
+// -----------------------------------------------------------------------------------------
+template <typename T, int PF, int MODE, int MW>
+__global__ void __launch_bounds__(kRetainThreads)
+omnibus_c2_stream_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const StreamScreen<stream_nj(MW)> ss)
+{
+    static_assert(MODE == 0 || MODE == 1, "planar inputs");
+    if (omni_gate_skip(g)) return;
+    constexpr int kMaxDates = stream_nj(MW);
+    typedef typename std::conditional<MW == 2, Bits128,
+                                      typename std::conditional<MW == 1, unsigned long long, unsigned>::type>::type MT;
+    __shared__ StreamEntry tab_lds[kMaxDates + 1];
+    __shared__ __align__(16) uint32_t out_img[(kRetainThreads / 64) * 16 * kMaxDates];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kRetainThreads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+    for (int j = tid; j <= kMaxDates; j += kRetainThreads) tab_lds[j] = ss.e[j];
+    if (g.write_tab && b == 0) {
+        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
+    }
+    PlaneReader<T, MODE> rd;
+    {
+        const int64_t xc = in ? x0 : g.nx - 1;                  // idle lanes re-read the last pixel
+        if (MODE == 1) {
+            const int64_t ub = row * g.sy + bpx0;
+            rd.voff = (unsigned)(xc - bpx0) * (unsigned)sizeof(T);
+            rd.r11 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c11 + ub), 0, 0x7fffffff, 0x00020000);
+            rd.r12r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12r + ub), 0, 0x7fffffff, 0x00020000);
+            rd.r12i = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12i + ub), 0, 0x7fffffff, 0x00020000);
+            rd.r22 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c22 + ub), 0, 0x7fffffff, 0x00020000);
+            rd.sstep = (unsigned)g.st * (unsigned)sizeof(T);
+        } else {
+            const int64_t off0 = row * g.sy + xc * g.sx;
+            rd.p11 = g.c11 + off0;
+            rd.p12r = g.c12r + off0;
+            rd.p12i = g.c12i + off0;
+            rd.p22 = g.c22 + off0;
+            rd.st = g.st;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 1: the global test of every segment start, dates last to first ----
+    const T dlo = (T)ss.dlo, dhi = (T)ss.dhi;
+    MT gF = mask_zero<MT>(), gC = mask_zero<MT>();
+    bool bad = false, dead = false;
+    {
+        DateVal<T> ring[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = k - 1 - u;
+            ring[u] = rd.load(t > 0 ? t : 0);
+        }
+        double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0, PP = 1.0;
+        int emin = 1, emax = 1;
+        auto back = [&](const DateVal<T> &q, const int t, const StreamEntry &c) {
+            const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+            bad = bad | !((q.a > (T)0) & (det > dlo) & (det < dhi));
+            dead = dead | !((det > (T)0) | (det < (T)0));
+            PP = PP * (double)det;
+            S11 += (double)q.a;
+            S12r += (double)q.b;
+            S12i += (double)q.c;
+            S22 += (double)q.d;
+            const int jj = k - t;
+            const double pp = S11 * S22;
+            const double dets = pp - ((S12r * S12r) + (S12i * S12i));
+            const float df = (float)dets;
+            bool okd;
+            int es, eP;
+            float ms, mP;
+            if (sizeof(T) == 4) {
+                okd = df > 7.888609052210118e-31f;
+                log2_parts(df, es, ms);
+            } else {
+                okd = (dets > 0.0) & (dets < (double)INFINITY);
+                log2_parts(dets, es, ms);
+            }
+            log2_parts(PP, eP, mP);
+            emin = eP < emin ? eP : emin;
+            emax = eP > emax ? eP : emax;
+            const int E = (eP - c.re) - __mul24(jj, es);
+            const float x = (float)E + __builtin_fmaf(-c.jf, ms, mP - c.rf);
+            const float qq = (float)pp * __builtin_amdgcn_rcpf(df);
+            const float rel = c.cj * qq;
+            const float m2 = c.mj * rel;
+            bad = bad | !(okd & (rel < 0.01f));
+            mask_push(gF, x + m2 < c.a);
+            mask_push(gC, x - m2 > c.b);
+        };
+        int tb = k - 1;
+        for (; tb >= PF - 1; tb -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = tb - u;
+                back(ring[u], t, ss.e[k - t]);
+                ring[u] = rd.load(t >= PF ? t - PF : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb - u;
+            if (t >= 0) back(ring[u], t, ss.e[k - t]);
+        }
+        bad = bad | (emax - emin > 900);
+    }
+    MT gI = mask_undecided(gF, gC);
+    mask_keep_low(gF, k - 1);
+    mask_keep_low(gI, k - 1);
+    if (dead) {
+        bad = false;
+        gF = mask_zero<MT>();
+        gI = mask_zero<MT>();
+    }
+    const unsigned shard = (unsigned)(b % kShards);
+    const int64_t wpx0 = bpx0 + (tid & ~63);
+    const int64_t wleft = g.nx - wpx0;
+    const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
+    uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
+    const bool cand = in && (bad || mask_bit(gF, 0) || mask_bit(gI, 0));
+    const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
+    bool listed = cand;
+    if (dense) {
+        // ---- pass 2: marginal tests and restarts, dates first to last ----
+        // A global test pass 1 could not decide (its band grows with the square of the series
+        // length: at 96 dates a few per cent of the pixels have one) is decided HERE, exactly: the
+        // search goes on as if it fired, and a second running state -- the reference's own sums and
+        // product from that segment start, carried on across the restarts to the last date -- gives
+        // the test's determinants bit for bit, hence the tight band of the marginal tests.  If it
+        // turns out not to fire, the changes recorded behind its start are dropped.  One pending test
+        // per pixel; a second one hands the pixel over.
+        bool handoff = in && bad;
+        bool done = !in || bad || !(mask_bit(gF, 0) || mask_bit(gI, 0));
+        bool pend = !done && mask_bit(gI, 0);
+        int lp = 0;
+        T p11 = (T)0, p12r = (T)0, p12i = (T)0, p22 = (T)0;
+        double PQ = 1.0;
+        MT mask = mask_zero<MT>();
+        DateVal<T> ring[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) ring[u] = rd.load(u < k ? u : k - 1);
+        T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
+        double PP = 1.0;
+        int j = 0;
+        auto fwd = [&](const DateVal<T> &q, const int t) {
+            const bool last = (t == k - 1);
+            const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+            s11 = s11 + q.a;
+            s12r = s12r + q.b;
+            s12i = s12i + q.c;
+            s22 = s22 + q.d;
+            PP = PP * (double)det;
+            j = j + 1;
+            const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
+            const bool oks = (dets > (T)0) & (dets < (T)INFINITY);
+            const StreamEntry *ep = tab_lds + j;                 // the lane's own j
+            const int re = ep->re;
+            const float rf = ep->rf, ca = ep->a, cb = ep->b;
+            int es, eP;
+            float ms, mP;
+            log2_parts(dets, es, ms);
+            log2_parts(PP, eP, mP);
+            const int E = (eP - re) - __mul24(j, es);
+            const float x = (float)E + __builtin_fmaf(-(float)j, ms, mP - rf);
+            // (the first date of the series only starts the state: j = 1, no test)
+            const bool tested = t > 0;
+            const bool fires = tested & (last | (oks & (x < ca)));
+            const bool cant = !tested | (!last & oks & (x > cb));
+            const bool act = !done;
+            const bool und = act & !(fires | cant);
+            const bool f = act & fires;
+            handoff = handoff | und;
+            mask_set(mask, t, f);                                // :252
+            const bool gi = mask_bit(gI, t), gf = mask_bit(gF, t);
+            const bool newp = f & !last & gi;                    // an undecided global test starts here
+            handoff = handoff | (newp & pend);
+            done = done | und | (newp & pend) | (f & (last | !(gf | gi)));   // :256, :241-242
+            p11 = p11 + q.a;
+            p12r = p12r + q.b;
+            p12i = p12i + q.c;
+            p22 = p22 + q.d;
+            PQ = PQ * (double)det;
+            const bool startp = newp & !pend;
+            p11 = startp ? q.a : p11;
+            p12r = startp ? q.b : p12r;
+            p12i = startp ? q.c : p12i;
+            p22 = startp ? q.d : p22;
+            PQ = startp ? (double)det : PQ;
+            lp = startp ? t : lp;
+            pend = pend | startp;
+            s11 = f ? q.a : s11;
+            s12r = f ? q.b : s12r;
+            s12i = f ? q.c : s12i;
+            s22 = f ? q.d : s22;
+            PP = f ? (double)det : PP;
+            j = f ? 1 : j;
+        };
+        int tb = 0;
+        for (; tb + PF <= k; tb += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = tb + u;
+                fwd(ring[u], t);
+                ring[u] = rd.load(t + PF < k ? t + PF : k - 1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb + u;
+            if (t < k) fwd(ring[u], t);
+        }
+        if (__any(pend)) {
+            // the pending global test over ts[lp:], from the reference's own sums
+            const int jp = k - lp;
+            const T dets = (p11 * p22) - ((p12r * p12r) + (p12i * p12i));
+            const bool oks = (dets > (T)0) & (dets < (T)INFINITY);
+            const StreamEntry *ep = tab_lds + jp;
+            int es, eP;
+            float ms, mP;
+            log2_parts(dets, es, ms);
+            log2_parts(PQ, eP, mP);
+            const int E = (eP - ep->re) - __mul24(jp, es);
+            const float x = (float)E + __builtin_fmaf(-(float)jp, ms, mP - ep->rf);
+            const bool fires = oks & (x < ep->a);
+            const bool cant = oks & (x > ep->b);
+            if (pend) {
+                if (!(fires | cant)) handoff = true;
+                if (cant) mask_keep_low(mask, lp + 1);       // the search ended at lp (:241-242)
+            }
+        }
+        if (handoff) mask = mask_zero<MT>();                  // pass B writes that pixel's changes
+        if (change_rows_wave_ok(wob, k, wnp)) {
+            store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * kMaxDates), k, mask, lane);
+        } else if (in) {
+            uint8_t *res = wob + (int64_t)lane * k;
+            for (int t = 0; t < k; ++t) res[t] = (uint8_t)(mask_bit(mask, t) ? 1 : 0);
+        }
+        listed = handoff;
+    }
+    if (__any(listed)) {
+        const unsigned long long lm_ = __ballot(listed);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(lm_));
+        base = __shfl(base, 0);
+        if (listed) {
+            const unsigned slot = base + (unsigned)__popcll(lm_ & ((1ull << lane) - 1ull));
+            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
+            if (slot < g.dump_cap) {
+                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
+                for (int t = 0; t < k; ++t) {
+                    const DateVal<T> q = rd.load(t);
+                    Pack<T, 4> o;
+                    o.v[0] = q.a;
+                    o.v[1] = q.b;
+                    o.v[2] = q.c;
+                    o.v[3] = q.d;
+                    *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = o;
+                }
+            }
+        }
+    }
+    if (!dense && wnp > 0) zero_fill_span(wob, wnp * k, lane);
+}
+
 // =========================================================================================
 // pass B
 // =========================================================================================
@@ -2576,9 +2855,13 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
     const int lane = threadIdx.x;
     const int k = s.k;
     const int ns = k - 1;                       // segment starts per pixel: 0 .. k - 2
-    const int ppw = 64 / ns;                    // pixels per wave
-    const int grp = lane / ns;
-    const int l = lane - grp * ns;
+    // up to 64 starts: 64 / ns pixels per wave, one start per lane; 65 .. 128 starts (series of up
+    // to 129 dates): one pixel per wave, lane l takes the starts l and l + 64, one after the other
+    const int ppw = ns <= 64 ? 64 / ns : 1;     // pixels per wave
+    const int nsw = ns <= 64 ? ns : 64;         // lanes per pixel
+    const int nsweep = ns <= 64 ? 1 : 2;
+    const int grp = lane / nsw;
+    const int l0 = lane - grp * nsw;
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards;
     const unsigned nlblock = gridDim.x / kShards;
@@ -2635,6 +2918,10 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
             }
             return q;
         };
+        int nxt_a = -1, nxt_b = -1;             // per sweep: the next segment start, or stop
+        for (int sweep = 0; sweep < nsweep; ++sweep) {
+        const int l = l0 + 64 * sweep;
+        const bool lact = active && l < ns;
         Accum<T> A;
         A.reset();
         int fire_at = -1;
@@ -2648,13 +2935,13 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
             for (int u = 0; u < 4; ++u) {
                 const int t = l + i0 + u;
                 q[u].v[0] = q[u].v[1] = q[u].v[2] = q[u].v[3] = (T)0;
-                if (active && t < k) q[u] = fetch(t);
+                if (lact && t < k) q[u] = fetch(t);
             }
         };
         Pack<T, 4> qn[4];
         fetch4(0, qn);
         for (int i0 = 0; i0 < k; i0 += 4) {     // the lane's dates are l + i0 .. l + i0 + 3
-            if (!__any(active && l + i0 < k)) break;
+            if (!__any(lact && l + i0 < k)) break;
             Pack<T, 4> q[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) q[u] = qn[u];
@@ -2663,7 +2950,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u;
                 const int t = l + i;
-                const bool on = active && t < k;
+                const bool on = lact && t < k;
                 if (on) A.step(q[u].v[0], q[u].v[1], q[u].v[2], q[u].v[3]);
                 const int jj = i + 1;
                 const bool last = (t == k - 1);
@@ -2694,16 +2981,20 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
                 if (on && last && fires) nxt = fire_at;      // the global test of ts[l:] fired (jj >= 2 here)
             }
         }
+        if (sweep == 0) nxt_a = nxt; else nxt_b = nxt;
+        }
         // follow the chain from l = 0; the group's first lane writes the changes
         int at = 0;
         for (int step = 0; step < ns; ++step) {
-            const int src = grp * ns + (at >= 0 && at < ns ? at : 0);
-            const int n1 = __shfl(nxt, src);
+            const int ats = (at >= 0 && at < ns) ? at : 0;
+            const int src = grp * nsw + (ats & 63) % nsw;
+            const int na = __shfl(nxt_a, src), nb = __shfl(nxt_b, src);
+            const int n1 = (ns > 64 && ats >= 64) ? nb : na;
             if (at >= 0 && at < ns) {
                 if (n1 < 0) {
                     at = -1;                                   // :241-242
                 } else {
-                    if (active && l == 0) s.change[pix * (int64_t)k + n1] = 1;   // :252 (the row was zero-filled)
+                    if (active && l0 == 0) s.change[pix * (int64_t)k + n1] = 1;  // :252 (the row was zero-filled)
                     at = n1;                                   // :255; n1 = k - 1 ends the search (:256)
                 }
             }
@@ -3369,7 +3660,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     g.gate_mode = 0;
     {
         const size_t per = (size_t)k * 4 * sizeof(T);
-        size_t cap = retain ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
+        // (the streaming searches of longer series write the few pixels they hand over as well: pass B
+        // would otherwise gather 4 x k isolated values per pixel from planes megabytes apart)
+        size_t cap = (retain || stream_long) ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
         g.seg = omni_seg(npix, ny);
         if (cap > g.seg) cap = g.seg;
         g.dump = reinterpret_cast<T *>(ws + w.off_dump);
@@ -3537,7 +3830,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             const char *e = getenv("ND_AMD_SEARCH_STARTS");      // list length per shard up to which ...; 0 = off
             return e ? atoi(e) : 512;
         }();
-        const bool starts_form = low_threshold && k >= 2 && k <= 65 && starts_env > 0 && mode_env < 0;
+        const bool starts_form = low_threshold && k >= 2 && k <= 129 && starts_env > 0 && mode_env < 0;
         if (starts_form) {
             s.starts_max = (uint32_t)starts_env;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
@@ -3824,6 +4117,19 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             // on 48 x 2048 x 4096.)
             if (retain && (fused_form_long == 2 || (fused_form_long < 0 && alpha > 0.02 && sizeof(T) == 8))) {
                 launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream);
+            } else if (fused_form_long == 3 || (fused_form_long < 0 && alpha > 0.02)) {
+                // longer series between the streaming search's thresholds and the sparse regime: the
+                // chain search in two streaming passes (ND_AMD_FUSED_FORM=3 forces it, 0 the one-pass form)
+                if (k <= 32) {
+                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));
+                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 0>), grid, block, 0, stream, g, tab, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));
+                } else if (k <= 64) {
+                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 1>), grid, block, 0, stream, g, tab, make_stream_screen<T, 64>(htab, scr, (int)k, n_looks));
+                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 1>), grid, block, 0, stream, g, tab, make_stream_screen<T, 64>(htab, scr, (int)k, n_looks));
+                } else {
+                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 2>), grid, block, 0, stream, g, tab, make_stream_screen<T, 128>(htab, scr, (int)k, n_looks));
+                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 2>), grid, block, 0, stream, g, tab, make_stream_screen<T, 128>(htab, scr, (int)k, n_looks));
+                }
             } else
             if (k <= 32) {
                 if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, nopm, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));

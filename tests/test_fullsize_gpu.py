@@ -226,12 +226,16 @@ def test_every_kernel_form_gives_the_same_map(env):
 
 
 @pytest.mark.parametrize('k,dtype,env', [(20, 'f64', {}), (24, 'f64', {}), (40, 'f32', {'ND_AMD_FUSED_FORM': '2'}),
-                                         (33, 'f32', {'ND_AMD_FUSED_FORM': '2'}), (32, 'f32', {}), (12, 'f64', {})])
+                                         (33, 'f32', {'ND_AMD_FUSED_FORM': '2'}), (32, 'f32', {}), (12, 'f64', {}),
+                                         (40, 'f32', {}), (63, 'f32', {}), (96, 'f32', {}), (128, 'f32', {}), (40, 'f64', {}),
+                                         (96, 'f32', {'ND_AMD_FUSED_FORM': '3', 'ND_AMD_SEARCH_STARTS': '0'})])
 def test_chain_form_series_lengths(k, dtype, env):
     """dense_chain beyond the 24 float32 dates of the benchmark: 32 float32 / 16 float64 dates (two
     waves per SIMD), the 64-bit-mask instantiations for 17 .. 24 float64 dates (default between the
     streaming search's thresholds and the sparse regime) and 33 .. 48 float32 dates (forced; a series
-    shorter than the instantiation's 48 dates exercises the masked tail), each against the oracle."""
+    shorter than the instantiation's 48 dates exercises the masked tail), and beyond the registers
+    the chain search in two streaming passes (33 .. 128 dates: 64- and 128-bit masks, pending global
+    tests, the per-start pass B with two starts per lane), each against the oracle."""
     import json
     import os
     import subprocess
@@ -240,7 +244,7 @@ def test_chain_form_series_lengths(k, dtype, env):
     e = dict(os.environ)
     e.update(env)
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py'), '--k', str(k), '--dtype', dtype,
-                          '--ny', '512', '--nx', '2048', '--alphas', '0.05,0.3,0.6', '--steps', '1',
+                          '--ny', '256' if k > 64 else '512', '--nx', '2048', '--alphas', '0.05,0.3,0.6', '--steps', '1',
                           '--cpu-rows', '256', '--layouts', 'planar'],
                          env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
