@@ -3638,7 +3638,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const char *e = getenv("ND_AMD_FUSED_ALPHA");
         return e ? atof(e) : 0.75;
     }();
-    const bool fused = retain && dense_ok && !stats && g.dense_min <= 64 && alpha < fused_alpha;
+    // (z / P rasters asked for on top: they come from one launch of the plain pass A first, see below)
+    const bool fused = retain && dense_ok && g.dense_min <= 64 && alpha < fused_alpha;
+    const bool fused_stats = fused && stats;
     // Series beyond the register forms (33 .. 128 dates; float64: 17 .. 128): the streaming search with
     // 64- or 128-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
     // (k = 48 at alpha = 0.01: 118 ms per 16.7 Mpx).
@@ -4033,6 +4035,23 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
 #undef ND_LAUNCH_PM
         }
     } else if (fused) {
+        if (fused_stats) {
+            // the rasters from the plain pass A (it evaluates the whole-series test of every pixel
+            // anyway), the map from the fused search: without this split a low-threshold call with
+            // rasters sent every pixel through pass B (24 x 2048 x 4096 at alpha = 0.01: 3.2 ms against 0.7)
+            const int dm = g.dense_min;
+            g.dense_min = 65;
+            {
+                KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+                launch_retain<T>(g, tab, nblocks, true, stream);
+            }
+            ND_HIP_CHECK(hipGetLastError());
+            // its candidate lists are not used: the search below makes its own
+            ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
+            g.z_out = nullptr;
+            g.p_out = nullptr;
+            g.dense_min = dm;
+        }
         gated = take_sample();
         const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
         g.gate_mode = gated ? 1 : 0;
@@ -4070,7 +4089,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             // separate dense kernel below)
             g.gate_mode = 2;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-            launch_retain<T>(g, tab, nblocks, stats, stream);
+            launch_retain<T>(g, tab, nblocks, stats && !fused_stats, stream);
         }
         g.gate_mode = 0;
     } else if (stream_long) {
