@@ -3558,6 +3558,19 @@ static void launch_retain(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_
     }
 }
 
+// ND_AMD_FUSED_FORM: which fused search serves the thresholds below the sparse regime -- 0 the
+// streaming search, 1 the triangle of dense_search on the retained series, 2 dense_chain on the
+// retained series, 3 dense_chain in two streaming passes (longer series); unset (-1): by threshold
+// and series length.  Speed only: every form gives the same map.
+static int fused_form_env()
+{
+    static const int v = [] {
+        const char *e = getenv("ND_AMD_FUSED_FORM");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
 template <typename T>
 static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im, const void *c22,
                            int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int64_t st,
@@ -3962,10 +3975,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                     return e ? atoi(e) : -1;
                 }();
                 const bool pm_direct4 = pm_sector_env >= 0 ? pm_sector_env != 0 : alpha <= 1e-3;
-                static const int fused_form_pm = [] {
-                    const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 2 = chain; else by alpha
-                    return e ? atoi(e) : -1;
-                }();
+                const int fused_form_pm = fused_form_env();
                 if ((fused_form_pm == 2 || (fused_form_pm != 0 && alpha > 0.02)) && k <= 24) {
                     // dense_chain behind the LDS-DMA staging: the form for the thresholds in between
                     if (k <= 8)
@@ -4057,13 +4067,11 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         g.gate_mode = gated ? 1 : 0;
         {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
-        // Two forms of the fused kernel, same map: the streaming one wins while searches beyond
-        // three dates are rare (a row needs one with probability ~ alpha per pixel): measured
-        // 2.3 vs 3.1 ms at alpha = 0.01, break-even at 0.05, 6.3 vs 5.1 ms at 0.2 (24 x 4096^2).
-        static const int fused_form = [] {
-            const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 1 = triangle in registers, 2 = chain; else by alpha
-            return e ? atoi(e) : -1;
-        }();
+        // Forms of the fused kernel, same map: the streaming one wins while searches beyond three dates
+        // are rare (kernel 1.40 - 1.46 ms at alpha = 0.01 against 1.57 for dense_chain, 1.18 against 1.31 at
+        // 1e-4); above, dense_chain costs the same at every threshold (1.55 ms) where the streaming
+        // search's deep searches take 2.5 ms at 0.05 and 4.6 at 0.2 (24 x 4096^2).
+        const int fused_form = fused_form_env();
         const bool regs_form = fused_form == 1;
         const bool chain_form = fused_form == 2 || (fused_form < 0 && alpha > 0.02);
         if (chain_form) {
@@ -4125,10 +4133,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             OmniPmDmaArgs<T> nopm;
             memset(&nopm, 0, sizeof(nopm));
             const bool buf = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
-            static const int fused_form_long = [] {
-                const char *e = getenv("ND_AMD_FUSED_FORM");      // 0 = streaming, 2 = chain; else by alpha
-                return e ? atoi(e) : -1;
-            }();
+            const int fused_form_long = fused_form_env();
             // float64 series of 17 .. 24 dates still fit the registers (as 32 float32 dates do): the
             // chain form.  (33 .. 48 float32 dates: the instantiation exists -- ND_AMD_FUSED_FORM=2 --
             // but spills 2 KB per lane under the 256-register cap of two waves per SIMD and is no
