@@ -866,7 +866,7 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         int ks = g.k;
         asm volatile("" : "+s"(ks));
         dense_chain<T, KMAX, 32>(v, ks, in, ss, tab_lds, mask, handoff, cand);
-        dense = __popcll(__ballot(cand)) >= g.dense_min;
+        dense = true;                 // the search is done: its result serves every pixel of the wave
         flag = cand;
         if (dense) {
             if (handoff) mask = 0u;                           // pass B writes that pixel's changes
@@ -1297,23 +1297,17 @@ __device__ __forceinline__ void store_change_row(uint8_t *res, const int k, cons
 
 template <typename T, int KMAX>
 __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDenseArgs<T> s,
-                                                              const DenseScreen scr_arg)
+                                                              const StreamScreen<32> ss)
 {
-    __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
+    __shared__ StreamEntry tab_lds[33];
     const int lane = threadIdx.x;
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards, nlblock = gridDim.x / kShards;
     const uint32_t n = s.flag_count[shard * kCounterStride + 1];
     if (lblock >= n) return;                  // the usual case in the sparse regime: nothing listed
     const uint32_t *list = s.dense_idx + (size_t)shard * s.segd;
-    // static indices only: a lane-indexed read of the argument struct would pull all of it into
-    // scalar registers at once
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j <= KMAX; ++j) scr_lds[j] = scr_arg.e[j];
-    }
+    if (lane <= 32) tab_lds[lane] = ss.e[lane];
     __syncthreads();
-    const ScreenRegs scr = screen_regs_load(scr_lds, lane);
 
     for (uint32_t w = lblock; w < n; w += nlblock) {
         // (opaque copy of k per wave of pixels: everything derived from k alone -- per-date
@@ -1351,9 +1345,11 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
             v[t][3] = (s.c22 + ot)[delta];
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the loads together, ahead of every use
+        // (round 3: the two linear passes of dense_chain; the triangle of dense_search took 1.18 ms
+        // here at alpha = 0.8, where a fifth of the pixels are flagged and most waves are dense)
         unsigned mask;
-        bool handoff;
-        dense_search<T, KMAX>(v, k, active, scr, mask, handoff);
+        bool handoff, cand;
+        dense_chain<T, KMAX, 32>(v, k, active, ss, tab_lds, mask, handoff, cand);
         if (active && !handoff && mask != 0u) store_change_row(s.change + pix * (int64_t)k, k, mask);
         if (__any(handoff)) {
             const unsigned long long m = __ballot(handoff);
@@ -1599,8 +1595,11 @@ omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Stre
     int ks = g.k;
     asm volatile("" : "+s"(ks));
     dense_chain<T, KMAX, NJ>(v, ks, in, ss, tab_lds, mask, handoff, cand);
-    bool listed = cand;                                       // pixels that go to pass B
-    const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
+    // The search of every pixel is done whatever the wave's share of candidates: its result is
+    // used for all of them (only what the screen could not decide goes to pass B; `dense_min`
+    // belongs to the forms that search on demand).
+    bool listed = cand;
+    const bool dense = true;
     if (dense) {
         if (handoff) mask = 0;                                // pass B writes that pixel's changes
         if (change_rows_wave_ok(wob, k, wnp)) {
@@ -3651,8 +3650,17 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const char *e = getenv("ND_AMD_FUSED_ALPHA");
         return e ? atof(e) : 0.75;
     }();
+    // The chain form in registers costs the same at every threshold (1.55 ms on 24 x 4096^2), and the
+    // sparse design passes that where a tenth of the pixels are candidates (alpha = 0.76 / 0.8 / 0.85:
+    // 2.9 / 2.5 / 2.1 ms): it is offered up to 0.93, and the device-side sample decides.  The forms
+    // that pay more for fusing (pixel-major: the LDS images; longer series: two streaming passes)
+    // keep 0.75.
+    static const double fused_alpha_regs = [] {
+        const char *e = getenv("ND_AMD_FUSED_ALPHA");
+        return e ? atof(e) : 0.93;
+    }();
     // (z / P rasters asked for on top: they come from one launch of the plain pass A first, see below)
-    const bool fused = retain && dense_ok && g.dense_min <= 64 && alpha < fused_alpha;
+    const bool fused = retain && dense_ok && g.dense_min <= 64 && alpha < fused_alpha_regs;
     const bool fused_stats = fused && stats;
     // Series beyond the register forms (33 .. 128 dates; float64: 17 .. 128): the streaming search with
     // 64- or 128-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
@@ -3763,17 +3771,18 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         if (per_shard_d < 1) per_shard_d = 1;
         const dim3 gridd((unsigned)(per_shard_d * kShards)), blockd(64);
         const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+        const StreamScreen<32> ssd = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_DENSE, sq);
         if (k <= 8)
-            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 8>), gridd, blockd, 0, sq, d, scr);
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 8>), gridd, blockd, 0, sq, d, ssd);
         else if (k <= 16)
-            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 16>), gridd, blockd, 0, sq, d, scr);
+            hipLaunchKernelGGL((omnibus_c2_dense_kernel<T, 16>), gridd, blockd, 0, sq, d, ssd);
         else if (sizeof(T) == 4 && k <= 24)
             hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 24>), gridd, blockd, 0, sq,
-                               reinterpret_cast<const OmniDenseArgs<float> &>(d), scr);
+                               reinterpret_cast<const OmniDenseArgs<float> &>(d), ssd);
         else if (sizeof(T) == 4)
             hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 32>), gridd, blockd, 0, sq,
-                               reinterpret_cast<const OmniDenseArgs<float> &>(d), scr);
+                               reinterpret_cast<const OmniDenseArgs<float> &>(d), ssd);
     };
     const bool low_threshold = fused || stream_long || (pm_ids != nullptr && alpha < fused_alpha);
     auto launch_search = [&](hipStream_t sq, const uint32_t *count, const uint32_t *idx, const T *dump,
