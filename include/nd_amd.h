@@ -91,7 +91,8 @@ const char *nd_amd_last_error(void);
  * with a new (k, n_looks, alpha, dtype) tabulates one pair of decision bounds
  * per sub-series length on the host (O(k^2) work, cached); their safety
  * margin grows with k (see omni_bounds) so that very long series stay exact.
- * Fast forms of the low-threshold regime (alpha < 0.75, most pixels changing)
+ * Fast forms of the regimes in which most pixels change (alpha below ~0.9;
+ * chosen by threshold, series length and a device-side sample of the data)
  * cover k <= 128; longer series are still exact but search pixel by pixel.
  * ---------------------------------------------------------------------- */
 size_t nd_amd_omnibus_c2_workspace_bytes(int dtype, int64_t ny, int64_t nx, int64_t k,
