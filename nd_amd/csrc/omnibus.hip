@@ -2188,7 +2188,7 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
             //   otherwise the global test decidedly does not fire       -> the search ends (:241-242)
             // A run of A1 bits is a run of changes at consecutive dates: one count-trailing-zeros.
             const MT one = (MT)1;
-            const MT LA = one << (k - 2);
+            const MT LA = k >= 2 ? one << (k - 2) : (MT)0;         // (a single date: no test at all)
             const MT LB = k >= 3 ? one << (k - 3) : (MT)0;
             const MT gOK = gF & ~gI;
             const MT A1 = gOK & (LA | m2F);
