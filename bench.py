@@ -466,10 +466,10 @@ def extras(main, barrier, dev, only=None):
             dom = max(km, key=km.get)
             entry(key, 'OmnibusTest C2 %dt x %d x %d f32 in the reference layout (y, x, time), C12 complex64, '
                   'alpha=%g' % (main.k, main.rows, main.nx, alpha), dt, 10, main.npix, km,
-                  roof(key, 'pm_dma' if alpha > 0.5 else 'stream_kernel', dom, km, main.alg_bytes,
+                  roof(key, 'pm_dma', dom, km, main.alg_bytes,
                        note='LDS-DMA staging of pixel-major spans (global_load_lds_dwordx4)' if alpha > 0.5 else
-                       'streaming search on the wave\'s LDS-DMA images of the pixel-major series '
-                       '(24.6 KB per wave, six waves per CU)'),
+                       'dense_chain behind the staging: C12 through an LDS-DMA image, C11 / C22 straight '
+                       'into registers (half the LDS, twice the waves per CU)'),
                   res['bad'] == 0 and same, sample=res, equal_to_planar_map=same)
             del ch, ref
         del c12, pmv

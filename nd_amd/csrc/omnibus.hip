@@ -798,7 +798,12 @@ __device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, 
 
 // CHAIN: the search fused in (dense_chain on the registers the series was picked into), for
 // thresholds between the streaming search's and the sparse regime; `ss` is only read then.
-template <typename T, int KMAX, bool STATS, bool CHAIN = false>
+// DIRECT (with CHAIN): only C12 goes through an LDS image; each lane reads its own C11 / C22 series
+// (k contiguous values) straight into registers, every 16-byte piece in flight at once -- the lines
+// are shared by neighbouring lanes and consecutive pieces, so they are fetched once -- and the image
+// is half the size: twice the waves per CU (24 x 4096^2: 2.5 -> 2.0 ms).  C12 as well, no image at
+// all: 3.3 ms -- its 192-byte pitch per lane is too much for the address coalescer.
+template <typename T, int KMAX, bool STATS, bool CHAIN = false, bool DIRECT = false>
 __global__ void __launch_bounds__(64)
 omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const OmniPmDmaArgs<T> pm,
                          const StreamScreen<32> ss)
@@ -829,8 +834,10 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
                 __builtin_amdgcn_global_load_lds((glb_u8_t *)(src + eb), (lds_u8_t *)(dst + c0), 16, 0, kNtAux);
         }
     };
-    stage(g.c11, 0);
-    stage(g.c22, 3);
+    if (!DIRECT) {
+        stage(g.c11, 0);
+        stage(g.c22, 3);
+    }
     stage(g.c12r, 1);
     if (!pm.c12_joint) stage(g.c12i, 2);
 
@@ -848,8 +855,28 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         __syncthreads();
     }
     const int own = in ? lane : np - 1;
+    if (DIRECT) {
+        // (issued before the wait above would be better still; the compiler hoists what it can)
+        constexpr int VE = 16 / (int)sizeof(T);
+        const T *p11 = g.c11 + (px0 + own) * (int64_t)k;
+        const T *p22 = g.c22 + (px0 + own) * (int64_t)k;
+#pragma unroll
+        for (int u = 0; u < KMAX / VE; ++u) {
+            if (u * VE < k) {
+                typedef T tv __attribute__((ext_vector_type(VE)));
+                const tv qa = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p11) + u);
+                const tv qd = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p22) + u);
+#pragma unroll
+                for (int i = 0; i < VE; ++i) {
+                    v[u * VE + i][0] = qa[i];
+                    v[u * VE + i][3] = qd[i];
+                }
+            }
+        }
+    } else {
     pm_pick<T, KMAX, 0, false>(v, img + pm.img_off[0] + own * k * pm.ids[0], k, pm.ids[0]);
     pm_pick<T, KMAX, 3, false>(v, img + pm.img_off[3] + own * k * pm.ids[3], k, pm.ids[3]);
+    }
     if (pm.c12_joint) {
         pm_pick<T, KMAX, 1, true>(v, img + pm.img_off[1] + own * k * 2, k, 2);
     } else {
@@ -3985,6 +4012,25 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 }();
                 const bool pm_direct4 = pm_sector_env >= 0 ? pm_sector_env != 0 : alpha <= 1e-3;
                 const int fused_form_pm = fused_form_env();
+                static const int pm_direct_env = [] {
+                    const char *e = getenv("ND_AMD_PM_DIRECT");        // 0: every variable through an LDS image
+                    return e ? atoi(e) : 1;
+                }();
+                // dense_chain behind the staging, C11 / C22 straight into registers and only C12 through
+                // LDS: at every threshold below the sparse regime (2.0 ms; the streaming search on full
+                // LDS images: 2.05 / 2.37 ms at alpha = 1e-4 / 0.01, dense_chain on full images: 2.5 ms)
+                if (fused_form_pm != 0 && k <= 24 && pm_direct_env && pm_ids[0] == 1 && pm_ids[3] == 1) {
+                    OmniPmDmaArgs<T> dd = dm;
+                    dd.img_off[1] = 0;
+                    dd.img_off[2] = 64 * (int)k * dd.ids[1];
+                    const size_t lds_c12 = (size_t)64 * k * (dd.ids[1] + (dd.c12_joint ? 0 : dd.ids[2])) * sizeof(T);
+                    if (k <= 8)
+                        hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 8, false, true, true>), gridw, blockw, lds_c12, stream, g, tab, dd, ss0);
+                    else if (k <= 16)
+                        hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 16, false, true, true>), gridw, blockw, lds_c12, stream, g, tab, dd, ss0);
+                    else
+                        hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 24, false, true, true>), gridw, blockw, lds_c12, stream, g, tab, dd, ss0);
+                } else
                 if ((fused_form_pm == 2 || (fused_form_pm != 0 && alpha > 0.02)) && k <= 24) {
                     // dense_chain behind the LDS-DMA staging: the form for the thresholds in between
                     if (k <= 8)

@@ -193,11 +193,13 @@ def test_dense_thresholds_whole_raster_equals_oracle(oracle, stack, alpha):
 
 
 @pytest.mark.parametrize('env', [{'ND_AMD_FUSED_FORM': '0'}, {'ND_AMD_FUSED_FORM': '1'}, {'ND_AMD_FUSED_FORM': '2'},
-                                 {'ND_AMD_SEARCH_STARTS': '0'}, {'ND_AMD_PM_STREAM_LDS': '0'},
-                                 {'ND_AMD_FUSED_ALPHA': '0'}, {'ND_AMD_PM_FORM': '1'},
+                                 {'ND_AMD_SEARCH_STARTS': '0'}, {'ND_AMD_PM_STREAM_LDS': '0', 'ND_AMD_FUSED_FORM': '0'},
+                                 {'ND_AMD_FUSED_ALPHA': '0'}, {'ND_AMD_PM_FORM': '1'}, {'ND_AMD_PM_DIRECT': '0'},
                                  {'ND_AMD_GATE': '0'}, {'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '1'},
-                                 {'ND_AMD_PM_STREAM_LDS': '1'}, {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_GATE': '0'},
-                                 {'ND_AMD_PM_STREAM_SECTOR': '0'}, {'ND_AMD_PM_STREAM_SECTOR': '1'},
+                                 {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_FUSED_FORM': '0'},
+                                 {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '0'},
+                                 {'ND_AMD_PM_STREAM_SECTOR': '0', 'ND_AMD_FUSED_FORM': '0'},
+                                 {'ND_AMD_PM_STREAM_SECTOR': '1', 'ND_AMD_FUSED_FORM': '0'},
                                  {'ND_AMD_SEARCH_MODE': '0'}, {'ND_AMD_SEARCH_MODE': '1'},
                                  {'ND_AMD_SEARCH_MODE': '2'}, {'ND_AMD_SEARCH_MODE': '2', 'ND_AMD_FUSED_ALPHA': '0'}])
 def test_every_kernel_form_gives_the_same_map(env):
