@@ -108,6 +108,36 @@ int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void *c12im,
                       void *hip_stream);
 
 /* ------------------------------------------------------------------------
+ * OmnibusTest(ml=w): spatial multilooking fused into the test.
+ * Replaces  ds_m = BoxcarFilter(w=ml).apply(ds_m); n = ml ** 2
+ *           followed by nd._change.change_detection(values, alpha, n)
+ *           nd/change.py:61-69 (BoxcarFilter = scipy.ndimage.convolve with
+ *           ones((ml, ml)) / ml**2, mode 'reflect': nd/filters.py:256-267, 294-298).
+ *
+ * The four planes are read once: every (date, variable) value is the boxcar
+ * mean of its ml x ml window in scipy's arithmetic (double products and sums
+ * in footprint order, rounded to float32) and exists only in registers; the
+ * number of looks is ml * ml.  Results equal nd_amd_correlate on every plane
+ * followed by nd_amd_omnibus_c2 bit for bit.
+ * Covered: float32, stride_x == 1, ml = 3 or 5, 2 <= k <= 24, ny, nx > ml;
+ * anything else returns ND_AMD_EUNSUPPORTED (and the workspace query 0): the
+ * caller then multilooks with nd_amd_correlate and calls nd_amd_omnibus_c2.
+ * The workspace must hold the multilooked series of every pixel the test can
+ * list (they exist nowhere else): nd_amd_omnibus_c2_ml_workspace_bytes() is
+ * the minimum the call accepts; only the listed part is ever touched.
+ * ---------------------------------------------------------------------- */
+size_t nd_amd_omnibus_c2_ml_workspace_bytes(int dtype, int64_t ny, int64_t nx, int64_t k, int ml);
+
+int nd_amd_omnibus_c2_ml(const void *c11, const void *c12re, const void *c12im,
+                         const void *c22, int dtype,
+                         int64_t ny, int64_t nx, int64_t k,
+                         int64_t stride_y, int64_t stride_x, int64_t stride_t,
+                         int ml, double alpha,
+                         uint8_t *change, void *z_out, void *p_out,
+                         void *workspace, size_t workspace_bytes,
+                         void *hip_stream);
+
+/* ------------------------------------------------------------------------
  * OmnibusTest, full-pol C3 (3 x 3 complex Hermitian) -- EXTENSION.
  * The reference has no full-pol implementation (p = 2 is hard-coded,
  * nd/_change.pyx:51, 99, 135); this is the same algorithm with p = 3 and the

@@ -23,6 +23,7 @@ KERNEL_NAMES = {1: 'omnibus_c2_global', 2: 'omnibus_c2_search', 3: 'correlate',
 SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_omnibus_c2_workspace_bytes', 'nd_amd_omnibus_c2',
            'nd_amd_omnibus_c2_pixel_major',
+           'nd_amd_omnibus_c2_ml_workspace_bytes', 'nd_amd_omnibus_c2_ml',
            'nd_amd_omnibus_c3_workspace_bytes', 'nd_amd_omnibus_c3',
            'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_correlate1d_yx', 'nd_amd_nlmeans3d',
            'nd_amd_relayout_planar', 'nd_amd_relayout_planar_complex',
@@ -60,6 +61,11 @@ def lib():
     L.nd_amd_omnibus_c2.restype = i32
     L.nd_amd_omnibus_c2.argtypes = ([vp] * 4 + [i32] + [i64] * 6 + [C.c_uint32, dbl]
                                     + [vp, vp, vp, vp, C.c_size_t, vp])
+    L.nd_amd_omnibus_c2_ml_workspace_bytes.restype = C.c_size_t
+    L.nd_amd_omnibus_c2_ml_workspace_bytes.argtypes = [i32, i64, i64, i64, i32]
+    L.nd_amd_omnibus_c2_ml.restype = i32
+    L.nd_amd_omnibus_c2_ml.argtypes = ([vp] * 4 + [i32] + [i64] * 6 + [i32, dbl]
+                                       + [vp, vp, vp, vp, C.c_size_t, vp])
     L.nd_amd_omnibus_c2_pixel_major.restype = i32
     L.nd_amd_omnibus_c2_pixel_major.argtypes = ([vp] * 4 + [i32] + [i64] * 3 + [C.POINTER(i64)]
                                                 + [C.c_uint32, dbl] + [vp, vp, vp, vp, C.c_size_t, vp])

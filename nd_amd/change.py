@@ -7,6 +7,8 @@ returns a boolean DataArray `change` with dims ('y', 'x', 'time'), exactly as
 nd.change.OmnibusTest does (nd/change.py:32-116); the per-pixel work that the reference hands to
 `nd._change.change_detection` (nd/change.py:69) runs in the HIP kernels of nd_amd/csrc/omnibus.hip.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -156,17 +158,27 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
                     stats=stats)
         if res is None:
             names = _VARS3 if full_pol else _VARS
-            stack = None if ml is not None else _planes_in_place(ds_m, dev, names)
+            # (time-first device datasets are planar where they lie -- also in front of the fused
+            #  multilooking, which only reads them)
+            fused_ml = ml is not None and os.environ.get('ND_AMD_ML_FUSED', '1') != '0'
+            stack = _planes_in_place(ds_m, dev, names) if (ml is None or fused_ml) else None
             if stack is None:
                 stack = _covariance_planes(ds_m, dev, names)
-            if ml is not None:      # spatial multilooking first; the looks multiply accordingly
-                stack, n = _multilook_planes(stack, int(ml)), ml * ml
-            if full_pol:
-                res = kernels.change_detection_c3(list(stack), alpha=alpha, n=int(n),
-                                                  dims=('time', 'y', 'x'), stats=stats)
-            else:
-                res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
-                                               n=int(n), dims=('time', 'y', 'x'), stats=stats)
+            if fused_ml and not full_pol:
+                # multilooking fused into the test: the planes are read once (nd/change.py:61-69)
+                res = kernels.change_detection_multilooked(stack[0], stack[1], stack[2], stack[3],
+                                                           alpha=alpha, ml=int(ml), stats=stats)
+            if res is None:
+                if ml is not None:  # spatial multilooking first; the looks multiply accordingly
+                    if not torch.is_tensor(stack):
+                        stack = _covariance_planes(ds_m, dev, names)
+                    stack, n = _multilook_planes(stack, int(ml)), ml * ml
+                if full_pol:
+                    res = kernels.change_detection_c3(list(stack), alpha=alpha, n=int(n),
+                                                      dims=('time', 'y', 'x'), stats=stats)
+                else:
+                    res = kernels.change_detection(stack[0], stack[1], stack[2], stack[3], alpha=alpha,
+                                                   n=int(n), dims=('time', 'y', 'x'), stats=stats)
     change = res[0] if stats else res
     change = change.view(torch.bool)            # 0 / 1 bytes: reinterpreted, not copied
     dims = ['y', 'x', 'time']

@@ -32,156 +32,9 @@
 // function has closed recurrences (chisq_pair in omnibus_common.hpp).
 #include <type_traits>
 
-#include "omnibus_common.hpp"
+#include "omnibus_c2_device.hpp"
 
 namespace nd_amd {
-
-// ---- the reference's running state (nd/_change.pyx:53-69) -------------------------------
-template <typename T>
-struct Accum {
-    T s11, s12r, s12i, s22;
-    double prod;
-    __device__ __forceinline__ void reset()
-    {
-        s11 = 0;
-        s12r = 0;
-        s12i = 0;
-        s22 = 0;
-        prod = 1.0;
-    }
-    __device__ __forceinline__ void step(T a, T b, T c, T d)
-    {
-        const T det = (a * d) - ((b * b) + (c * c));
-        prod = prod * (double)det;
-        s11 = s11 + a;
-        s12r = s12r + b;
-        s12i = s12i + c;
-        s22 = s22 + d;
-    }
-};
-
-// z = -2 rho ln Q over j matrices (nd/_change.pyx:72-76)
-template <typename T>
-__device__ __forceinline__ T z_stat(const Accum<T> &A, int j, double nlooks, const OmniTabEntry &e)
-{
-    const T det_of_sum = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
-    const double logQ =
-        nlooks * ((e.pklogk + log(A.prod)) - ((double)j * log((double)det_of_sum)));
-    return (T)(e.m2rho * logQ);
-}
-
-// Screen statistic: z from approx_ln.  |z_approx - z| <= |m2rho| n (k+1) 1e-7; the host widens
-// zlo_a / zhi_a by ten times that, so z_approx < zlo_a implies z < zlo (omni tables).
-template <typename T>
-__device__ __forceinline__ double z_approx(const Accum<T> &A, int j, double nlooks, double m2rho,
-                                           double pklogk)
-{
-    const T det_of_sum = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
-    const double logQ = nlooks * ((pklogk + approx_ln(A.prod)) -
-                                  ((double)j * approx_ln((double)det_of_sum)));
-    return m2rho * logQ;
-}
-template <typename T>
-__device__ __forceinline__ double z_approx(const Accum<T> &A, int j, double nlooks,
-                                           const OmniTabEntry &e)
-{
-    return z_approx<T>(A, j, nlooks, e.m2rho, e.pklogk);
-}
-
-// The input planes are read exactly once and the change map is written once: both bypass the
-// cache hierarchy's retention ("nt" = aux bit 1 on gfx950 buffer ops, __builtin_nontemporal_* on
-// plain accesses).  Measured on pass A: 1.30 -> 1.14 ms (profiles/r01_probe_bandwidth.txt).
-constexpr int kNtAux = 2;
-
-__device__ __forceinline__ void store_zero16_nt(uint4 *p)
-{
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const u4 z = {0u, 0u, 0u, 0u};
-    __builtin_nontemporal_store(z, reinterpret_cast<u4 *>(p));
-}
-
-// raw buffer load of one element: descriptor (SGPRs) + lane byte offset + scalar byte offset
-template <typename T>
-__device__ __forceinline__ T buffer_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff);
-template <>
-__device__ __forceinline__ float buffer_load<float>(__amdgpu_buffer_rsrc_t rsrc, unsigned voff,
-                                                    unsigned soff)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, kNtAux));
-}
-template <>
-__device__ __forceinline__ double buffer_load<double>(__amdgpu_buffer_rsrc_t rsrc, unsigned voff,
-                                                      unsigned soff)
-{
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, kNtAux));
-}
-
-template <typename T, int N>
-struct alignas(sizeof(T) * N) Pack {
-    T v[N];
-};
-
-// =========================================================================================
-// pass A
-// =========================================================================================
-template <typename T>
-struct OmniGlobalArgs {
-    const T *c11, *c12r, *c12i, *c22;
-    int64_t nx, nrows;        // pixels per row, rows (flattened to one row when planes are contiguous)
-    int64_t sy, sx, st;       // element strides
-    int64_t blocks_per_row;
-    int k;
-    int write_tab;            // block 0 copies `tab` into tab_dev
-    double nlooks, alpha;
-    OmniTabEntry e;           // constants of the test over all k matrices
-    uint8_t *change;
-    T *z_out, *p_out;
-    // The list of pixels whose global test can fire is kept in kShards independent segments
-    // (shard = block index mod kShards), each with its own counter on its own 128-byte line:
-    // one counter would serialise ~2e5 wave-level atomics per launch at ~88 per microsecond.
-    uint32_t *flag_count;     // [kShards] counters, kCounterStride words apart
-    uint32_t *flag_idx;       // [kShards][seg] pixel indices
-    uint32_t seg;             // list entries per shard
-    OmniTabEntry *tab_dev;
-    T *dump;                  // [kShards][dump_cap][date][4] series of the first dump_cap pixels of a shard
-    uint32_t dump_cap;
-    // Waves in which at least `dense_min` pixels are listed are not listed pixel by pixel: one
-    // entry (the pixel index of lane 0) goes to the dense list and omnibus_c2_dense_kernel searches
-    // all 64 pixels from registers.  Counter: word 1 of the shard's counter line.
-    uint32_t *dense_idx;      // [kShards][segd]
-    uint32_t segd;
-    int dense_min;            // 65 = never
-    // Data-driven choice between the sparse design (this pass + pass B) and the fused search, made
-    // on the device: omnibus_c2_sample_kernel counts the candidates among `gate_n` sampled pixels
-    // into *gate; both variants are launched and the one the count does not favour returns at
-    // once.  gate_mode 0: no gate; 1: run only if the sample is dense; 2: only if it is sparse.
-    const uint32_t *gate;
-    uint32_t gate_n;
-    int gate_mode;
-};
-
-// dense <=> at least 1/8 of the sampled pixels pass the global screen (measured break-even of
-// pass A + pass B against the fused kernel: ~10 % candidates)
-template <typename T>
-__device__ __forceinline__ bool omni_gate_skip(const OmniGlobalArgs<T> &g)
-{
-    if (g.gate_mode == 0) return false;
-    const uint32_t hits = __builtin_nontemporal_load(g.gate);
-    const bool dense = hits * 8u >= g.gate_n;
-    return (g.gate_mode == 1) != dense;
-}
-
-constexpr int kGlobalThreads = 256;
-#ifndef ND_RETAIN_THREADS
-#define ND_RETAIN_THREADS 256
-#endif
-constexpr int kRetainThreads = ND_RETAIN_THREADS;   // block size of the register-retaining pass A
-constexpr int kShards = 128;
-constexpr int kCounterStride = 32;   // uint32 words between shard counters (128 B)
-#ifndef ND_TIME_CHUNK
-#define ND_TIME_CHUNK 4
-#endif
-constexpr int kTimeChunk = ND_TIME_CHUNK;
 
 // STATS = false: the kernel only decides which pixels CAN fire (z >= zlo) and lists them; the
 //                chi-square evaluation of those happens in pass B.
@@ -725,17 +578,6 @@ omnibus_c2_retain_pm_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const 
 }
 
 
-__device__ __forceinline__ void zero_fill_span(uint8_t *ob, const int nb, const int lane)
-{
-    int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
-    if (head > nb) head = nb;
-    if (lane < head) ob[lane] = 0;
-    const int nvec = (nb - head) >> 4;
-    uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
-    for (int i = lane; i < nvec; i += 64) store_zero16_nt(vz + i);
-    const int tail0 = head + (nvec << 4);
-    if (tail0 + lane < nb) ob[tail0 + lane] = 0;
-}
 
 // -----------------------------------------------------------------------------------------
 // pass A for the reference's layout, LDS-DMA form.  One wave per 64 pixels: the wave's span of
@@ -749,8 +591,6 @@ __device__ __forceinline__ void zero_fill_span(uint8_t *ob, const int nb, const 
 // the rest.  (omnibus_c2_retain_pm_kernel: two dependent load -> LDS -> register rounds, 0.41 of
 // the HBM peak at k = 24; this form: see DESIGN.md.)
 // -----------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
-typedef __attribute__((address_space(1))) const unsigned char glb_u8_t;
 
 template <typename T>
 struct OmniPmDmaArgs {
@@ -790,11 +630,6 @@ __device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int 
     }
 }
 
-// (defined with the dense-wave searches below)
-template <typename T, int KMAX, int NJ, typename MT>
-__device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, const bool active,
-                                            const StreamScreen<NJ> &ss, const StreamEntry *tab_lds,
-                                            MT &mask_out, bool &handoff_out, bool &cand_out);
 
 // CHAIN: the search fused in (dense_chain on the registers the series was picked into), for
 // thresholds between the streaming search's and the sparse regime; `ss` is only read then.
@@ -1157,156 +992,6 @@ __device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k,
     handoff_out = handoff;
 }
 
-// -----------------------------------------------------------------------------------------
-// The same search in two passes over the registers, linear in k (round 3).
-//
-// dense_search above walks a triangle: one row per segment start, each row re-adding its dates.
-// But single_pixel_change_detection consumes every date ONCE: within a segment the marginal tests
-// j = 2, 3, ... extend one running sum date by date, and where one fires the next segment starts at
-// that very date (nd/_change.pyx:247-256).  The only thing that looks ahead is the global test of
-// ts[l:], asked at each segment start.  So:
-//   pass 1 (dates last to first, as in omnibus_c2_stream_kernel): the global test of EVERY start
-//           from suffix sums in double, with the rounding band of the reference's forward float
-//           sums; two bits per date (fires / cannot fire).
-//   pass 2 (dates first to last, date index wave-uniform, every lane busy at every date): each lane
-//           carries the reference's own running state of its CURRENT segment -- the four sums in
-//           `floating`, started as 0 + a_l, and the double product of the determinants -- adds date
-//           t, and decides the marginal test over its j = t - l + 1 dates (bit-identical
-//           determinants, tight band; the constants of the lane's own j come from an LDS table).
-//           Where it fires: change at t, and if the global test of ts[t:] (pass 1) fires too the
-//           state restarts as date t alone; if that test cannot fire the lane is finished; an
-//           undecided test of either kind hands the pixel to the exact pass.  At the last date the
-//           marginal test IS the global test of the segment, which fired.
-// ~105 vector instructions per date in all, whatever the threshold: no rows, no deep searches,
-// no divergence.
-// -----------------------------------------------------------------------------------------
-// MT: unsigned for KMAX <= 32, unsigned long long up to 64 dates
-template <typename T, int KMAX, int NJ, typename MT>
-__device__ __forceinline__ void dense_chain(const T (&v)[KMAX][4], const int k, const bool active,
-                                            const StreamScreen<NJ> &ss, const StreamEntry *tab_lds,
-                                            MT &mask_out, bool &handoff_out, bool &cand_out)
-{
-    static_assert(KMAX <= (int)(8 * sizeof(MT)) && KMAX <= NJ, "mask width");
-    // the instantiation serves kmin <= k <= KMAX (8, 16, 24, 32 dates; 48 takes 33 .. 48)
-    constexpr int kmin = KMAX == 8 ? 2 : (KMAX == 48 ? 33 : KMAX - 7);
-    const T dlo = (T)ss.dlo, dhi = (T)ss.dhi;
-    MT gF = 0, gC = 0;
-    bool bad = false, dead = false;
-    {
-        double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0, PP = 1.0;
-        int emin = 1, emax = 1;
-#pragma unroll
-        for (int t = KMAX - 1; t >= 0; --t) {
-            // branch-free: elements beyond k hold a copy of a valid date and are masked out
-            const bool live = (t < kmin) || (t < k);
-            const T a = v[t][0], b = v[t][1], c = v[t][2], d = v[t][3];
-            const T det = (a * d) - ((b * b) + (c * c));
-            bad = bad | (live & !((a > (T)0) & (det > dlo) & (det < dhi)));
-            dead = dead | (live & !((det > (T)0) | (det < (T)0)));
-            PP = PP * (live ? (double)det : 1.0);
-            S11 += live ? (double)a : 0.0;
-            S12r += live ? (double)b : 0.0;
-            S12i += live ? (double)c : 0.0;
-            S22 += live ? (double)d : 0.0;
-            const int jr = k - t;
-            const int jj = jr > 0 ? jr : 0;
-            const StreamEntry e = ss.e[jj];                  // wave-uniform: one scalar load
-            const double pp = S11 * S22;
-            const double dets = pp - ((S12r * S12r) + (S12i * S12i));
-            const float df = (float)dets;
-            bool okd;
-            int es, eP;
-            float ms, mP;
-            if (sizeof(T) == 4) {
-                okd = df > 7.888609052210118e-31f;
-                log2_parts(df, es, ms);
-            } else {
-                okd = (dets > 0.0) & (dets < (double)INFINITY);
-                log2_parts(dets, es, ms);
-            }
-            log2_parts(PP, eP, mP);
-            emin = eP < emin ? eP : emin;
-            emax = eP > emax ? eP : emax;
-            const int E = (eP - e.re) - __mul24(jj, es);
-            const float x = (float)E + __builtin_fmaf(-e.jf, ms, mP - e.rf);
-            const float qq = (float)pp * __builtin_amdgcn_rcpf(df);
-            const float rel = e.cj * qq;                     // 1.46 * 5 n u * s11 s22 / det
-            const float m2 = e.mj * rel;
-            bad = bad | (live & !(okd & (rel < 0.01f)));
-            mask_push(gF, x + m2 < e.a);
-            mask_push(gC, x - m2 > e.b);
-            __builtin_amdgcn_sched_barrier(0);               // one date at a time (registers)
-        }
-        bad = bad | (emax - emin > 900);
-    }
-    // KMAX pushes: the bit of date t sits at position t
-    MT gI = (MT) ~(gF | gC);
-    mask_keep_low(gF, k - 1);
-    mask_keep_low(gI, k - 1);
-    if (dead) {                                 // a NaN or zero determinant: no change anywhere, no exact pass
-        bad = false;
-        gF = 0;
-        gI = 0;
-    }
-    cand_out = active && (bad || ((gF | gI) & (MT)1));
-    bool handoff = active && (bad || (gI & (MT)1));
-    bool done = !active || bad || !(gF & (MT)1) || (gI & (MT)1);
-    MT mask = 0;
-    // the running state of the segment that starts at date 0 (0 + a_0 = a_0)
-    T s11 = v[0][0], s12r = v[0][1], s12i = v[0][2], s22 = v[0][3];
-    double PP = (double)((v[0][0] * v[0][3]) - ((v[0][1] * v[0][1]) + (v[0][2] * v[0][2])));
-    int j = 1;
-#pragma unroll
-    for (int t = 1; t < KMAX; ++t) {
-        const bool live = (t < kmin) || (t < k);
-        const bool last = (t == k - 1);
-        T a = v[t][0], b = v[t][1];
-        const T c = v[t][2], d = v[t][3];
-        // (opaque to the optimiser: it would otherwise keep the 24 determinants of pass 1, and their
-        // conversions to double, alive in 72 registers instead of recomputing them here; for the long
-        // series also b^2 + c^2, one register per date)
-        asm volatile("" : "+v"(a));
-        if (KMAX * sizeof(T) > 96) asm volatile("" : "+v"(b));
-        const T det = (a * d) - ((b * b) + (c * c));
-        s11 = s11 + a;
-        s12r = s12r + b;
-        s12i = s12i + c;
-        s22 = s22 + d;
-        PP = PP * (double)det;
-        j = j + 1;
-        const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-        const bool oks = (dets > (T)0) & (dets < (T)INFINITY);
-        const StreamEntry *ep = tab_lds + j;                 // the lane's own j
-        const int re = ep->re;
-        const float rf = ep->rf, ca = ep->a, cb = ep->b;
-        int es, eP;
-        float ms, mP;
-        log2_parts(dets, es, ms);
-        log2_parts(PP, eP, mP);
-        const int E = (eP - re) - __mul24(j, es);
-        const float x = (float)E + __builtin_fmaf(-(float)j, ms, mP - rf);
-        const bool fires = last | (oks & (x < ca));
-        const bool cant = !last & oks & (x > cb);
-        const bool act = !done & live;
-        const bool und = act & !(fires | cant);
-        const bool f = act & fires;
-        handoff = handoff | und;
-        mask |= f ? ((MT)1 << t) : (MT)0;                    // :252
-        // the segment that starts at t (:255): its global test was decided in pass 1
-        const bool gi = (gI >> t) & (MT)1, gf = (gF >> t) & (MT)1;
-        handoff = handoff | (f & !last & gi);
-        done = done | und | (f & (last | gi | !gf));         // :256, :241-242
-        s11 = f ? a : s11;
-        s12r = f ? b : s12r;
-        s12i = f ? c : s12i;
-        s22 = f ? d : s22;
-        PP = f ? (double)det : PP;
-        j = f ? 1 : j;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    mask_out = mask;
-    handoff_out = handoff;
-}
 
 // One lane's whole row of the change map from its mask: every byte is written.
 __device__ __forceinline__ void store_change_row(uint8_t *res, const int k, const unsigned long long mask)
@@ -1546,10 +1231,6 @@ omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Dens
 // form for thresholds at which marginal tests beyond three dates are common (everything between
 // the reference's default 0.01 and the sparse regime).  Same loads as omnibus_c2_retain_kernel.
 // -----------------------------------------------------------------------------------------
-// (series of up to 96 registers: three waves per SIMD; beyond -- 32 float32 / 16 float64 dates and
-// more -- two: under the cap of three the search spilled 150 - 230 bytes per lane)
-constexpr int chain_waves(const int kmax, const size_t elem) { return kmax * (int)elem <= 96 ? 3 : 2; }
-constexpr int chain_nj(const int kmax) { return kmax > 32 ? 64 : 32; }
 
 template <typename T, int KMAX, bool EXACT>
 __global__ void __launch_bounds__(kRetainThreads, chain_waves(KMAX, sizeof(T)))
@@ -3416,7 +3097,7 @@ std::vector<OmniTabEntry> get_table_impl(int k, uint32_t n_looks, double alpha, 
 // gathered from the planes by pass B instead: slower, never wrong).
 struct OmniWorkspace {
     size_t off_count, off_tab, off_idx, off_dense, off_hand, off_dump, min_total, recommended;
-    uint32_t segd, hand_words;
+    uint32_t seg, segd, hand_words;
 };
 
 constexpr int kRetainMaxF32 = 48, kRetainMaxF64 = 24;
@@ -3434,23 +3115,32 @@ static uint32_t omni_seg(int64_t npix, int64_t ny)
     return (uint32_t)(2 * nb256 + (2 * ny + 256) * 4 + 256);
 }
 
-static OmniWorkspace omni_layout(int64_t npix, int64_t ny, int64_t k, size_t elem)
+// seg_ml != 0: the multilooking pass A (omnibus_ml.hip) numbers its waves differently -- its own list
+// length per shard -- and the dump must hold EVERY listed pixel (the multilooked series exists
+// nowhere else: pass B cannot gather it from the planes), so the dump is part of the minimum.
+static OmniWorkspace omni_layout(int64_t npix, int64_t ny, int64_t k, size_t elem, uint32_t seg_ml = 0)
 {
     OmniWorkspace w;
+    const uint32_t seg = seg_ml ? seg_ml : omni_seg(npix, ny);
+    w.seg = seg;
     w.off_count = 0;
     w.off_tab = align256(kCounterBytes);
     w.off_idx = w.off_tab + align256((size_t)(k + 1) * sizeof(OmniTabEntry));
-    w.off_dense = w.off_idx + align256((size_t)omni_seg(npix, ny) * kShards * sizeof(uint32_t));
+    w.off_dense = w.off_idx + align256((size_t)seg * kShards * sizeof(uint32_t));
     // dense-wave list: at most one entry per 64 listed pixels of a shard
-    w.segd = omni_seg(npix, ny) / 64 + 8;
+    w.segd = seg / 64 + 8;
     w.off_hand = w.off_dense + align256((size_t)w.segd * kShards * sizeof(uint32_t));
     // hand-over marks of the register form of pass B: one bit per list entry (OmniSearchArgs::hand_bits)
-    w.hand_words = omni_seg(npix, ny) / 64 + 1;
+    w.hand_words = seg / 64 + 1;
     w.off_dump = w.off_hand + align256((size_t)w.hand_words * kShards * sizeof(unsigned long long));
     w.min_total = w.off_dump;
     const size_t per = (size_t)k * 4 * elem;
     size_t cap = ((size_t)npix / 8 / kShards + 63) & ~(size_t)63;   // per shard
     w.recommended = w.off_dump + align256(cap * kShards * per);
+    if (seg_ml) {
+        w.min_total = w.off_dump + align256((size_t)seg * kShards * per);
+        w.recommended = w.min_total;
+    }
     return w;
 }
 
@@ -3602,12 +3292,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                            int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int64_t st,
                            uint32_t n_looks, double alpha, uint8_t *change, void *z_out,
                            void *p_out, void *workspace, size_t workspace_bytes,
-                           hipStream_t stream, const int64_t *pm_ids = nullptr)
+                           hipStream_t stream, const int64_t *pm_ids = nullptr,
+                           const OmniMlPlan *mlp = nullptr)
 {
+    // mlp != null: OmnibusTest(ml=w) -- pass A multilooks on the fly (omnibus_ml.hip; float32 only)
     // pm_ids != null: pixel-major inputs, element (y, x, t) of variable v at
     // ptr_v[((y * nx + x) * k + t) * pm_ids[v]]; sy / sx / st then describe the unit-stride case
     const int64_t npix = ny * nx;
-    const OmniWorkspace w = omni_layout(npix, ny, k, sizeof(T));
+    const OmniWorkspace w = omni_layout(npix, ny, k, sizeof(T), mlp ? mlp->seg : 0);
     if (workspace == nullptr || workspace_bytes < w.min_total) {
         set_error("nd_amd_omnibus_c2: workspace of at least %zu bytes needed, %zu given",
                   w.min_total, workspace_bytes);
@@ -3666,7 +3358,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const char *e = getenv("ND_AMD_DENSE_MIN");
         return e ? atoi(e) : 16;
     }();
-    const bool dense_ok = k <= (sizeof(T) == 4 ? 32 : 16) && pm_ids == nullptr;
+    const bool dense_ok = k <= (sizeof(T) == 4 ? 32 : 16) && pm_ids == nullptr && mlp == nullptr;
     g.dense_min = dense_ok ? dense_env : 65;
     const bool stats = (z_out != nullptr) || (p_out != nullptr);
     const bool retain = k <= (sizeof(T) == 4 ? kRetainMaxF32 : kRetainMaxF64);
@@ -3692,8 +3384,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // Series beyond the register forms (33 .. 128 dates; float64: 17 .. 128): the streaming search with
     // 64- or 128-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
     // (k = 48 at alpha = 0.01: 118 ms per 16.7 Mpx).
-    const bool stream_long = !dense_ok && pm_ids == nullptr && k <= kDenseMax && dense_env <= 64 &&
-                             alpha < fused_alpha;
+    const bool stream_long = !dense_ok && pm_ids == nullptr && mlp == nullptr && k <= kDenseMax &&
+                             dense_env <= 64 && alpha < fused_alpha;
+    // multilooking pass A: the search fused in (dense_chain on the retained, multilooked series) at
+    // every threshold below the sparse regime -- by alpha alone: the density sample reads the planes
+    // as they are, not multilooked
+    const bool ml_chain = mlp != nullptr && k >= 2 && dense_env <= 64 && alpha < fused_alpha_regs;
     // z / P rasters asked for on top: they come from one launch of the plain pass A (which
     // evaluates the whole-series test of every pixel anyway), the map from the streaming search
     const bool stats_split = stream_long && stats;
@@ -3713,7 +3409,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // (the streaming searches of longer series write the few pixels they hand over as well: pass B
         // would otherwise gather 4 x k isolated values per pixel from planes megabytes apart)
         size_t cap = (retain || stream_long) ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
-        g.seg = omni_seg(npix, ny);
+        g.seg = w.seg;
         if (cap > g.seg) cap = g.seg;
         g.dump = reinterpret_cast<T *>(ws + w.off_dump);
         g.dump_cap = (uint32_t)cap;
@@ -3811,7 +3507,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 32>), gridd, blockd, 0, sq,
                                reinterpret_cast<const OmniDenseArgs<float> &>(d), ssd);
     };
-    const bool low_threshold = fused || stream_long || (pm_ids != nullptr && alpha < fused_alpha);
+    const bool low_threshold = fused || stream_long || ml_chain || (pm_ids != nullptr && alpha < fused_alpha);
     auto launch_search = [&](hipStream_t sq, const uint32_t *count, const uint32_t *idx, const T *dump,
                              uint32_t seg, uint32_t dump_cap, int64_t npix_listed,
                              unsigned long long *hand, uint32_t hand_words) -> int {
@@ -3944,7 +3640,32 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     };
 
     bool gated = false;
-    if (pm_ids != nullptr) {
+    if (mlp != nullptr) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (g.dump_cap < g.seg) {
+                set_error("nd_amd_omnibus_c2_ml: workspace too small for the dump of every listed pixel");
+                return ND_AMD_EWORKSPACE;
+            }
+            if (ml_chain) {
+                if (stats) {            // the rasters from a pass of their own, the map from the fused search
+                    KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+                    launch_ml_pass_a(g, tab, *mlp, nullptr, true, false, stream);
+                    g.z_out = nullptr;
+                    g.p_out = nullptr;
+                }
+                const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
+                const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
+                KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
+                launch_ml_pass_a(g, tab, *mlp, &ss0, false, true, stream);
+            } else {
+                KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+                launch_ml_pass_a(g, tab, *mlp, nullptr, stats, true, stream);
+            }
+        } else {
+            set_error("nd_amd_omnibus_c2_ml: float32 only");
+            return ND_AMD_EUNSUPPORTED;
+        }
+    } else if (pm_ids != nullptr) {
         if (!retain || !flat) {
             set_error("nd_amd_omnibus_c2_pixel_major: %lld dates exceed the register-retaining sizes",
                       (long long)k);
@@ -4306,6 +4027,46 @@ extern "C" int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void 
     return omnibus_c2_impl<double>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x,
                                    stride_t, n_looks, alpha, change, z_out, p_out, workspace,
                                    workspace_bytes, stream);
+}
+
+extern "C" size_t nd_amd_omnibus_c2_ml_workspace_bytes(int dtype, int64_t ny, int64_t nx, int64_t k, int ml)
+{
+    OmniMlPlan p;
+    if (ny <= 0 || nx <= 0 || k <= 0 || !omni_ml_plan(ny, nx, k, nx, 1, ny * nx, ml, dtype, &p)) return 0;
+    return omni_layout(ny * nx, ny, k, 4, p.seg).min_total;
+}
+
+extern "C" int nd_amd_omnibus_c2_ml(const void *c11, const void *c12re, const void *c12im, const void *c22,
+                                    int dtype, int64_t ny, int64_t nx, int64_t k, int64_t stride_y,
+                                    int64_t stride_x, int64_t stride_t, int ml, double alpha,
+                                    uint8_t *change, void *z_out, void *p_out, void *workspace,
+                                    size_t workspace_bytes, void *hip_stream)
+{
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_omnibus_c2_ml: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (ny < 0 || nx < 0 || k < 0 || ml < 1) {
+        set_error("nd_amd_omnibus_c2_ml: bad shape or window (%lld, %lld, %lld; ml = %d)", (long long)ny,
+                  (long long)nx, (long long)k, ml);
+        return ND_AMD_EINVAL;
+    }
+    if (ny == 0 || nx == 0 || k == 0) return ND_AMD_OK;
+    if (!c11 || !c12re || !c12im || !c22 || !change) {
+        set_error("nd_amd_omnibus_c2_ml: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    OmniMlPlan p;
+    if (ny * nx >= 0xffffffffLL ||
+        !omni_ml_plan(ny, nx, k, stride_y, stride_x, stride_t, ml, dtype, &p)) {
+        set_error("nd_amd_omnibus_c2_ml: fused multilooking covers float32, x-contiguous planes, ml = 3 or 5, "
+                  "2 <= k <= 24 (multilook with nd_amd_correlate and call nd_amd_omnibus_c2 otherwise)");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    return omnibus_c2_impl<float>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x, stride_t,
+                                  (uint32_t)(ml * ml), alpha, change, z_out, p_out, workspace,
+                                  workspace_bytes, stream, nullptr, &p);
 }
 
 extern "C" int nd_amd_omnibus_c2_pixel_major(const void *c11, const void *c12re, const void *c12im,

@@ -96,6 +96,41 @@ def change_detection(c11, c12re, c12im, c22, alpha, n=1, dims=('time', 'y', 'x')
     return change
 
 
+def change_detection_multilooked(c11, c12re, c12im, c22, alpha, ml, stats=False):
+    """OmnibusTest(ml=w) in one pass over four planar (time, y, x) device planes: boxcar multilooking
+    (scipy's arithmetic, 'reflect' border) fused into the test, n = ml ** 2 looks (nd/change.py:61-69).
+    Returns None where the fused kernel does not apply (the caller multilooks the stack and uses
+    change_detection); otherwise the uint8 map (y, x, time) [, z, P]."""
+    planes = (c11, c12re, c12im, c22)
+    if not all(torch.is_tensor(t) and t.is_cuda and t.dim() == 3 for t in planes):
+        return None
+    if c11.dtype != torch.float32 or int(ml) != ml:
+        return None
+    for t in planes:
+        if t.shape != c11.shape or t.stride() != c11.stride() or t.dtype != c11.dtype or t.device != c11.device:
+            return None
+    k, ny, nx = c11.shape
+    st, sy, sx = c11.stride()
+    dev = c11.device
+    L = _lib.lib()
+    nbytes = L.nd_amd_omnibus_c2_ml_workspace_bytes(_lib.F32, ny, nx, k, int(ml)) if ny * nx * k > 0 else 0
+    if nbytes == 0 or sx != 1:
+        return None
+    with torch.cuda.device(dev):
+        change = torch.empty((ny, nx, k), dtype=torch.uint8, device=dev)
+        z = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
+        P = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rc = L.nd_amd_omnibus_c2_ml(_ptr(c11), _ptr(c12re), _ptr(c12im), _ptr(c22), _lib.F32, ny, nx, k,
+                                    sy, sx, st, int(ml), float(alpha), _ptr(change), _ptr(z), _ptr(P),
+                                    _ptr(ws), nbytes, _stream_ptr(dev))
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        _lib.check(rc)
+        ws.record_stream(torch.cuda.current_stream(dev))
+    return (change, z, P) if stats else change
+
+
 def change_detection_pixel_major(c11, c12re, c12im, c22, alpha, n=1, stats=False):
     """change_detection for four device variables in the reference's own layout, (y, x, time) with
     time fastest; `c12re` / `c12im` may be the `.real` / `.imag` views of one complex tensor (read
