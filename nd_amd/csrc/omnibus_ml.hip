@@ -15,18 +15,26 @@
 // omnibus_c2_chain_kernel; the window sums need the neighbours, which live in other lanes and other
 // waves, so the planes pass through LDS:
 //
-//   * A block of 768 threads owns a strip of 12 rows and WALKS it along x in tiles of 64 columns.
-//     Wave w owns tile row w, lane j the pixel in column j of the tile.
+//   * A block of 768 threads owns a strip of 12 rows and WALKS a segment of it along x in tiles of
+//     64 columns.  Wave w owns tile row w, lane j the pixel in column j of the tile.
 //   * A tile is consumed in steps of 8 planes (2 dates x 4 variables).  The planes of a step are
-//     staged by LDS-DMA (buffer_load_dword ... lds: memory -> LDS, no registers): 12 + 2h rows of 64
-//     NEW columns each -- every transfer is one aligned, fully coalesced 256-byte row piece, and no
-//     column is ever fetched twice: the 2h columns a tile shares with its left neighbour are carried
-//     over inside LDS (a tile's outputs are the 64 columns that end h columns before its last new
-//     column).  Only the h rows above and below a strip are fetched by two blocks.
+//     staged by LDS-DMA (memory -> LDS, no registers): 12 + 2h rows of the 64 NEW columns of the tile,
+//     as `buffer_load_dwordx4 ... lds` -- one instruction moves 4 rows x 256 bytes, each piece
+//     aligned and whole (32 instructions per step for the whole block; the first form moved one row
+//     per `buffer_load_dword ... lds`: 112 instructions per step at ~29 cycles each through the
+//     texture addresser -- half of the step's time, measured with s_memtime stamps).  No column is
+//     fetched twice: the 2h columns a tile shares with its left neighbour are carried over in LDS
+//     (a tile's outputs are the 64 columns that end h columns before its last new column).  Only the
+//     h rows above and below a strip are fetched by two blocks.  Tiles that reach over the right
+//     edge of the raster take a per-element form with the border rule applied per lane.
 //   * Three staging slots: while step S is computed the transfers of S + 1 and S + 2 are in flight.
+//     The transfers are issued from inline assembly and waited for by count: the compiler's
+//     wait-count pass would otherwise put `s_waitcnt vmcnt(0)` in front of every LDS read that
+//     follows a transfer (it cannot prove dynamic LDS disjoint), i.e. wait for the planes of two
+//     steps ahead before the current step's first read.
 //   * Compute role: a thread forms the window sums of a patch of 4 columns x 2 rows of ONE plane,
-//     walking the patch's 2 + 2h input rows once (two 16-byte LDS reads per row, bank-conflict free
-//     by construction of the lane -> (plane, patch) map); every element is converted to double and
+//     walking the patch's 2 + 2h input rows once (16-byte LDS reads, bank-conflict free by
+//     construction of the lane -> (plane, patch) map); every element is converted to double and
 //     multiplied by 1 / w^2 once per patch, every output receives its w^2 terms in scipy's order.
 //     The 8 results (float) go to a result area in LDS; after a barrier every thread picks up the 8
 //     values of ITS pixel: v[2 s + ...][0..3].
@@ -34,8 +42,8 @@
 //     forms: fold + screen + list + dump + zero-fill (sparse regime) or dense_chain (fused search).
 //
 // Traffic: 4 k planes x (12 + 2h) / 12 rows, nothing else.  Work: w^2 dependent double additions per
-// value (scipy's order leaves no sharing between neighbouring windows) -- the kernel is bound by
-// vector issue, not by memory, from 5 x 5 on.
+// value (scipy's order leaves no sharing between neighbouring windows) -- vector issue, not memory,
+// is what bounds the kernel.
 #include "omnibus_c2_device.hpp"
 
 namespace nd_amd {
@@ -46,30 +54,49 @@ template <int K>
 struct MlGeom {
     static constexpr int HALO = K / 2;
     static constexpr int W = 64, HT = kMlTileRows, NT = 64 * HT, NWAVE = HT, G = 8;
-    static constexpr int ROWS = HT + 2 * HALO;
-    static constexpr int NRD = (4 + 2 * HALO + 3) / 4;            // 16-byte reads per staged row and patch
-    static constexpr int PITCH = 60 + 4 * NRD;                    // floats per staged row
-    static constexpr int PSZ = (ROWS * PITCH + 63) / 64 * 64;     // floats per staged plane (64-dword multiple)
+    static constexpr int ROWS = HT + 2 * HALO;                    // staged rows of a plane
+    static constexpr int PROWS = 16;                              // rows of a plane's LDS image (4 per transfer)
+    static constexpr int PSZ = PROWS * 64;                        // floats per staged plane, pitch 64
     static constexpr int SLOT = G * PSZ;
     static constexpr int RES = G * NT;
     static constexpr int NCAR = G * ROWS * 2 * HALO;              // carried elements per step
-    static constexpr int NSLOT = 3;
+    static constexpr int NSLOT = K == 3 ? 3 : 2;                  // NSLOT - 1 steps of transfers in flight (LDS budget)
+    static_assert(ROWS <= PROWS, "window too tall for the plane image");
 };
 
 struct OmniMlArgs {
     int64_t ny, nx;           // raster
-    int segw;                 // output columns per segment (multiple of 64)
+    int segw;                 // columns per segment (multiple of 64)
     int xsegs;                // segments per strip
-    int tmax;                 // upper bound of the tiles of a segment (segw / 64 + 1): numbering of the waves
+    int tmax;                 // tile numbers per strip: ceil(nx / 64) + 2
+    int x4;                   // rows and planes 16-byte aligned: 16-byte transfers allowed
     double wt;                // 1 / ml^2 (nd/filters.py:297)
     int list;                 // 0: no candidate list (z / P rasters only)
+    unsigned long long *trace;   // ND_ML_TRACE builds: time stamps of one block (tools/exp_ml_trace.py)
+    int trace_block;
 };
 
-// all LDS writes of this wave done, then the workgroup barrier (no wait for the LDS-DMA transfers in
-// flight: those are waited for explicitly, by count)
+// all LDS operations of this wave done, then the workgroup barrier (no wait for the LDS-DMA transfers
+// in flight: those are waited for explicitly, by count)
 __device__ __forceinline__ void ml_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// wait until at most n of this wave's transfers are outstanding (n wave-uniform: what one step of
+// four 16-byte or sixteen 4-byte transfers can leave)
+__device__ __forceinline__ void ml_wait_vm(const int n)
+{
+#ifdef ND_ML_WAIT0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+#endif
+    if (n >= 16)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 4)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __device__ __forceinline__ int ml_reflect(int cc, const int len)     // scipy 'reflect': d c b a | a b c d | d c b a
@@ -85,22 +112,63 @@ __device__ __forceinline__ int ml_reflect(int cc, const int len)     // scipy 'r
     return cc;
 }
 
-// LDS-DMA issued from inline assembly: 64 x 4 bytes, memory -> LDS at `lds_addr` + 4 * lane.  The
-// compiler's wait-count pass does not see these transfers, which is the point: it would otherwise
-// put `s_waitcnt vmcnt(0)` in front of EVERY LDS read that follows a transfer it cannot prove
-// disjoint (it cannot, for dynamic LDS) -- i.e. wait for the planes of two steps ahead before the
-// current step's first read.  The kernel waits for its transfers itself, by count.  (Wait counts
-// the compiler emits for its own loads stay safe: transfers it does not know about only make
-// `vmcnt(n)` wait for more than it had to.)
+// LDS-DMA from inline assembly (see the header): memory -> LDS at `lds_addr` + (4 | 16) * lane.
+// (Wait counts the compiler emits for its own loads stay safe: transfers it does not know about only
+// make `vmcnt(n)` wait for more than it had to.  One wait state between a write of M0 and the
+// transfer that reads it: the s_nop.  M0 is reserved: the compiler keeps nothing in it on gfx9.)
 typedef int ml_v4i __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ void ml_dma_row(const ml_v4i rsrc, const unsigned lds_base, const int voff, const int soff)
+// A wave's transfers of one step, issued as ONE block of assembly: M0 (the LDS byte address the
+// transfers are relative to), then four transfers that reach the rows of the wave's plane image
+// through the instruction's 12-bit offset.
+//  * M0 once per step: a write of M0 in front of EVERY transfer made the transfers of a wave run one
+//    at a time (~200 - 500 cycles each, s_memtime stamps; 3 300 of a step's 6 600 cycles).
+//  * The immediate offset moves the memory address as well as the LDS address
+//    (tools/probe_ldsdma.hip): the descriptor starts 4096 bytes early and every scalar offset carries
+//    4096 minus the immediate.
+//  * One block, operands in registers of their own, five wait states in front: what the compiler's
+//    hazard recogniser guarantees for its own VMEM instructions -- no VALU write (v_readlane restoring
+//    a spilled SGPR, v_readfirstlane) of a scalar operand within five wait states, no reuse of an
+//    address register between two transfers -- it cannot guarantee for inline assembly, which it does
+//    not look into.  (Found the hard way: with one statement per transfer, results changed with
+//    register allocation.)
+#ifdef ND_ML_NT
+#define ND_ML_POL " nt"
+#else
+#define ND_ML_POL ""
+#endif
+__device__ __forceinline__ void ml_dma16x4(const ml_v4i rsrc, const unsigned m0, const int a0, const int a1,
+                                           const int a2, const int a3, const int so)
 {
-    // (one wait state between a write of M0 and the LDS-DMA that reads it: the s_nop)
-    asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+    const int o0 = __builtin_amdgcn_readfirstlane(so + 4096), o1 = __builtin_amdgcn_readfirstlane(so + 3072),
+              o2 = __builtin_amdgcn_readfirstlane(so + 2048), o3 = __builtin_amdgcn_readfirstlane(so + 1024);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %1, %5, %6 offen offset:0" ND_ML_POL " lds\n\t"
+                 "buffer_load_dwordx4 %2, %5, %7 offen offset:1024" ND_ML_POL " lds\n\t"
+                 "buffer_load_dwordx4 %3, %5, %8 offen offset:2048" ND_ML_POL " lds\n\t"
+                 "buffer_load_dwordx4 %4, %5, %9 offen offset:3072" ND_ML_POL " lds"
                  :
-                 : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF)
-                 : "memory", "scc");   // (M0 is reserved: the compiler keeps nothing in it on gfx9)
+                 : "s"(__builtin_amdgcn_readfirstlane((int)m0)), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(rsrc),
+                   "s"(o0), "s"(o1), "s"(o2), "s"(o3)
+                 : "memory");
+}
+// four rows of the per-element form: rows R .. R + 3 of the plane image, one address register
+template <int R>
+__device__ __forceinline__ void ml_dma4x4(const ml_v4i rsrc, const unsigned m0, const int voff, const int s0,
+                                          const int s1, const int s2, const int s3)
+{
+    const int o0 = __builtin_amdgcn_readfirstlane(s0 + 4096 - 256 * R),
+              o1 = __builtin_amdgcn_readfirstlane(s1 + 4096 - 256 * (R + 1)),
+              o2 = __builtin_amdgcn_readfirstlane(s2 + 4096 - 256 * (R + 2)),
+              o3 = __builtin_amdgcn_readfirstlane(s3 + 4096 - 256 * (R + 3));
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "buffer_load_dword %1, %2, %3 offen offset:%7" ND_ML_POL " lds\n\t"
+                 "buffer_load_dword %1, %2, %4 offen offset:%8" ND_ML_POL " lds\n\t"
+                 "buffer_load_dword %1, %2, %5 offen offset:%9" ND_ML_POL " lds\n\t"
+                 "buffer_load_dword %1, %2, %6 offen offset:%10" ND_ML_POL " lds"
+                 :
+                 : "s"(__builtin_amdgcn_readfirstlane((int)m0)), "v"(voff), "s"(rsrc), "s"(o0), "s"(o1), "s"(o2),
+                   "s"(o3), "n"(256 * R), "n"(256 * (R + 1)), "n"(256 * (R + 2)), "n"(256 * (R + 3))
+                 : "memory");
 }
 __device__ __forceinline__ ml_v4i ml_make_rsrc(const float *p)
 {
@@ -149,12 +217,12 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                      const StreamScreen<32> ss)
 {
     typedef MlGeom<K> M;
-    constexpr int HALO = M::HALO, ROWS = M::ROWS, PITCH = M::PITCH, PSZ = M::PSZ, NT = M::NT;
+    constexpr int HALO = M::HALO, ROWS = M::ROWS, PSZ = M::PSZ, NT = M::NT;
     constexpr int NSTEP = KMAX / 2;                 // steps per tile (2 dates x 4 variables each)
     extern __shared__ __align__(16) unsigned char nd_smem_ml[];
-    float *slots = reinterpret_cast<float *>(nd_smem_ml);                 // [3][SLOT]
-    float *res = slots + M::NSLOT * M::SLOT;                              // [wave][8][64]
-    float *carry = res + M::RES;                                          // [NSTEP][NCAR]
+    float *res = reinterpret_cast<float *>(nd_smem_ml);                   // [2][wave][8][64]
+    float *slots = res + 2 * M::RES;                                          // [3][8][16][64]
+    float *carry = slots + M::NSLOT * M::SLOT;                            // [NSTEP][8][ROWS][2h]
     StreamEntry *tab_lds = reinterpret_cast<StreamEntry *>(carry + NSTEP * M::NCAR);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -164,9 +232,15 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     const int64_t b = blockIdx.x;
     const int strip = (int)(b / ml.xsegs), xseg = (int)(b - (int64_t)strip * ml.xsegs);
     const int y0 = strip * M::HT;
+    // The block loads the columns [Xs, Xs + 64 ntiles) and owns the OUTPUT columns [Xs - h, Xe - h):
+    // every tile's outputs end h columns before its last new column, so a segment needs no tile
+    // beyond its own columns -- only the last segment of a strip, which owns the columns up to the
+    // right edge, runs one tile further.
+    const bool last_seg = xseg + 1 == ml.xsegs;
     const int Xs = xseg * ml.segw;
-    const int Xe = (Xs + ml.segw < nx) ? Xs + ml.segw : nx;      // outputs of this block: columns [Xs, Xe)
-    const int ntiles = (Xe - Xs + HALO + 63) / 64;
+    const int out_lo = xseg == 0 ? 0 : Xs - HALO;
+    const int out_hi = last_seg ? nx : Xs + ml.segw - HALO;
+    const int ntiles = last_seg ? (nx - Xs + HALO + 63) / 64 : ml.segw / 64;
     const int nstep_k = (k + 1) >> 1;               // steps that hold dates of the series
 
     if (CHAIN && tid <= 32) tab_lds[tid] = ss.e[tid];
@@ -174,47 +248,51 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
         for (int j = tid; j <= k; j += NT) g.tab_dev[j] = tab.e[j];
     }
 
-    // ---- staging: wave `wave` moves rows wave and wave + 12 (if staged) of every plane of a step ----
+    // ---- staging ----
     const float *vp[4] = {g.c11, g.c12r, g.c12i, g.c22};
-    ml_v4i rs[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) rs[v] = ml_make_rsrc(vp[v]);
     const unsigned lds0 = (unsigned)(uintptr_t)(ml_lds_f32 *)slots;       // LDS byte address of the slots
-    const bool two_rows = wave + M::NWAVE < ROWS;                // wave-uniform
-    const int roffA = __builtin_amdgcn_readfirstlane(ml_reflect(y0 - HALO + wave, ny) * (int)g.sy * 4);
-    const int roffB = __builtin_amdgcn_readfirstlane(
-        ml_reflect(y0 - HALO + (two_rows ? wave + M::NWAVE : wave), ny) * (int)g.sy * 4);
     const int sstep = (int)g.st * 4;                             // bytes between dates (host: k * st * 4 < 2^31)
-
-    auto stage = [&](const int s, const int Xi, const int slot) {
-        // planes 8 s .. 8 s + 7 = dates 2 s, 2 s + 1 (a date beyond the series repeats the last one)
-        const int xm = ml_reflect(Xi + lane, nx);
-        const int voff = xm * 4;
-        const int t0 = 2 * s < k ? 2 * s : k - 1, t1 = 2 * s + 1 < k ? 2 * s + 1 : k - 1;
-        const int so0 = t0 * sstep, so1 = t1 * sstep;
-        const unsigned sb = lds0 + 4u * (unsigned)(slot * M::SLOT + wave * PITCH + 2 * HALO);
+    // Waves 0 .. 7 stage: wave w the plane w of the step (variable w & 3, date w >> 2), whose LDS image
+    // (16 rows x 256 bytes) is within reach of the transfers' 12-bit offset from one value of M0.
+    // (a) 16-byte form: four transfers of 4 rows x 64 columns; lane -> row 4 q + (lane >> 4), columns
+    //     4 (lane & 15) .. + 3 of the tile.
+    // (b) 4-byte form (tiles over the right edge, unaligned planes): one transfer per row, the border
+    //     rule applied per lane.
+    const bool stager = wave < 8;
+    const int myvar = wave & 3, mydate = (wave >> 2) & 1;
+    // (the transfers' immediate offset moves the memory address as well as the LDS address: the
+    //  descriptor starts 4096 bytes early and every scalar offset carries 4096 minus the immediate)
+    const float *myp = myvar == 0 ? g.c11 : (myvar == 1 ? g.c12r : (myvar == 2 ? g.c12i : g.c22));
+    const ml_v4i myrs = ml_make_rsrc(myp - 1024);
+    int rowoff[4];
 #pragma unroll
-        for (int pl = 0; pl < 8; ++pl) {
-            if (pl == 0) ml_dma_row<0 * 4 * PSZ>(rs[0], sb, voff, so0 + roffA);
-            if (pl == 1) ml_dma_row<1 * 4 * PSZ>(rs[1], sb, voff, so0 + roffA);
-            if (pl == 2) ml_dma_row<2 * 4 * PSZ>(rs[2], sb, voff, so0 + roffA);
-            if (pl == 3) ml_dma_row<3 * 4 * PSZ>(rs[3], sb, voff, so0 + roffA);
-            if (pl == 4) ml_dma_row<4 * 4 * PSZ>(rs[0], sb, voff, so1 + roffA);
-            if (pl == 5) ml_dma_row<5 * 4 * PSZ>(rs[1], sb, voff, so1 + roffA);
-            if (pl == 6) ml_dma_row<6 * 4 * PSZ>(rs[2], sb, voff, so1 + roffA);
-            if (pl == 7) ml_dma_row<7 * 4 * PSZ>(rs[3], sb, voff, so1 + roffA);
+    for (int q = 0; q < 4; ++q) {
+        int r = 4 * q + (lane >> 4);
+        r = r < ROWS ? r : ROWS - 1;                             // (rows of the image beyond the staged ones)
+        rowoff[q] = ml_reflect(y0 - HALO + r, ny) * (int)g.sy * 4 + (lane & 15) * 16;
+    }
+
+    // returns the number of transfers this wave issued
+    auto stage = [&](const int s, const int Xi, const int slot) -> int {
+        if (!stager) return 0;
+        // planes 8 s .. 8 s + 7 = dates 2 s, 2 s + 1 (a date beyond the series repeats the last one)
+        int t = 2 * s + mydate;
+        t = t < k ? t : k - 1;
+        const int so = t * sstep;
+        const unsigned m0b = lds0 + 4u * (unsigned)(slot * M::SLOT + wave * PSZ);
+        if (ml.x4 && Xi + 64 <= nx) {
+            const int xb = Xi * 4;
+            ml_dma16x4(myrs, m0b, rowoff[0] + xb, rowoff[1] + xb, rowoff[2] + xb, rowoff[3] + xb, so);
+            return 4;
         }
-        if (two_rows) {
-            const unsigned sb2 = sb + 4u * (unsigned)(M::NWAVE * PITCH);
-            ml_dma_row<0 * 4 * PSZ>(rs[0], sb2, voff, so0 + roffB);
-            ml_dma_row<1 * 4 * PSZ>(rs[1], sb2, voff, so0 + roffB);
-            ml_dma_row<2 * 4 * PSZ>(rs[2], sb2, voff, so0 + roffB);
-            ml_dma_row<3 * 4 * PSZ>(rs[3], sb2, voff, so0 + roffB);
-            ml_dma_row<4 * 4 * PSZ>(rs[0], sb2, voff, so1 + roffB);
-            ml_dma_row<5 * 4 * PSZ>(rs[1], sb2, voff, so1 + roffB);
-            ml_dma_row<6 * 4 * PSZ>(rs[2], sb2, voff, so1 + roffB);
-            ml_dma_row<7 * 4 * PSZ>(rs[3], sb2, voff, so1 + roffB);
-        }
+        // (rare: the row offsets are worked out here, not kept in registers across the walk)
+        const int voff = ml_reflect(Xi + lane, nx) * 4;
+        auto ro = [&](const int r) { return so + ml_reflect(y0 - HALO + (r < ROWS ? r : ROWS - 1), ny) * (int)g.sy * 4; };
+        ml_dma4x4<0>(myrs, m0b, voff, ro(0), ro(1), ro(2), ro(3));
+        ml_dma4x4<4>(myrs, m0b, voff, ro(4), ro(5), ro(6), ro(7));
+        ml_dma4x4<8>(myrs, m0b, voff, ro(8), ro(9), ro(10), ro(11));
+        ml_dma4x4<12>(myrs, m0b, voff, ro(12), ro(13), ro(14), ro(15));
+        return 16;
     };
 
     // ---- prologue: the carried columns of the segment's first tile, straight from memory ----
@@ -231,87 +309,127 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
             carry[e] = vp[q & 3][(int64_t)t * g.st + (int64_t)ym * g.sy + xm];
         }
     }
-    stage(0, Xs, 0);
-    if (nstep_k > 1 || ntiles > 1) stage(nstep_k > 1 ? 1 : 0, nstep_k > 1 ? Xs : Xs + 64, 1);
-    __syncthreads();
-    // carry-in of the very first step
-    if (tid < M::NCAR) {
-        const int c = tid % (2 * HALO), r = (tid / (2 * HALO)) % ROWS, pl = tid / (2 * HALO * ROWS);
-        slots[pl * PSZ + r * PITCH + c] = carry[tid];
+    const int total_steps = ntiles * nstep_k;
+    constexpr int PF = M::NSLOT - 1;                             // steps of transfers in flight
+    {
+        int sp = 0, Xp = Xs, c1 = 0;
+        for (int j = 0; j < PF; ++j) {
+            if (j < total_steps) {
+                const int c = stage(sp, Xp, j);
+                if (j == 1) c1 = c;
+            }
+            if (++sp == nstep_k) {
+                sp = 0;
+                Xp += 64;
+            }
+        }
+        ml_wait_vm(c1);                                          // step 0 has landed (this wave's part)
     }
+    __syncthreads();
 
-    // compute role
+    // compute role: waves 0 .. 5 the patch rows of planes 0 .. 3, waves 6 .. 11 of planes 4 .. 7
     const int py = wave % (M::HT / 2), quad = wave / (M::HT / 2);
     const int cpl = quad * 4 + (lane >> 4), cpx = lane & 15;
-    const int rd_off = cpl * PSZ + (2 * py) * PITCH + 4 * cpx;                          // floats into a slot
-    const int wr_off = (2 * py) * (8 * 64) + cpl * 64 + 4 * cpx;                        // floats into res
+    // the patch's window columns are the tile's new columns 4 px - 2h .. 4 px + 3: for px = 0 the
+    // first 2h of them are the carried ones (read from the carry buffer, rows 2h floats apart)
+    const int rd_main = cpl * PSZ + (2 * py) * 64 + 4 * cpx;                         // floats into a slot
+    const int rd_c = (cpl * ROWS + 2 * py) * 2 * HALO;                               // floats into a step's carry
+    const int wr_off = (2 * py) * (8 * 64) + cpl * 64 + 4 * cpx;                     // floats into a result buffer
+    // carried columns: the wave that stages plane w also saves its last 2h new columns (lane e < ROWS 2h)
+    const int co_rd = wave * PSZ + (lane / (2 * HALO)) * 64 + 64 - 2 * HALO + lane % (2 * HALO);
+    const int co_wr = wave * ROWS * 2 * HALO + lane;
+    const bool co_lane = stager && lane < ROWS * 2 * HALO;
     const double wt = ml.wt;
 
-    const int total_steps = ntiles * nstep_k;
-    int S = 0;                       // global step counter of the block
+    int S = 0;                       // step counter of the block
     int slot_i = 0;                  // slot of step S
+    int s_prev = 0;                  // plane group of step S - 1
     float v[KMAX][4];
 
+#ifdef ND_ML_TRACE
+#define ML_STAMP(j)                                                                                  \
+    do {                                                                                             \
+        if (ml.trace && b == ml.trace_block && lane == 0 && S < 128)                                  \
+            ml.trace[((size_t)wave * 128 + S) * 12 + (j)] = __builtin_amdgcn_s_memtime();            \
+    } while (0)
+#else
+#define ML_STAMP(j)
+#endif
+    // One barrier per step.  Behind the barrier that opens step S everything of step S - 1 is visible:
+    // its window sums (result buffer (S - 1) & 1), and every patch has read its planes.  Step S then
+    //   A. saves the carried columns of step S - 1's planes and sends the transfers of step S + PF into
+    //      that slot (the wave that stages a plane is the one that saves its columns: no other order
+    //      is needed), and asks for its pixels' 8 values of step S - 1 (the loads land in the retained
+    //      registers while the sums of step S are being formed);
+    //   B. forms the window sums of step S into result buffer S & 1;
+    //   C. waits for its transfers of step S + 1 and meets the others at the barrier.
+    // The last step of a tile picks its values up behind that barrier and runs the tile's tail.
     for (int i = 0; i < ntiles; ++i) {
         const int Xi = Xs + 64 * i;
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             if (s < nstep_k) {
                 float *cur = slots + slot_i * M::SLOT;
-                const int slot_n = slot_i + 1 == M::NSLOT ? 0 : slot_i + 1;
-                const int slot_nn = slot_n + 1 == M::NSLOT ? 0 : slot_n + 1;
-                // ---- the transfers of this step have landed (this wave's), then everybody's ----
-                if (S + 1 < total_steps) {
-                    if (two_rows)
-                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    else
-                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int slot_p = slot_i == 0 ? M::NSLOT - 1 : slot_i - 1;      // slot of step S - 1 = of S + PF
+                ML_STAMP(0);
+                // ---- A ----
+                float cv = 0.f;
+                if (S > 0 && co_lane) cv = slots[slot_p * M::SLOT + co_rd];
+                if (s > 0) {
+                    const float *R = res + ((S - 1) & 1) * M::RES + wave * (8 * 64) + lane;
+#pragma unroll
+                    for (int pl = 0; pl < 8; ++pl) v[2 * (s - 1) + (pl >> 2)][pl & 3] = R[pl * 64];
                 }
-                ml_barrier();
-                // ---- two steps ahead ----
-                if (S + 2 < total_steps) {
-                    int s2 = s + 2, X2 = Xi;
+                if (S > 0 && co_lane) carry[s_prev * M::NCAR + co_wr] = cv;
+                int cnt_new = 0;
+#ifndef ND_ML_NO_DMA
+                if (S + PF < total_steps) {
+                    int s2 = s + PF, X2 = Xi;
                     while (s2 >= nstep_k) {
                         s2 -= nstep_k;
                         X2 += 64;
                     }
-                    stage(s2, X2, slot_nn);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the columns above are in registers
+                    cnt_new = stage(s2, X2, slot_p);
                 }
-                // ---- carried columns: this step's last 2h new columns for the next tile, and the
-                //      next step's first 2h columns from what the previous tile left ----
-                if (tid < M::NCAR) {
-                    const int c = tid % (2 * HALO), r = (tid / (2 * HALO)) % ROWS, pl = tid / (2 * HALO * ROWS);
-                    const int sn = s + 1 < nstep_k ? s + 1 : 0;
-                    const float out_this = cur[pl * PSZ + r * PITCH + 64 + c];
-                    // (a one-step tile: the next step is the next tile's, its carry is this step's)
-                    const float in_next = sn == s ? out_this : carry[sn * M::NCAR + tid];
-                    // (the next step of the LAST plane group belongs to the next tile: its carry is
-                    //  what this tile's step 0 stored -- written a whole tile ago)
-                    if (S + 1 < total_steps) slots[slot_n * M::SLOT + pl * PSZ + r * PITCH + c] = in_next;
-                    carry[s * M::NCAR + tid] = out_this;
-                }
-                // ---- window sums of this thread's patch ----
+#endif
+                // (a series of one step per tile: the columns saved above are the ones this very step
+                //  reads -- the only case in which A and B of one step touch the same carry entries)
+                if (nstep_k == 1) ml_barrier();
+                ML_STAMP(1);
+                // ---- B: window sums of this thread's patch ----
+#ifdef ND_ML_NO_COMPUTE
+                if (g.k < 0)
+#endif
                 {
                     double acc[2][4];
 #pragma unroll
                     for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
                         for (int ii = 0; ii < 4; ++ii) acc[oy][ii] = 0.0;
-                    const float *P = cur + rd_off;
+                    const float *P = cur + rd_main;
+                    // first piece of a row: the 2h columns in front of the patch's own four
+                    const float *F = cpx ? P - 2 * HALO : carry + s * M::NCAR + rd_c;
+                    const int fstride = cpx ? 64 : 2 * HALO;
 #pragma unroll
                     for (int r = 0; r < 2 + 2 * HALO; ++r) {
-                        float wv[4 * M::NRD];
-                        const float4 *rp = reinterpret_cast<const float4 *>(P + r * PITCH);
-#pragma unroll
-                        for (int cc = 0; cc < M::NRD; ++cc) {
-                            const float4 q = rp[cc];
-                            wv[4 * cc + 0] = q.x;
-                            wv[4 * cc + 1] = q.y;
-                            wv[4 * cc + 2] = q.z;
-                            wv[4 * cc + 3] = q.w;
+                        float wv[4 + 2 * HALO];
+                        if (HALO == 1) {
+                            const float2 f = *reinterpret_cast<const float2 *>(F + r * fstride);
+                            wv[0] = f.x;
+                            wv[1] = f.y;
+                        } else {
+                            const float4 f = *reinterpret_cast<const float4 *>(F + r * fstride);
+                            wv[0] = f.x;
+                            wv[1] = f.y;
+                            wv[2] = f.z;
+                            wv[3] = f.w;
                         }
+                        const float4 q = *reinterpret_cast<const float4 *>(P + r * 64);
+                        wv[2 * HALO + 0] = q.x;
+                        wv[2 * HALO + 1] = q.y;
+                        wv[2 * HALO + 2] = q.z;
+                        wv[2 * HALO + 3] = q.w;
                         double d[4 + 2 * HALO];
 #pragma unroll
                         for (int cc = 0; cc < 4 + 2 * HALO; ++cc) d[cc] = wt * (double)wv[cc];
@@ -326,25 +444,32 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                             }
                         }
                     }
+                    float *W = res + (S & 1) * M::RES + wr_off;
 #pragma unroll
                     for (int oy = 0; oy < 2; ++oy) {
                         const float4 o = make_float4((float)acc[oy][0], (float)acc[oy][1], (float)acc[oy][2],
                                                      (float)acc[oy][3]);
-                        *reinterpret_cast<float4 *>(res + wr_off + oy * (8 * 64)) = o;
+                        *reinterpret_cast<float4 *>(W + oy * (8 * 64)) = o;
                     }
                 }
+                ML_STAMP(2);
+                // ---- C: the transfers of the next step have landed (this wave's), then everybody's ----
+                ml_wait_vm(PF >= 2 ? cnt_new : 0);
+                ML_STAMP(3);
                 ml_barrier();
-                // ---- this thread's pixel: its 8 values of the step ----
-                {
-                    const float *R = res + wave * (8 * 64) + lane;
+                ML_STAMP(4);
+                if (s == nstep_k - 1) {
+                    // the tile's last step: its values now (the tail below needs the whole series)
+                    const float *R = res + (S & 1) * M::RES + wave * (8 * 64) + lane;
 #pragma unroll
                     for (int pl = 0; pl < 8; ++pl) {
                         const int t = 2 * s + (pl >> 2);
                         if (t < KMAX) v[t][pl & 3] = R[pl * 64];
                     }
                 }
+                s_prev = s;
                 S += 1;
-                slot_i = slot_n;
+                slot_i = slot_i + 1 == M::NSLOT ? 0 : slot_i + 1;
             } else {
                 // dates beyond the series: a copy of a valid date (dense_chain masks them out)
 #pragma unroll
@@ -354,19 +479,21 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                 }
             }
         }
+        const int Sres = (S - 1) & 1;            // result buffer of the tile's last step: this wave's rows are free
 
         // ================= the series of this tile's pixels is complete =================
         const int y = y0 + wave;
         const int x = Xi - HALO + lane;
-        const bool in = (y < ny) && (x >= Xs) && (x < Xe);
+        const bool in = (y < ny) && (x >= out_lo) && (x < out_hi);
         // valid span of the wave: lanes lo .. lo + wnp - 1
         int xlo = Xi - HALO, xhi = Xi - HALO + 64;
-        xlo = xlo < Xs ? Xs : xlo;
-        xhi = xhi > Xe ? Xe : xhi;
+        xlo = xlo < out_lo ? out_lo : xlo;
+        xhi = xhi > out_hi ? out_hi : xhi;
         const int wnp = (y < ny && xhi > xlo) ? xhi - xlo : 0;
         const int lo = xlo - (Xi - HALO);
         uint8_t *wob = g.change + ((int64_t)y * nx + xlo) * (int64_t)k;
-        const int64_t wid = (b * ml.tmax + i) * (int64_t)M::NWAVE + wave;
+        // (a number no other wave of the launch has)
+        const int64_t wid = ((int64_t)strip * ml.tmax + (Xi >> 6)) * (int64_t)M::NWAVE + wave;
         const unsigned shard = (unsigned)(wid % kShards);
         const uint32_t pix = (uint32_t)((int64_t)y * nx + x);
 
@@ -383,7 +510,7 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
             if (wnp > 0) {
                 if ((k & 3) == 0) {
                     // (the wave's rows of the result area are its own until the next step's barrier)
-                    ml_store_change_rows(wob, reinterpret_cast<uint32_t *>(res + wave * (8 * 64)), k, mask,
+                    ml_store_change_rows(wob, reinterpret_cast<uint32_t *>(res + Sres * M::RES + wave * (8 * 64)), k, mask,
                                          lane, lo, wnp);
                 } else if (in) {
                     uint8_t *rr = g.change + (int64_t)pix * k;
@@ -453,7 +580,7 @@ bool omni_ml_plan(int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int
     if (nx <= 2 * halo || ny <= 2 * halo || nx > 0x3fffffff || ny > 0x3fffffff) return false;
     if (sx != 1 || sy < nx || st < 0) return false;
     // buffer offsets are 32-bit: date + row + column, in bytes
-    if (((int64_t)k * st + ny * sy + nx) * 4 >= 0x7fffffffLL) return false;
+    if (((int64_t)k * st + ny * sy + nx) * 4 + 8192 >= 0x7fffffffLL) return false;
     p->ml = ml;
     p->ny = ny;
     p->nx = nx;
@@ -466,7 +593,7 @@ bool omni_ml_plan(int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int
     p->xsegs = (int)ceil_div(nx, (int64_t)p->segw);
     p->nblocks = (int64_t)p->strips * p->xsegs;
     // waves that list pixels: tiles per segment <= segw / 64 + 1
-    const int64_t waves = p->nblocks * (p->segw / 64 + 1) * kMlTileRows;
+    const int64_t waves = (int64_t)p->strips * (ceil_div(nx, 64) + 2) * kMlTileRows;
     p->seg = (uint32_t)(ceil_div(waves, (int64_t)kShards) * 64 + 64);
     return true;
 }
@@ -476,7 +603,7 @@ static void launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, cons
                         const StreamScreen<32> *ss, bool stats, int64_t nblocks, hipStream_t stream)
 {
     typedef MlGeom<K> M;
-    const size_t lds = ((size_t)M::NSLOT * M::SLOT + M::RES + (size_t)(KMAX / 2) * M::NCAR) * sizeof(float) +
+    const size_t lds = ((size_t)M::NSLOT * M::SLOT + 2 * M::RES + (size_t)(KMAX / 2) * M::NCAR) * sizeof(float) +
                        33 * sizeof(StreamEntry);
     const dim3 grid((unsigned)nblocks), block(M::NT);
     StreamScreen<32> none;
@@ -507,9 +634,21 @@ void launch_ml_pass_a(const OmniGlobalArgs<float> &g, const OmniTab &tab, const 
     a.nx = p.nx;
     a.segw = p.segw;
     a.xsegs = p.xsegs;
-    a.tmax = p.segw / 64 + 1;
+    a.tmax = (int)ceil_div(p.nx, 64) + 2;
+    a.x4 = ((((uintptr_t)g.c11 | (uintptr_t)g.c12r | (uintptr_t)g.c12i | (uintptr_t)g.c22) & 15) == 0 &&
+            (g.sy & 3) == 0 && (g.st & 3) == 0) ? 1 : 0;
+    {
+        const char *e4 = getenv("ND_AMD_ML_X4");          // 0: per-element transfers everywhere (diagnostic)
+        if (e4 && atoi(e4) == 0) a.x4 = 0;
+    }
     a.wt = 1.0 / (double)(p.ml * p.ml);
     a.list = list ? 1 : 0;
+    {
+        const char *e = getenv("ND_AMD_ML_TRACE");       // device pointer (hex) of >= 147456 bytes, diagnostic builds
+        a.trace = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 16)) : nullptr;
+        const char *eb = getenv("ND_AMD_ML_TRACE_BLOCK");
+        a.trace_block = eb ? atoi(eb) : 1000;
+    }
     const int k = g.k;
 #define ND_ML_K(KK)                                                                       \
     do {                                                                                  \
