@@ -224,6 +224,7 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     float *slots = res + 2 * M::RES;                                          // [3][8][16][64]
     float *carry = slots + M::NSLOT * M::SLOT;                            // [NSTEP][8][ROWS][2h]
     StreamEntry *tab_lds = reinterpret_cast<StreamEntry *>(carry + NSTEP * M::NCAR);
+    int *rowtab = reinterpret_cast<int *>(tab_lds + 33);                  // byte offsets of the 16 image rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,6 +245,7 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     const int nstep_k = (k + 1) >> 1;               // steps that hold dates of the series
 
     if (CHAIN && tid <= 32) tab_lds[tid] = ss.e[tid];
+    if (tid < M::PROWS) rowtab[tid] = ml_reflect(y0 - HALO + (tid < ROWS ? tid : ROWS - 1), ny) * (int)g.sy * 4;
     if (g.write_tab && b == 0) {
         for (int j = tid; j <= k; j += NT) g.tab_dev[j] = tab.e[j];
     }
@@ -285,9 +287,10 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
             ml_dma16x4(myrs, m0b, rowoff[0] + xb, rowoff[1] + xb, rowoff[2] + xb, rowoff[3] + xb, so);
             return 4;
         }
-        // (rare: the row offsets are worked out here, not kept in registers across the walk)
+        // (rare: the row offsets come from a table in LDS -- worked out per step they were hoisted out of
+        //  the walk by the dozen and spilled: ~100 v_readlane per step)
         const int voff = ml_reflect(Xi + lane, nx) * 4;
-        auto ro = [&](const int r) { return so + ml_reflect(y0 - HALO + (r < ROWS ? r : ROWS - 1), ny) * (int)g.sy * 4; };
+        auto ro = [&](const int r) { return so + rowtab[r]; };
         ml_dma4x4<0>(myrs, m0b, voff, ro(0), ro(1), ro(2), ro(3));
         ml_dma4x4<4>(myrs, m0b, voff, ro(4), ro(5), ro(6), ro(7));
         ml_dma4x4<8>(myrs, m0b, voff, ro(8), ro(9), ro(10), ro(11));
@@ -344,13 +347,17 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     int S = 0;                       // step counter of the block
     int slot_i = 0;                  // slot of step S
     int s_prev = 0;                  // plane group of step S - 1
+    float cv = 0.f;                  // carried column element of step S - 1 (see the end of a step)
     float v[KMAX][4];
 
 #ifdef ND_ML_TRACE
+    // time stamps of steps 32 .. 47 of one block, kept in LDS (no memory traffic inside the loop) and
+    // written out when the block ends
+    unsigned *trc = reinterpret_cast<unsigned *>(rowtab + 16);
 #define ML_STAMP(j)                                                                                  \
     do {                                                                                             \
-        if (ml.trace && b == ml.trace_block && lane == 0 && S < 128)                                  \
-            ml.trace[((size_t)wave * 128 + S) * 12 + (j)] = __builtin_amdgcn_s_memtime();            \
+        if (ml.trace && b == ml.trace_block && lane == 0 && S >= 32 && S < 48)                        \
+            trc[(wave * 16 + (S - 32)) * 5 + (j)] = (unsigned)__builtin_amdgcn_s_memtime();          \
     } while (0)
 #else
 #define ML_STAMP(j)
@@ -359,11 +366,11 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     // its window sums (result buffer (S - 1) & 1), and every patch has read its planes.  Step S then
     //   A. saves the carried columns of step S - 1's planes and sends the transfers of step S + PF into
     //      that slot (the wave that stages a plane is the one that saves its columns: no other order
-    //      is needed), and asks for its pixels' 8 values of step S - 1 (the loads land in the retained
-    //      registers while the sums of step S are being formed);
+    //      is needed);
     //   B. forms the window sums of step S into result buffer S & 1;
-    //   C. waits for its transfers of step S + 1 and meets the others at the barrier.
-    // The last step of a tile picks its values up behind that barrier and runs the tile's tail.
+    //   C. waits for its transfers of step S + 1, meets the others at the barrier and asks for its pixels'
+    //      8 values of step S (the loads land in the retained registers while step S + 1 runs; behind
+    //      the last step of a tile the tail consumes them at once).
     for (int i = 0; i < ntiles; ++i) {
         const int Xi = Xs + 64 * i;
 #pragma unroll
@@ -373,13 +380,6 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                 const int slot_p = slot_i == 0 ? M::NSLOT - 1 : slot_i - 1;      // slot of step S - 1 = of S + PF
                 ML_STAMP(0);
                 // ---- A ----
-                float cv = 0.f;
-                if (S > 0 && co_lane) cv = slots[slot_p * M::SLOT + co_rd];
-                if (s > 0) {
-                    const float *R = res + ((S - 1) & 1) * M::RES + wave * (8 * 64) + lane;
-#pragma unroll
-                    for (int pl = 0; pl < 8; ++pl) v[2 * (s - 1) + (pl >> 2)][pl & 3] = R[pl * 64];
-                }
                 if (S > 0 && co_lane) carry[s_prev * M::NCAR + co_wr] = cv;
                 int cnt_new = 0;
 #ifndef ND_ML_NO_DMA
@@ -389,7 +389,7 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                         s2 -= nstep_k;
                         X2 += 64;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the columns above are in registers
+                    asm volatile("" : : "v"(cv) : "memory");                    // the columns above are in registers
                     cnt_new = stage(s2, X2, slot_p);
                 }
 #endif
@@ -458,8 +458,12 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                 ML_STAMP(3);
                 ml_barrier();
                 ML_STAMP(4);
-                if (s == nstep_k - 1) {
-                    // the tile's last step: its values now (the tail below needs the whole series)
+                // the last 2h new columns of this step's planes, for the next tile (saved by the wave that
+                // staged the plane, in front of its next transfers into this slot: part A of the next step)
+                if (co_lane) cv = cur[co_rd];
+                // this thread's pixel: its 8 values of the step (the loads land in the retained registers
+                // while the next step's sums are formed; the tile's last step is followed by the tail)
+                {
                     const float *R = res + (S & 1) * M::RES + wave * (8 * 64) + lane;
 #pragma unroll
                     for (int pl = 0; pl < 8; ++pl) {
@@ -565,6 +569,11 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
         // ---- a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275) ----
         if (!dense && wnp > 0 && ml.list) zero_fill_span(wob, wnp * k, lane);
     }
+#ifdef ND_ML_TRACE
+    __syncthreads();
+    if (ml.trace && b == ml.trace_block)
+        for (int e = tid; e < 12 * 16 * 5; e += NT) ml.trace[e] = trc[e];
+#endif
 }
 
 // -----------------------------------------------------------------------------------------
@@ -604,7 +613,11 @@ static void launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, cons
 {
     typedef MlGeom<K> M;
     const size_t lds = ((size_t)M::NSLOT * M::SLOT + 2 * M::RES + (size_t)(KMAX / 2) * M::NCAR) * sizeof(float) +
-                       33 * sizeof(StreamEntry);
+                       33 * sizeof(StreamEntry) + 16 * sizeof(int)
+#ifdef ND_ML_TRACE
+                       + 12 * 16 * 5 * 4
+#endif
+        ;
     const dim3 grid((unsigned)nblocks), block(M::NT);
     StreamScreen<32> none;
     if (!ss) memset(&none, 0, sizeof(none));

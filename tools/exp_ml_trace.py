@@ -17,15 +17,15 @@ for _ in range(3):
     tr.zero_()
     kernels.change_detection_multilooked(st[0], st[1], st[2], st[3], alpha=0.99, ml=ml)
 torch.cuda.synchronize()
-t = tr.cpu().numpy().reshape(12, 128, 12)
-nst = int((t[0, :, 0] > 0).sum())
-t0 = t[:, :nst, :5].astype(np.float64)
-print('steps', nst, 'cycles per step (wave 0):', (t0[0, -1, 4] - t0[0, 0, 0]) / nst)
+t = tr.cpu().numpy()[:12 * 16 * 5].reshape(12, 16, 5).astype(np.int64) & 0xffffffff
+t0 = t.astype(np.float64)
+nst = 16
+print('cycles per step (wave 0, steps 32 .. 47 of block %s):' % blk, (t0[0, -1, 0] - t0[0, 0, 0]) / (nst - 1))
 names = ['A(carry,res,dma)', 'B(compute)', 'C(wait dma)', 'barrier']
-for w in (0, 1, 5, 8, 11):
+for w in range(12):
     d = np.diff(t0[w], axis=1)
     gap = t0[w, 1:, 0] - t0[w, :-1, 4]            # tail / loop overhead between steps
-    print('wave %2d mean cycles:' % w, ' '.join('%s=%.0f' % (n, v) for n, v in zip(names, d[1:-1].mean(axis=0))),
+    print('wave %2d mean cycles:' % w, ' '.join('%s=%.0f' % (n, v) for n, v in zip(names, d.mean(axis=0))),
           'between=%.0f (max %.0f)' % (gap.mean(), gap.max()))
-arr = t0[:, 1:nst - 1, 3]
+arr = t0[:, :, 3]
 print('arrival skew at the barrier: mean max-min = %.0f cycles' % (arr.max(axis=0) - arr.min(axis=0)).mean())
