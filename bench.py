@@ -51,7 +51,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # workload's kernels, from separate rocprofv3 --pmc passes over `bench.py --traffic-run KEY`
 # (tools/collect_traffic.sh writes the file, with the commit it was taken at).  Reported with its
 # source; a workload or kernel the file does not hold gets traffic = null.
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r03_traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+
+
+def csrc_sha():
+    """Hash of the kernel sources the traffic figures were measured on (tools/summarize_traffic.py
+    stores it in the file): figures of other sources are not reported as measurements."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'nd_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.hpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def profiled_traffic(key, hint):
@@ -64,6 +77,9 @@ def profiled_traffic(key, hint):
     rows = [r for r in tab.get('workloads', {}).get(key, []) if hint in r['kernel']]
     if not rows:
         return None, None
+    if tab.get('csrc_sha') != csrc_sha():
+        return None, ('stale: %s was measured on kernel sources %s (commit %s), this build is %s'
+                      % (os.path.relpath(TRAFFIC_FILE, ROOT), tab.get('csrc_sha'), tab.get('commit', '?'), csrc_sha()))
     r = max(rows, key=lambda r: r['traffic_bytes'])
     return r['traffic_bytes'], ('%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py '
                                 '--traffic-run %s` at commit %s; kernel %s)'
@@ -395,7 +411,7 @@ def _free():
     torch.cuda.empty_cache()
 
 
-EXTRA_KEYS = ('omnibus_a0.01', 'omnibus_a0.0001', 'omnibus_a0.2', 'pm_a0.99', 'pm_a0.01', 'c3_a0.99', 'c3_a0.01',
+EXTRA_KEYS = ('omnibus_a0.01', 'omnibus_a0.0001', 'omnibus_a0.2', 'ml3', 'ml5', 'pm_a0.99', 'pm_a0.01', 'c3_a0.99', 'c3_a0.01',
               'boxcar3', 'boxcar5', 'gauss1', 'nlm_pm0', 'nlm_pm1', 'pipeline')
 
 
@@ -443,6 +459,41 @@ def extras(main, barrier, dev, only=None):
                          'search fused into the streaming pass over the planes (vector issue and HBM both '
                          'near their floors)') + '; bytes = planes read once + change map written once'),
               res['bad'] == 0, sample=res)
+        del ch
+
+    # -- OmnibusTest(ml=w): boxcar multilooking fused into the test (nd/change.py:61-69), the planes read once
+    for mlw in (3, 5):
+        key = 'ml%d' % mlw
+        if not want(key):
+            continue
+        alpha = 0.99                 # the benchmark's threshold (sparse regime: the fused kernel's)
+        fn = lambda: kernels.change_detection_multilooked(*main.stack, alpha=alpha, ml=mlw)       # noqa: E731
+        dt, km, ch = timed(fn, 10, 10, barrier)
+        if quick:
+            continue
+        kern = (np.ones((mlw, mlw)) / mlw ** 2).reshape(1, 1, mlw, mlw)
+        mlk = kernels.convolve(main.stack, kern)
+        two = kernels.change_detection(mlk[0], mlk[1], mlk[2], mlk[3], alpha=alpha, n=mlw * mlw)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ch, two))                 # whole raster against boxcar kernel + plain test
+        del mlk, two
+        ny_ = main.rows
+        res = checks.omnibus_ml_bands(main.stack, ch, mlw, alpha,
+                                      [(0, 12), (ny_ // 3, 12), (ny_ // 2 + 5, 12), (ny_ - 12, 12)])
+        dom = max(km, key=km.get)
+        # window sums: w^2 dependent float64 additions per value (scipy's order), 96 values per pixel
+        adds = main.npix * main.k * 4 * mlw * mlw
+        entry(key, 'OmnibusTest(ml=%d) C2 %dt x %d x %d f32, alpha=%g: %d x %d boxcar multilooking fused into '
+              'the test (n = %d looks)' % (mlw, main.k, main.rows, main.nx, alpha, mlw, mlw, mlw * mlw), dt, 10,
+              main.npix, km,
+              roof(key, 'ml_kernel', dom, km, main.alg_bytes,
+                   note='planes read once through LDS (16-byte LDS-DMA), window sums in scipy\'s order, series '
+                        'retained in registers; bound by vector issue, not memory: %.1f G dependent float64 '
+                        'additions per launch = %.2f T/s against 39.3 T/s (one per lane and 4 cycles)'
+                        % (adds / 1e9, adds / (km[dom] * 1e-3) / 1e12)),
+              res['bad'] == 0 and same, sample=res, equals_two_step_path_on_whole_raster=same,
+              valu={'bound': 'f64 add issue', 'achieved_Tadd_per_s': adds / (km[dom] * 1e-3) / 1e12,
+                    'peak_Tadd_per_s': 39.3, 'frac': adds / (km[dom] * 1e-3) / 1e12 / 39.3})
         del ch
 
     # -- the same test on data in the reference's own layout ((y, x, time), C12 interleaved complex):

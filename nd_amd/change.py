@@ -160,7 +160,12 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
             names = _VARS3 if full_pol else _VARS
             # (time-first device datasets are planar where they lie -- also in front of the fused
             #  multilooking, which only reads them)
-            fused_ml = ml is not None and os.environ.get('ND_AMD_ML_FUSED', '1') != '0'
+            # ND_AMD_ML_FUSED: 0 never, 2 at every threshold; default: in the sparse regime.  Below it the
+            # fused kernel carries the dense_chain search behind its window sums in one 12-wave block per
+            # CU (6.2 ms on 24 x 4096^2 at alpha = 0.01) and loses to the boxcar kernel + streaming search
+            # (4.1 ms); the maps are the same (tests/test_omnibus_ml_gpu.py runs both at every threshold).
+            ml_env = os.environ.get('ND_AMD_ML_FUSED', '1')
+            fused_ml = ml is not None and ml_env != '0' and (float(alpha) >= 0.93 or ml_env == '2')
             stack = _planes_in_place(ds_m, dev, names) if (ml is None or fused_ml) else None
             if stack is None:
                 stack = _covariance_planes(ds_m, dev, names)

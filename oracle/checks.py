@@ -42,6 +42,36 @@ def omnibus_sample(stack, change, alpha, n, nsample=100000, rows=(), seed=5, njo
             'flagged_fraction': float((want.sum(axis=1) > 0).mean())}
 
 
+def omnibus_ml_bands(stack, change, ml, alpha, bands, njobs=8):
+    """OmnibusTest(ml=w) (nd/change.py:61-69): stack planar (4, k, ny, nx) device tensor, change the
+    device map (ny, nx, k).  For every (y0, nrows) in `bands` the oracle multilooks the rows
+    [y0 - ml // 2, y0 + nrows + ml // 2) of every plane (scipy's boxcar arithmetic; the band keeps real
+    neighbour rows, or the raster's own reflection where it touches an edge), tests the band's core
+    with n = ml ** 2 and the core's map is compared byte for byte.
+    -> dict(bad=, compared=, flagged_fraction=)."""
+    nvar, k, ny, nx = stack.shape
+    assert nvar == 4
+    h = int(ml) // 2
+    kern = (np.ones((ml, ml), dtype=np.float64) / ml ** 2).reshape(1, ml, ml)
+    bad = comp = flagged = 0
+    for y0, nrows in bands:
+        a = max(0, min(int(y0), ny - nrows))
+        b = a + nrows
+        ea, eb = max(a - h, 0), min(b + h, ny)
+        sub = stack[:, :, ea:eb, :].cpu().numpy()
+        planes = []
+        for v in range(4):
+            mlv = O.convolve_reflect_mt(np.ascontiguousarray(sub[v]), kern, njobs=njobs)     # (k, rows, nx)
+            planes.append(np.ascontiguousarray(np.moveaxis(mlv[:, a - ea:a - ea + nrows, :], 0, -1)))
+        with np.errstate(all='ignore'):
+            want = O.change_detection_planes(planes, alpha, ml * ml, njobs=njobs)
+        got = change[a:b].cpu().numpy()
+        bad += int((got != want).sum())
+        comp += int(got.size)
+        flagged += int((want.sum(axis=2) > 0).sum())
+    return {'bad': bad, 'compared': comp, 'flagged_fraction': flagged / max(comp // k, 1)}
+
+
 def _crop_bounds(lo, n, size, halo):
     """[a, b) = core of a crop, [ea, eb) = core + halo clipped to [0, n)."""
     a = max(0, min(int(lo), n - size))

@@ -279,3 +279,24 @@ def test_long_series_statistics_at_scale(oracle, dtype, k):
     res = checks.omnibus_sample(st, ch, 0.01, 9, nsample=3000, rows=(0, ny - 1), seed=3)
     assert res['bad'] == 0, res
     assert res['flagged_fraction'] > 0.5
+
+
+@pytest.mark.parametrize('ml', [3, 5])
+def test_fused_multilook_whole_raster(oracle, stack, ml):
+    """OmnibusTest(ml=w) at full size: the fused kernel's map equals the boxcar kernel followed by the
+    plain test on the WHOLE raster at the benchmark's, the reference's default and the tutorial's
+    thresholds, and the oracle's (scipy boxcar -> change detection, n = ml ** 2) on four row bands
+    including both edges of the raster."""
+    import torch
+    from nd_amd import kernels
+    from oracle import checks
+    kern = (np.ones((ml, ml)) / ml ** 2).reshape(1, 1, ml, ml)
+    mlk = kernels.convolve(stack, kern)
+    for alpha in (0.99, 0.01, 1e-4):
+        got = kernels.change_detection_multilooked(stack[0], stack[1], stack[2], stack[3], alpha=alpha, ml=ml)
+        assert got is not None
+        two = kernels.change_detection(mlk[0], mlk[1], mlk[2], mlk[3], alpha=alpha, n=ml * ml)
+        assert torch.equal(got, two), 'alpha = %g' % alpha
+        res = checks.omnibus_ml_bands(stack, got, ml, alpha, [(0, 13), (1365, 12), (2049, 11), (NY - 13, 13)])
+        assert res['bad'] == 0 and res['compared'] == 49 * NX * K
+        del got, two

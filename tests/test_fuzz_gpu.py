@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEED = 20261004
-CASES_PER_FAMILY = {'omnibus': 1500, 'c3': 1200, 'nlmeans': 6000, 'correlate': 8000, 'gaussian': 8000}
+CASES_PER_FAMILY = {'omnibus': 1500, 'omnibus_ml': 500, 'c3': 1200, 'nlmeans': 6000, 'correlate': 8000, 'gaussian': 8000}
 
 
 @pytest.fixture(scope='module')

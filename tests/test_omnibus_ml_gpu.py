@@ -130,6 +130,10 @@ def test_apply_uses_the_fused_path(oracle, device, monkeypatch):
         ds[v] = (('time', 'y', 'x'), torch.from_numpy(p).to(device))
     want, _ = _oracle_ml(oracle, planes, 3, 0.9)
     got = OmnibusTest(ml=3, alpha=0.9).apply(ds)
+    assert calls == []                       # below the sparse regime: boxcar kernel + fused search
+    np.testing.assert_array_equal(got.values.cpu().numpy(), want.astype(bool))
+    monkeypatch.setenv('ND_AMD_ML_FUSED', '2')
+    got = OmnibusTest(ml=3, alpha=0.9).apply(ds)
     assert calls == [True]
     np.testing.assert_array_equal(got.values.cpu().numpy(), want.astype(bool))
     # reference layout (y, x, time) on the host
@@ -143,3 +147,9 @@ def test_apply_uses_the_fused_path(oracle, device, monkeypatch):
     got = OmnibusTest(ml=3, alpha=0.9).apply(dh)
     assert calls == [True, True]
     np.testing.assert_array_equal(got.values, want.astype(bool))
+    # the sparse regime takes the fused kernel by default
+    monkeypatch.delenv('ND_AMD_ML_FUSED')
+    want99, _ = _oracle_ml(oracle, planes, 3, 0.99)
+    got = OmnibusTest(ml=3, alpha=0.99).apply(ds)
+    assert calls == [True, True, True]
+    np.testing.assert_array_equal(got.values.cpu().numpy(), want99.astype(bool))

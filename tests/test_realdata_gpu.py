@@ -82,6 +82,13 @@ def test_omnibus_multilooked_bundled_raster(stack, oracle, device, alpha):
     got = OmnibusTest(ml=3, alpha=alpha).apply(ds)
     np.testing.assert_array_equal(got.values, want.astype(bool))
     assert want.sum() > 0
+    # the fused multilooking kernel itself, at every threshold (OmnibusTest picks it in the sparse regime)
+    import torch
+    from nd_amd import kernels
+    dev = [torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in planes]
+    got = kernels.change_detection_multilooked(*dev, alpha=alpha, ml=3)
+    assert got is not None
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
 def test_filters_on_bundled_raster(stack, oracle, device):

@@ -2,16 +2,16 @@
 # HBM traffic of every bench workload's kernels: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes (with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over `bench.py --traffic-run KEY`.
 #   bash tools/collect_traffic.sh gpurun_out/traffic [commit] [KEY ...]    (on the GPU box)
-# writes <outdir>/traffic.json -- copy it to profiles/r03_traffic.json, which bench.py reads.
+# writes <outdir>/traffic.json -- copy it to profiles/r04_traffic.json, which bench.py reads.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/$1; COMMIT=${2:-unknown}; shift; shift
 KEYS="$@"
-[ -z "$KEYS" ] && KEYS="headline omnibus_a0.01 omnibus_a0.0001 omnibus_a0.2 pm_a0.99 pm_a0.01 c3_a0.99 c3_a0.01 boxcar3 boxcar5 gauss1 nlm_pm0 nlm_pm1 pipeline"
+[ -z "$KEYS" ] && KEYS="headline omnibus_a0.01 omnibus_a0.0001 omnibus_a0.2 ml3 ml5 pm_a0.99 pm_a0.01 c3_a0.99 c3_a0.01 boxcar3 boxcar5 gauss1 nlm_pm0 nlm_pm1 pipeline"
 mkdir -p $OUT
 for K in $KEYS; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/tr_$C
-    rocprofv3 --kernel-trace --pmc $C -d /tmp/tr_$C -o p --output-format csv -- python3 $R/bench.py --traffic-run $K > $OUT/run_${K}_$C.log 2>&1
+    timeout -k 5 200 rocprofv3 --kernel-trace --pmc $C -d /tmp/tr_$C -o p --output-format csv -- python3 $R/bench.py --traffic-run $K > $OUT/run_${K}_$C.log 2>&1
     F=$(ls /tmp/tr_$C/*/p_counter_collection.csv /tmp/tr_$C/p_counter_collection.csv 2>/dev/null | head -1)
     cp "$F" $OUT/${K}_$C.csv
   done

@@ -12,6 +12,8 @@ for i, (k, ny, nx) in enumerate(SHAPES):
     planes = synth.omnibus_stack(100 + i, k, ny, nx, looks=1, dtype=np.float32, change_frac=0.05)
     d = [torch.from_numpy(p).to(dev) for p in planes]
     got = kernels.change_detection_multilooked(*d, alpha=alpha, ml=ml)
+    if got is None:
+        print((k, ny, nx), 'not covered'); continue
     two = _two_step(kernels, torch, d, ml, alpha)
     bad = (got != two).any(dim=2)
     n = int(bad.sum())

@@ -94,6 +94,61 @@ def case_omnibus(rng):
     return ok, desc
 
 
+def case_omnibus_ml(rng):
+    """OmnibusTest(ml=w): the fused multilooking kernel (nd_amd_omnibus_c2_ml) against scipy's boxcar
+    followed by the oracle's test with n = ml ** 2 (nd/change.py:61-69)."""
+    import scipy.ndimage as ndi
+    ml = int(rng.choice([3, 5]))
+    k = int(rng.choice([3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 20, 23, 24]))
+    ny, nx = int(rng.integers(ml, 60)), int(rng.integers(ml, 400))
+    if rng.random() < 0.3:
+        nx = int(rng.choice([64, 128, 192, 256, 68, 132]))        # whole tiles, 16-byte rows
+    looks = int(rng.choice([1, 1, 2, 4]))
+    alpha = float(rng.choice([0.01, 0.2, 0.7, 0.9, 0.95, 0.99, 0.999, 1e-4]))
+    w = wishart(rng, k, ny, nx, looks, np.float32)
+    planes = [w['C11'], w['C12re'], w['C12im'], w['C22']]
+    scale = float(rng.choice([1.0, 1.0, 1.0, 1e-3, 1e-6, 1e4]))
+    if scale != 1.0:
+        planes = [(p * np.float32(scale)).astype(np.float32) for p in planes]
+    if rng.random() < 0.7:
+        m = rng.random((ny, nx)) < 0.3
+        t0 = rng.integers(1, k, (ny, nx))
+        g = np.where((np.arange(k)[:, None, None] >= t0[None]) & m[None], rng.choice([0.1, 4.0, 30.0]), 1.0)
+        planes = [(p * g).astype(np.float32) for p in planes]
+    if rng.random() < 0.3:
+        bad = rng.random((k, ny, nx)) < 0.005
+        planes[int(rng.integers(0, 4))][bad] = rng.choice([0.0, np.nan, np.inf, -1.0])
+    if rng.random() < 0.2:                                          # a nodata margin
+        for p in planes:
+            p[:, :, : nx // 3] = 0
+    stats = bool(rng.random() < 0.4)
+    layout = str(rng.choice(['tyx', 'pad']))
+    desc = dict(ml=ml, k=k, ny=ny, nx=nx, looks=looks, alpha=alpha, stats=stats, layout=layout, scale=scale)
+    kern = (np.ones((ml, ml), dtype=np.float64) / ml ** 2).reshape(1, ml, ml)
+    with np.errstate(all='ignore'):
+        mlp = [ndi.convolve(p, kern) for p in planes]
+        want, zw, pw = O.change_detection_planes([np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in mlp],
+                                                 alpha, ml * ml, njobs=8, stats=True)
+    if layout == 'tyx':
+        dev = [torch.from_numpy(p).to(DEV) for p in planes]
+    else:
+        big = torch.zeros((4, k, ny + 2, nx + 8), dtype=torch.float32, device=DEV)
+        for v in range(4):
+            big[v, :, 1:ny + 1, 4:nx + 4] = torch.from_numpy(planes[v]).to(DEV)
+        dev = [big[v, :, 1:ny + 1, 4:nx + 4] for v in range(4)]
+    res = kernels.change_detection_multilooked(*dev, alpha=alpha, ml=ml, stats=stats)
+    if res is None:
+        return False, dict(desc, refused=True)
+    got = (res[0] if stats else res).cpu().numpy()
+    ok = np.array_equal(got, want)
+    if ok and stats:
+        z, P = res[1].cpu().numpy(), res[2].cpu().numpy()
+        with np.errstate(all='ignore'):
+            ok = (np.allclose(z, zw, rtol=1e-5, atol=0, equal_nan=True) and
+                  np.allclose(P, pw, rtol=1e-5, atol=1e-7, equal_nan=True))
+    return ok, desc
+
+
 def case_c3(rng):
     k = int(rng.choice([2, 3, 4, 7, 12, 24, 33, 48, 63, 64, 65]))
     ny, nx = int(rng.integers(1, 20)), int(rng.integers(1, 200))
@@ -280,7 +335,7 @@ def case_gaussian(rng):
     return np.array_equal(got, want, equal_nan=True), desc
 
 
-CASES = {'omnibus': case_omnibus, 'c3': case_c3, 'nlmeans': case_nlmeans, 'correlate': case_correlate,
+CASES = {'omnibus': case_omnibus, 'omnibus_ml': case_omnibus_ml, 'c3': case_c3, 'nlmeans': case_nlmeans, 'correlate': case_correlate,
          'gaussian': case_gaussian}
 
 
