@@ -196,6 +196,50 @@ def timed(fn, steps, warmup, barrier, launches_per_step=8, only=None, per_step=N
     return dt, _kernel_avgs(kt), out
 
 
+def device_state(index):
+    """Clocks, temperature and power of the device as rocm-smi reports them (None where it does not)."""
+    import subprocess
+    try:
+        r = subprocess.run(['rocm-smi', '-d', str(index), '--showclocks', '--showtemp', '--showpower', '--json'],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+    except Exception as e:              # noqa: BLE001
+        return {'error': repr(e)[:120]}
+    keep = {}
+    for key, val in card.items():
+        kl = key.lower()
+        if any(t in kl for t in ('sclk', 'mclk', 'fclk', 'socclk', 'temperature', 'power')):
+            keep[key] = val
+    return keep
+
+
+def transfer_rates(dev, nbytes=1 << 30):
+    """host <-> device rates, reported once and never part of `value` (inputs are resident
+    when the timed region starts).  One plane-sized block through page-locked memory, best of three."""
+    import torch
+    try:
+        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    except Exception as e:              # noqa: BLE001
+        return {'error': repr(e)[:120]}
+    devt = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    best = {}
+    for name, fn in (('h2d', lambda: devt.copy_(host, non_blocking=True)),
+                     ('d2h', lambda: host.copy_(devt, non_blocking=True))):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        best[name + '_GBs'] = nbytes / min(ts) / 1e9
+    best['block_bytes'] = nbytes
+    best['note'] = 'page-locked host memory, one 1 GiB copy, best of three; not part of `value`'
+    del devt, host
+    return best
+
+
 def roofline(kernel, avg_ms, alg_bytes, note=None, traffic=None, traffic_source=None):
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     r = {'kernel': kernel, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
@@ -585,11 +629,13 @@ def extras(main, barrier, dev, only=None):
         if want('gauss1'):
             import scipy.ndimage as ndi
             # (warm-up launches first: the host-side baseline just above leaves the GPU at idle clocks)
-            # (two batches of 20, the faster one: a host-side pause of tens of milliseconds inside a batch
-            # of sub-millisecond launches showed up in two of six runs of this line -- 3.3 / 4.2 ms "per
-            # step" around a kernel of 0.74 ms; the headline is never treated this way)
-            dt, km, _ = min((timed(lambda: kernels.gaussian_filter(x, (0, 1.0, 1.0), out=y), 20, 20 if i == 0 else 2, barrier)
-                             for i in range(2)), key=lambda r: r[0])
+            # (two batches of 20, BOTH reported: a host-side pause of tens of milliseconds inside a batch of
+            # sub-millisecond launches showed up in two of six runs of this line -- 3.3 / 4.2 ms "per step"
+            # around a kernel of 0.74 ms.  `ms` is the median of the two batches, i.e. their mean.)
+            batches = [timed(lambda: kernels.gaussian_filter(x, (0, 1.0, 1.0), out=y), 20, 20 if i == 0 else 2, barrier)
+                       for i in range(2)]
+            dt = sum(b_[0] for b_ in batches) / len(batches)
+            km = batches[0][1]
             if not quick:
                 res = checks.gaussian_bands(x, y, 1.0, [(0, 40), (2030, 2070), (4056, 4096)], [0, 23])
                 dom = max(km, key=km.get)
@@ -602,6 +648,7 @@ def extras(main, barrier, dev, only=None):
                       roof('gauss1', 'correlate1d', dom, km, 8 * x.numel(),
                            note='one read and one write of the array for both passes'),
                       res['bad'] == 0, unit_note='Mpx_per_s counts px.t', sample=res,
+                      batches_ms=[b_[0] / 20 * 1e3 for b_ in batches],
                       cpu_baseline={'value': crop.size / dtc / 1e6, 'unit': 'M px.t/s', 'cores': 1,
                                     'kind': 'reference', 'sample': 'scipy.ndimage.gaussian_filter (the reference\'s '
                                     'own arithmetic for this filter) on a 4 x 2048 x 2048 crop, %.2f s' % dtc})
@@ -725,8 +772,11 @@ def main():
     # roofline needs that kernel's duration measured live here), plus one torch event per step
     # boundary for the spread.  The other kernels' durations come from a second, untimed loop.
     per_step = []
+    state_before = device_state(local_rank)
     dt, avg, out = timed(w.step, args.steps, args.warmup, barrier, only=[w.dom], per_step=per_step)
+    state_after = device_state(local_rank)
     _, avg_all, _ = timed(w.step, max(3, min(args.steps, 10)), 1, barrier)
+    avg_timed = dict(avg)                      # measured inside the timed region
     for name, ms in avg_all.items():
         avg.setdefault(name, ms)
 
@@ -795,8 +845,14 @@ def main():
             },
             'comm': comm,
             'kernels_ms': avg,
-            'kernels_ms_note': '%s: events inside the timed region; the others: a second loop of the '
-                               'same step' % dom_k,
+            'kernels_ms_timed_region': avg_timed,
+            'kernels_ms_second_loop': {n_: m_ for n_, m_ in avg_all.items() if n_ not in avg_timed},
+            'kernels_ms_note': 'kernels_ms_timed_region: HIP events inside the timed region (the dominant '
+                               'kernel only: an event pair costs stream time); kernels_ms_second_loop: the '
+                               'same step run again behind it; kernels_ms: both together',
+            'device_state': {'before_timed_region': state_before, 'after_timed_region': state_after,
+                             'note': 'rocm-smi clocks / temperature / power around the timed region: the same '
+                                     'code ran pass A in 1.11 - 1.20 ms from box to box in round 3'},
         }
         if w.name == 'omnibus':
             # SURVEY 8(d) / BASELINE.md basis: the planes read once, k * 4 * sizeof(T) bytes per pixel
@@ -814,6 +870,7 @@ def main():
                                        note='algorithmic bytes = planes read once + change map written once'
                                        if w.name != 'pipeline' else 'algorithmic bytes = filter input + output')
         if world == 1 and w.name == 'omnibus':
+            res['transfer'] = transfer_rates(dev)
             if args.cpu_rows > 0:
                 res['cpu_baseline'] = cpu_baseline_omnibus(w, out)
             if not args.no_extra:

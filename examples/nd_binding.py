@@ -25,6 +25,7 @@ _L = C.CDLL(os.environ.get('ND_AMD_LIB') or os.path.join(_HERE, '..', 'nd_amd', 
 assert _L.nd_amd_abi_version() == 1               # built with: python -m nd_amd.build
 _L.nd_amd_last_error.restype = C.c_char_p
 _L.nd_amd_omnibus_c2_workspace_bytes.restype = C.c_size_t
+_L.nd_amd_omnibus_c2_ml_workspace_bytes.restype = C.c_size_t
 _DT = {np.dtype('float32'): 0, np.dtype('float64'): 1}            # ND_AMD_F32 / ND_AMD_F64
 _MODES = {'reflect': 0, 'constant': 1, 'nearest': 2, 'mirror': 3, 'wrap': 4}
 
@@ -68,6 +69,27 @@ def change_detection(c11, c12, c22, alpha, n=1):
         C.c_int64(ny), C.c_int64(nx), C.c_int64(k), _i64((1, 2, 2, 1)),      # date strides per variable
         C.c_uint32(n), C.c_double(alpha), _p(change), None, None,
         _p(ws), C.c_size_t(nbytes), _stream()))
+    return change.cpu().numpy()
+# --8<-- [end]
+
+
+# --8<-- [omnibus_ml]
+def change_detection_multilooked(c11, c12re, c12im, c22, alpha, ml):
+    """nd/change.py:61-69 with ml given: BoxcarFilter(w=ml) over every (y, x) plane, n = ml ** 2, then
+    the test -- in one pass.  c11 ... c22: float32 (time, y, x) arrays (the dataset's variables,
+    complex C12 already split by disassemble_complex); returns uint8 (y, x, time), or None where the
+    fused kernel does not apply (then: BoxcarFilter as before, and change_detection above)."""
+    k, ny, nx = c11.shape
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (c11, c12re, c12im, c22)]
+    nbytes = _L.nd_amd_omnibus_c2_ml_workspace_bytes(0, C.c_int64(ny), C.c_int64(nx), C.c_int64(k), C.c_int(ml))
+    if nbytes == 0:
+        return None
+    change = torch.empty((ny, nx, k), dtype=torch.uint8, device='cuda')
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    _check(_L.nd_amd_omnibus_c2_ml(
+        _p(dev[0]), _p(dev[1]), _p(dev[2]), _p(dev[3]), 0, C.c_int64(ny), C.c_int64(nx), C.c_int64(k),
+        C.c_int64(nx), C.c_int64(1), C.c_int64(ny * nx),                       # element strides y, x, time
+        C.c_int(ml), C.c_double(alpha), _p(change), None, None, _p(ws), C.c_size_t(nbytes), _stream()))
     return change.cpu().numpy()
 # --8<-- [end]
 

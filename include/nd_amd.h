@@ -11,6 +11,15 @@
  * success, a negative ND_AMD_E* code otherwise; nd_amd_last_error() returns a
  * thread-local description.  The library never throws and never aborts.
  *
+ * No host twins.  SURVEY.md 8(b) sketched a `*_cpu` entry next to every device
+ * entry (same arguments on host pointers).  The ABI deliberately has none: the
+ * reference interface itself has no such pair (its native calls ARE the host
+ * path), the product path has no CPU fallback by rule -- every entry fails with
+ * ND_AMD_EINVAL / ND_AMD_EHIP rather than compute on the host -- and the only
+ * CPU arithmetic of this repository, oracle/, is test infrastructure that
+ * nothing under nd_amd/ may link or call.  A caller that wants the host path
+ * keeps calling the reference's own nd._change / nd._filters / scipy.
+ *
  * Paths are relative to the reference checkout (/root/reference).
  */
 #ifndef ND_AMD_H

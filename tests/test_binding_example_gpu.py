@@ -35,6 +35,21 @@ def test_change_detection_binding(binding, oracle):
         assert want.sum() > 0
 
 
+def test_change_detection_multilooked_binding(binding, oracle):
+    """nd/change.py:61-69 with ml: scipy's boxcar on every plane, n = ml ** 2, the test."""
+    import scipy.ndimage as ndi
+    from tests import synth
+    for k, alpha, ml in ((12, 0.9, 3), (24, 0.99, 5), (8, 0.01, 3)):
+        planes = synth.omnibus_stack(seed=9 + k, k=k, ny=41, nx=150, looks=1, dtype=np.float32, change_frac=0.15)
+        got = binding.change_detection_multilooked(*planes, alpha, ml)
+        kern = (np.ones((ml, ml)) / ml ** 2).reshape(1, ml, ml)
+        mlp = [np.ascontiguousarray(np.moveaxis(ndi.convolve(p, kern), 0, -1)) for p in planes]
+        want = oracle.change_detection_planes(mlp, alpha, ml * ml)
+        assert got is not None and got.dtype == np.uint8 and got.shape == (41, 150, k)
+        np.testing.assert_array_equal(got, want)
+    assert binding.change_detection_multilooked(*planes, 0.9, 4) is None          # even window: not covered
+
+
 def test_convolve_binding(binding):
     """nd/filters.py:262-267: scipy.ndimage.convolve with the kernel broadcast to arr.ndim."""
     import scipy.ndimage as ndi

@@ -286,7 +286,7 @@ def test_integration_doc_quotes_the_example():
     ex = open(os.path.join(ROOT, 'examples', 'nd_binding.py')).read()
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     sections = dict(re.findall(r"# --8<-- \[(\w+)\]\n(.*?)\n# --8<-- \[end\]", ex, re.S))
-    assert set(sections) == {'load', 'omnibus', 'convolve', 'nlmeans', 'gaussian'}
+    assert set(sections) == {'load', 'omnibus', 'omnibus_ml', 'convolve', 'nlmeans', 'gaussian'}
     for name, code in sections.items():
         assert code.strip('\n') in doc, 'INTEGRATION.md does not quote section [%s] verbatim' % name
     # the header says what the example does with the optional tile arguments
