@@ -240,6 +240,64 @@ def transfer_rates(dev, nbytes=1 << 30):
     return best
 
 
+def boundary_check(w, out, dist, rank, world, rdev, core_rows=32, cols=2048):
+    """N > 1: the rows either side of every shard boundary, recomputed UNSHARDED on rank 0 and compared
+    with what the two neighbour ranks produced -- byte for byte (change map) and bit for bit (filtered
+    values of the pipeline, whose rows next to a boundary depend on the other rank's rows: the halo
+    exchange).  Every rank sends its first and last rows (inputs with the filter's halo, outputs) to
+    rank 0 point to point.  -> dict on rank 0 (None elsewhere); raises on any difference."""
+    import torch
+    halo = w.halo_rows
+    hx = halo                                   # the filter's reach along x equals its reach along y here
+    cols = min(cols, w.nx - hx) if w.nx > hx + 8 else w.nx
+    cin = min(cols + hx, w.nx)
+    nin = min(core_rows + halo, w.rows)
+    nco = min(core_rows, w.rows)
+    filt = getattr(w, 'filtered', None) if w.name == 'pipeline' else None
+
+    def pack(top):
+        sl = slice(0, nco) if top else slice(w.rows - nco, w.rows)
+        d = {'in': w.edge_inputs(top, nin, cin), 'map': out[sl, :cols].contiguous()}
+        if filt is not None:
+            d['filt'] = filt[:, :, sl, :cols].contiguous()
+        return d
+
+    mine = {'top': pack(True), 'bot': pack(False)}
+    names = ['in', 'map'] + (['filt'] if filt is not None else [])
+    if rank != 0:
+        for side in ('top', 'bot'):
+            for n_ in names:
+                dist.send(mine[side][n_].to(rdev), dst=0)
+        return None
+    edges = {0: mine}
+    for r in range(1, world):
+        edges[r] = {}
+        for side in ('top', 'bot'):
+            edges[r][side] = {}
+            for n_ in names:
+                t = torch.empty_like(mine[side][n_], device=rdev)
+                dist.recv(t, src=r)
+                edges[r][side][n_] = t.to(w.dev)
+    bad_map = bad_filt = compared = 0
+    for r in range(1, world):
+        up, dn = edges[r - 1]['bot'], edges[r]['top']
+        band = torch.cat([up['in'], dn['in']], dim=2)            # 2 (core + halo) rows around the boundary
+        ch, fl = w.band_result(band, (nin - nco, 2 * nco), cols)
+        want_map = torch.cat([up['map'], dn['map']], dim=0)
+        bad_map += int((ch != want_map).sum().item())
+        compared += int(want_map.numel())
+        if fl is not None:
+            want_f = torch.cat([up['filt'], dn['filt']], dim=2)
+            bad_filt += int((fl.view(torch.int32) != want_f.view(torch.int32)).sum().item())
+    res = {'boundaries': world - 1, 'rows_each_side': nco, 'columns': cols, 'map_bytes_compared': compared,
+           'map_bytes_differing': bad_map, 'filtered_values_differing': bad_filt if filt is not None else None,
+           'note': 'rank 0 recomputes the rows around every shard boundary unsharded from the neighbours\' '
+                   'inputs and compares with their outputs'}
+    if bad_map or bad_filt:
+        raise RuntimeError('sharded result differs from the unsharded one at a shard boundary: %r' % res)
+    return res
+
+
 def roofline(kernel, avg_ms, alg_bytes, note=None, traffic=None, traffic_source=None):
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     r = {'kernel': kernel, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
@@ -268,8 +326,32 @@ class Workload:
         self.npix = self.rows * self.nx
 
 
+    # ---- N > 1 self-check (boundary_check below): the rows either side of a shard boundary ----
+    halo_rows = 0
+
+    def edge_inputs(self, top, nrows, cols):
+        """this rank's first (top) or last `nrows` rows of every input plane, columns [0, cols)"""
+        st = self.inputs()
+        sl = slice(0, nrows) if top else slice(self.rows - nrows, self.rows)
+        return st[:, :, sl, :cols].contiguous()
+
+    def band_result(self, band, core, cols):
+        """the unsharded computation on a band of input rows (var, k, rows, cols + halo): the change map
+        of its `core` = (first row, rows) restricted to columns [0, cols) -- and, for the pipeline, the
+        filtered values there"""
+        raise NotImplementedError
+
+
 class OmnibusC2(Workload):
     name, dom = 'omnibus', 'omnibus_c2_global'
+
+    def inputs(self):
+        return self.stack
+
+    def band_result(self, band, core, cols):
+        from nd_amd import kernels
+        ch = kernels.change_detection(band[0], band[1], band[2], band[3], alpha=self.a.alpha, n=self.a.looks)
+        return ch[core[0]:core[0] + core[1], :cols], None
 
     def __init__(self, a, rank, world, dev):
         super().__init__(a, rank, world, dev)
@@ -303,6 +385,14 @@ class OmnibusC2(Workload):
 class OmnibusC3(Workload):
     name, dom = 'c3', 'omnibus_c2_global'          # the C3 pass A reports under the same id
 
+    def inputs(self):
+        return self.stack
+
+    def band_result(self, band, core, cols):
+        from nd_amd import kernels
+        ch = kernels.change_detection_c3([band[c] for c in range(9)], alpha=self.a.alpha, n=self.a.looks)
+        return ch[core[0]:core[0] + core[1], :cols], None
+
     def __init__(self, a, rank, world, dev):
         super().__init__(a, rank, world, dev)
         from nd_amd import synth
@@ -335,6 +425,18 @@ class OmnibusC3(Workload):
 
 class Pipeline(Workload):
     name, dom = 'pipeline', 'nlmeans_tiled'
+    halo_rows = TUT['r'][1] + TUT['f'][1]
+
+    def inputs(self):
+        return self.shard.core
+
+    def band_result(self, band, core, cols):
+        from nd_amd import tiles
+        filt = tiles.nlmeans_rows(band, band.shape[2], TUT['r'], TUT['f'], TUT['sigma'], TUT['h'],
+                                  n_eff=TUT['n_eff'], patch_mode=self.a.patch_mode)
+        filt = filt[:, :, core[0]:core[0] + core[1], :].contiguous()
+        ch = tiles.omnibus_rows(filt, self.a.alpha, TUT['n'])
+        return ch[:, :cols], filt[..., :cols]
 
     def __init__(self, a, rank, world, dev):
         super().__init__(a, rank, world, dev)
@@ -806,12 +908,18 @@ def main():
                 kernels.raise_if_no_solution(w.status_any)
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
+        # first contact with N > 1 must not be taken on trust: one rank per GPU, as many as asked for
+        if dist.get_world_size() != args.gpus:
+            raise RuntimeError('--gpus %d but the process group has %d ranks' % (args.gpus, dist.get_world_size()))
+        if not rehearse and len({r_['device_index'] for r_ in ranks}) != world:
+            raise RuntimeError('ranks share devices: %r' % [(r_['rank'], r_['device_index']) for r_ in ranks])
+        bcheck = boundary_check(w, out, dist, rank, world, rdev)
         comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
                 'data_path_collective': 'none (per-pixel path: every rank runs its own rows)'
                 if w.name != 'pipeline' else
                 'one point-to-point halo exchange per step (batch_isend_irecv with the row neighbours, '
                 'overlapped with the filter on the rows that need no halo)',
-                'ranks': ranks}
+                'ranks': ranks, 'boundary_check': bcheck}
 
     if rank == 0:
         is_default = (w.name == 'omnibus' and (w.k, args.ny, w.nx, args.alpha, args.looks, args.change_frac)

@@ -245,3 +245,7 @@ def test_bench_launch_line_with_two_ranks(workload, extra, tmp_path):
         assert 'point-to-point' in comm['data_path_collective']
     else:
         assert comm['data_path_collective'].startswith('none')
+    # rank 0 recomputed the rows around the shard boundary unsharded and found them equal
+    bc = comm['boundary_check']
+    assert bc['boundaries'] == 1 and bc['map_bytes_differing'] == 0 and bc['map_bytes_compared'] > 0
+    assert bc['filtered_values_differing'] == (0 if workload == 'pipeline' else None)
