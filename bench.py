@@ -431,9 +431,12 @@ class Pipeline(Workload):
         return self.shard.core
 
     def band_result(self, band, core, cols):
-        from nd_amd import tiles
-        filt = tiles.nlmeans_rows(band, band.shape[2], TUT['r'], TUT['f'], TUT['sigma'], TUT['h'],
-                                  n_eff=TUT['n_eff'], patch_mode=self.a.patch_mode)
+        import torch
+        from nd_amd import kernels, tiles
+        # the kernel itself on the whole band (no process group: this IS the unsharded computation)
+        filt = torch.empty_like(band)
+        kernels.pixelwise_nlmeans_3d(band.permute(1, 2, 3, 0), filt.permute(1, 2, 3, 0), TUT['r'], TUT['f'],
+                                     TUT['sigma'], TUT['h'], TUT['n_eff'], patch_mode=self.a.patch_mode)
         filt = filt[:, :, core[0]:core[0] + core[1], :].contiguous()
         ch = tiles.omnibus_rows(filt, self.a.alpha, TUT['n'])
         return ch[:, :cols], filt[..., :cols]
