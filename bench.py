@@ -240,6 +240,22 @@ def transfer_rates(dev, nbytes=1 << 30):
     return best
 
 
+VALU_PK_F32_TADD = 78.6        # packed float32 additions per second, 10^12 (MI355X_MICROARCH.md: 157.3 TFLOP/s FMA rate)
+
+
+def valu_roofline(r, adds_per_launch, what):
+    """Turns an HBM roofline block into that of a kernel bound by vector issue (non-local
+    means is not HBM-bound): `bound` = valu, achieved = dependent float32 additions per second against the
+    packed-float32 add rate; the HBM figures stay as `hbm`."""
+    t = r['kernel_ms'] * 1e-3
+    out = dict(r)
+    out['hbm'] = {'achieved': r['achieved'], 'peak': r['peak'], 'unit': r['unit'], 'frac': r['frac']}
+    out.update({'bound': 'valu', 'achieved': adds_per_launch / t / 1e12, 'peak': VALU_PK_F32_TADD,
+                'unit': 'T float32 additions/s', 'frac': adds_per_launch / t / 1e12 / VALU_PK_F32_TADD,
+                'algorithmic_additions_per_launch': int(adds_per_launch), 'valu_note': what})
+    return out
+
+
 def boundary_check(w, out, dist, rank, world, rdev, core_rows=32, cols=2048):
     """N > 1: the rows either side of every shard boundary, recomputed UNSHARDED on rank 0 and compared
     with what the two neighbour ranks produced -- byte for byte (change map) and bit for bit (filtered
@@ -503,10 +519,19 @@ class Pipeline(Workload):
         from nd_amd import kernels
         from oracle import checks
         kernels.raise_if_no_solution(self.status_any)
-        crops = [(0, 0), (self.rows, self.nx), (self.rows // 2, self.nx // 3)]
-        return checks.nlmeans_crops(self.stack, self.filtered, TUT['r'], TUT['f'], TUT['sigma'],
-                                    TUT['h'], TUT['n_eff'], self.a.patch_mode, crops, size=(8, 64),
-                                    then_omnibus=(self.a.alpha, TUT['n']), change=out)
+        # the two edge bands of the tile whole (rows 0 .. 7 and the last 8, every column: with neighbour
+        # ranks these are the rows the separate edge launches compute) and a crop from the interior
+        res = checks.nlmeans_crops(self.stack, self.filtered, TUT['r'], TUT['f'], TUT['sigma'],
+                                   TUT['h'], TUT['n_eff'], self.a.patch_mode, [(0, 0), (self.rows, 0)],
+                                   size=(8, self.nx), then_omnibus=(self.a.alpha, TUT['n']), change=out)
+        mid = checks.nlmeans_crops(self.stack, self.filtered, TUT['r'], TUT['f'], TUT['sigma'],
+                                   TUT['h'], TUT['n_eff'], self.a.patch_mode, [(self.rows // 2, self.nx // 3)],
+                                   size=(8, 64), then_omnibus=(self.a.alpha, TUT['n']), change=out)
+        for key in ('bad', 'compared', 'change_bad', 'change_compared'):
+            res[key] += mid[key]
+        res['max_rel'] = max(res['max_rel'], mid['max_rel'])
+        res['bands'] = 'rows 0-7 and the last 8, full width; one 8 x 64 interior crop'
+        return res
 
 
 WORKLOADS = {'omnibus': OmnibusC2, 'c3': OmnibusC3, 'pipeline': Pipeline}
@@ -798,9 +823,13 @@ def extras(main, barrier, dev, only=None):
             entry(key, 'NLMeansFilter 7x7 patch / 21x21 search on 12t x 4096 x 4096 f32, patch distances %s'
                   % ('as compiled (reference: window mean)' if pm == 0 else 'signed (true patch distances)'),
                   dt, steps, x.numel(), km,
-                  roof(key, 'nlmeans', dom, km, 8 * x.numel(),
-                       note='VALU/LDS-bound: HBM traffic is 8 B per px.t, the fraction of HBM peak is '
-                            'reported for completeness'),
+                  valu_roofline(roof(key, 'nlmeans', dom, km, 8 * x.numel(),
+                                     note='HBM traffic is 8 B per px.t: never the bound'),
+                                x.numel() * nq * (1 if pm == 0 else 49 * 3),
+                                '440 dependent float32 additions per output in the reference\'s visiting order '
+                                '(packed over two outputs)' if pm == 0 else
+                                '440 x 49 patch elements x (subtract, multiply, add) per output before the '
+                                'cross-lane sharing of the patch-row sums (the kernel performs ~1/5 of them)'),
                   res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
         del x, y
         _free()
@@ -816,7 +845,12 @@ def extras(main, barrier, dev, only=None):
         dt, km, ch = timed(w.step, 3, 2, barrier)
         if not quick:
             res = w.check(ch)
-            entry('pipeline', w.describe(), dt, 3, w.npix, km, roof('pipeline', 'nlmeans', w.dom, km, w.alg_bytes),
+            nq_t = 3 * 7 * 7 - 1                              # neighbours of the tutorial's window
+            entry('pipeline', w.describe(), dt, 3, w.npix, km,
+                  valu_roofline(roof('pipeline', 'nlmeans', w.dom, km, w.alg_bytes),
+                                w.npix * w.k * 4 * nq_t,
+                                '146 dependent float32 additions per output (three dates x 7 x 7 window, the '
+                                'reference\'s visiting order), packed over two outputs'),
                   res['bad'] == 0 and res['change_bad'] == 0, sample=res)
         del w, ch
         _free()
@@ -980,6 +1014,9 @@ def main():
             res['roofline'] = roofline(dom_k, avg[dom_k], w.alg_bytes, traffic=traffic, traffic_source=source,
                                        note='algorithmic bytes = planes read once + change map written once'
                                        if w.name != 'pipeline' else 'algorithmic bytes = filter input + output')
+            if w.name == 'pipeline':
+                res['roofline'] = valu_roofline(res['roofline'], w.npix * w.k * 4 * (3 * 7 * 7 - 1),
+                                                '146 dependent float32 additions per output, packed over two outputs')
         if world == 1 and w.name == 'omnibus':
             res['transfer'] = transfer_rates(dev)
             if args.cpu_rows > 0:

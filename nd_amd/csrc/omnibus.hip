@@ -832,167 +832,6 @@ struct OmniDenseArgs {
 // (log2_parts, the screen registers and dense_x live in omnibus_common.hpp: the full-pol kernels use them too)
 
 
-// nd/_change.pyx:224-257 for one pixel per lane, on a series held in registers (static indices
-// only).  Per segment start l the reference evaluates the global test over ts[l:] and then the
-// marginal tests over ts[l:l+j], j = 2, 3, ... up to the first one that fires.
-//
-// Phase 1 (one backward pass over the dates) decides the global test of EVERY l from suffix sums
-//   kept in double.  The reference forms the same sums forward in `floating`; the two differ by
-//   rounding only, and that difference is bounded per pixel:
-//       |det_ref - det| <= 5 n u s11 s22      (n = k - l terms, u = 2^-24 (T = float) / 2^-53;
-//                                              forward-summation bound gamma_(n-1) on s11, s22 and,
-//                                              through Cauchy-Schwarz, on s12; plus the five roundings
-//                                              of the determinant itself)
-//   which widens the screen's band by m2 = 1.46 j 5 n u (s11 s22 / det) in log2 units.  Outside
-//   the widened band the decision is certain; inside, the pixel is handed to pass B.
-// Phase 2 walks the segments forward (static unroll over l; a lane takes part in row l when its
-//   segment starts there).  The marginal sums are the reference's own additions in the
-//   reference's order (0 + a_l + a_l+1 + ...), so their determinant is bit-identical to the
-//   reference's and only the logarithms are approximate (tight band).  Rows stop accumulating as
-//   soon as every participating lane has found its first firing marginal -- at low thresholds
-//   that is after the first step.
-// The double product of determinants is replaced by exact integer sums of per-date logarithms.
-// A test is decided from x = log2(prod) - j log2(det of sum) - R(j) against the host's bounds
-// (DenseScreenEntry, read from LDS); a lane whose x falls between them -- or whose data leaves the
-// domain in which x is meaningful -- stops and is reported in `handoff` (pass B redoes the pixel
-// exactly).
-//   mask: bit t set <=> change detected at date t (valid for lanes with !handoff)
-// The screen's per-j constants live in four registers of every wave, entry j in lane j - 1, and are
-// fetched with v_readlane (a few cycles, no memory access; the index is wave-uniform).
-// (Parking the per-date logarithms in LDS between the two phases saves 48 registers but puts an
-// LDS round trip into every row of phase 2: measured slower.)
-template <typename T, int KMAX>
-__device__ __forceinline__ void dense_search(const T (&v)[KMAX][4], const int k, const bool active,
-                                             const ScreenRegs &scr, unsigned &mask_out,
-                                             bool &handoff_out)
-{
-    static_assert(KMAX <= kDenseMax, "screen table too small");
-    int le[KMAX], lm[KMAX];
-    bool bad = false;
-    int eabs = 0;
-    unsigned gF = 0, gI = 0;           // bit l: global test of ts[l:] fires / is undecided
-    {
-        double S11 = 0.0, S12r = 0.0, S12i = 0.0, S22 = 0.0;
-        int Le = 0, Lm = 0;
-        const float cu = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 7.5f;   // 1.46 * 5 u, rounded up
-#pragma unroll
-        for (int t = KMAX - 1; t >= 0; --t) {
-            // branch-free: elements beyond k hold a copy of a valid date and are masked out.  The
-            // instantiation for KMAX serves KMAX - 8 < k <= KMAX (2 <= k for KMAX = 8), so the
-            // early dates are known to be inside the series.
-            constexpr int kmin = KMAX == 8 ? 2 : KMAX - 7;
-            const bool in = (t < kmin) || (t < k);
-            const T det = (v[t][0] * v[t][3]) - ((v[t][1] * v[t][1]) + (v[t][2] * v[t][2]));
-            const bool ok = (det > (T)0) && (det < (T)INFINITY) && (v[t][0] > (T)0);
-            bad = bad || (in && !ok);
-            int e;
-            float m;
-            log2_parts(ok ? det : (T)1, e, m);
-            const int le_t = in ? e : 0;
-            const int lm_t = in ? (int)rintf(m * kLogFix) : 0;
-            le[t] = le_t;
-            lm[t] = lm_t;
-            eabs += le_t < 0 ? -le_t : le_t;
-            S11 += in ? (double)v[t][0] : 0.0;
-            S12r += in ? (double)v[t][1] : 0.0;
-            S12i += in ? (double)v[t][2] : 0.0;
-            S22 += in ? (double)v[t][3] : 0.0;
-            Le += le_t;
-            Lm += lm_t;
-            if (t < KMAX - 1 && t < k - 1) {                 // global test of ts[t:], j = k - t >= 2
-                const int jj = k - t;
-                const double pp = S11 * S22;
-                const double dets = pp - ((S12r * S12r) + (S12i * S12i));
-                const bool okd = (dets > 0.0) && (dets < (double)INFINITY);
-                const DenseScreenEntry c = screen_entry(scr, jj);
-                const float x = dense_x<double>(dets, okd, Le, Lm, jj, c);
-                // rounding of the reference's float sums: relative bound on its determinant
-                const float q = (float)pp * __builtin_amdgcn_rcpf((float)dets);
-                const float rel = cu * (float)jj * q;          // 1.46 * 5 n u * s11 s22 / det
-                const float m2 = (float)jj * rel * 1.01f;
-                const bool sane = okd && (rel < 0.01f);
-                const bool fires = sane && (x + m2 < c.a);
-                const bool cant = sane && (x - m2 > c.b);
-                gF |= fires ? (1u << t) : 0u;
-                gI |= (fires || cant) ? 0u : (1u << t);
-            }
-            // one date at a time: interleaving the evaluations of all dates for instruction-level
-            // parallelism costs more than 100 registers, i.e. half the waves
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // |log2| of every partial product stays below 900: the reference's double product neither
-    // overflows nor loses precision to subnormals, so its logarithm is what the sums here model
-    bad = bad || (eabs > 900);
-    bool handoff = active && bad;
-    bool done = !active || bad;
-    int cur = 0;
-    unsigned mask = 0;
-#pragma unroll
-    for (int l = 0; l < KMAX - 1; ++l) {
-        if (l < k - 1) {
-            bool act = !done && (cur == l);
-            if (__any(act)) {
-                if (act && ((gI >> l) & 1u)) {           // global test undecided: pass B's pixel
-                    handoff = true;
-                    done = true;
-                    act = false;
-                }
-                if (act && !((gF >> l) & 1u)) {          // :241-242
-                    done = true;
-                    act = false;
-                }
-                // (the reference's sums start from 0: 0 + a_l = a_l exactly, up to the sign of a zero
-                // cross term, which no product below can see)
-                T s11 = v[l][0], s12r = v[l][1], s12i = v[l][2], s22 = v[l][3];
-                int Le = le[l], Lm = lm[l];
-                int fire_at = -1;
-                bool open = __any(act);
-#pragma unroll
-                for (int t = l + 1; t < KMAX; ++t) {
-                    if (open && t < k) {
-                        const int2 lg = make_int2(le[t], lm[t]);
-                        s11 = s11 + v[t][0];
-                        s12r = s12r + v[t][1];
-                        s12i = s12i + v[t][2];
-                        s22 = s22 + v[t][3];
-                        Le += lg.x;
-                        Lm += lg.y;
-                        const bool need = act && fire_at < 0;
-                        if (t == k - 1) {
-                            // the marginal test over all of ts[l:] IS the global test, which fires
-                            if (need) fire_at = t;
-                        } else {
-                            const int jj = t - l + 1;
-                            const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                            const bool ok = (dets > (T)0) && (dets < (T)INFINITY);
-                            const DenseScreenEntry c = screen_entry(scr, jj);
-                            const float x = dense_x<T>(dets, ok, Le, Lm, jj, c);
-                            const bool fires = ok && (x < c.a);
-                            const bool cant = ok && (x > c.b);
-                            if (need && !(fires || cant)) {       // undecided: pass B's pixel
-                                handoff = true;
-                                done = true;
-                                act = false;
-                            }
-                            if (act && need && fires) fire_at = t;
-                        }
-                        open = __any(act && fire_at < 0);
-                    }
-                }
-                if (act) {                             // fire_at >= l + 1
-                    mask |= 1u << fire_at;             // :252, l + r with r = j - 1
-                    cur = fire_at;                     // :255
-                    if (cur >= k - 1) done = true;     // :256
-                }
-            }
-        }
-    }
-    mask_out = mask;
-    handoff_out = handoff;
-}
-
-
 // One lane's whole row of the change map from its mask: every byte is written.
 __device__ __forceinline__ void store_change_row(uint8_t *res, const int k, const unsigned long long mask)
 {
@@ -1087,143 +926,6 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
             }
         }
     }
-}
-
-// -----------------------------------------------------------------------------------------
-// pass A with the search fused in (low thresholds: most waves are dense).  Same loads as
-// omnibus_c2_retain_kernel; a wave in which at least `dense_min` pixels pass the global screen
-// searches all its pixels right away from the registers the series already sits in and writes
-// their rows of the change map whole -- the planes are read once and neither the dense list nor a
-// second kernel is involved.  Sparser waves list their candidates for pass B as usual.
-// Two blocks per CU (the search needs ~250 registers), against four for the plain pass A: this
-// form is chosen by the host when the threshold makes dense waves the rule (alpha < 0.75).
-// -----------------------------------------------------------------------------------------
-template <typename T, int KMAX, bool EXACT>
-__global__ void __launch_bounds__(kRetainThreads, 2)
-omnibus_c2_fused_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const DenseScreen scr_arg)
-{
-    if (omni_gate_skip(g)) return;
-    __shared__ DenseScreenEntry scr_lds[kDenseMax + 1];
-    __shared__ __align__(16) uint32_t out_img[(kRetainThreads / 64) * 16 * KMAX];   // store_change_rows_wave
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int64_t b = blockIdx.x;
-    const int64_t row = b / g.blocks_per_row;
-    const int64_t bx = b - row * g.blocks_per_row;
-    const int64_t bpx0 = bx * (int64_t)kRetainThreads;
-    const int64_t x0 = bpx0 + tid;
-    const int k = EXACT ? KMAX : g.k;
-    const bool in = x0 < g.nx;
-
-    // ---- issue every load of the series (as in omnibus_c2_retain_kernel) ----
-    T v[KMAX][4];
-    if (EXACT) {
-        const int64_t ub = row * g.sy + bpx0;
-        const unsigned lx = in ? (unsigned)tid : (unsigned)(g.nx - 1 - bpx0);   // idle lanes re-read the last pixel
-        const unsigned voff = lx * (unsigned)sizeof(T);
-        const auto r11 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c11 + ub), 0, 0x7fffffff, 0x00020000);
-        const auto r12r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12r + ub), 0, 0x7fffffff, 0x00020000);
-        const auto r12i = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c12i + ub), 0, 0x7fffffff, 0x00020000);
-        const auto r22 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(g.c22 + ub), 0, 0x7fffffff, 0x00020000);
-        const unsigned sstep = (unsigned)g.st * (unsigned)sizeof(T);   // host guarantees k * st * sizeof(T) < 2^31
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t) {
-            const unsigned soff = (unsigned)t * sstep;
-            v[t][0] = buffer_load<T>(r11, voff, soff);
-            v[t][1] = buffer_load<T>(r12r, voff, soff);
-            v[t][2] = buffer_load<T>(r12i, voff, soff);
-            v[t][3] = buffer_load<T>(r22, voff, soff);
-        }
-    } else {
-        const int64_t xc = in ? x0 : g.nx - 1;
-        const int64_t off0 = row * g.sy + xc * g.sx;
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t) {
-            const int64_t off = off0 + (int64_t)(t < k ? t : k - 1) * g.st;    // no per-date branch
-            v[t][0] = __builtin_nontemporal_load(g.c11 + off);
-            v[t][1] = __builtin_nontemporal_load(g.c12r + off);
-            v[t][2] = __builtin_nontemporal_load(g.c12i + off);
-            v[t][3] = __builtin_nontemporal_load(g.c22 + off);
-        }
-    }
-    if (tid == 0) {
-#pragma unroll
-        for (int j = 0; j <= KMAX; ++j) scr_lds[j] = scr_arg.e[j];      // static indices only
-    }
-    if (g.write_tab && b == 0) {
-        for (int j = tid; j <= k; j += kRetainThreads) g.tab_dev[j] = tab.e[j];
-    }
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);      // keep the loads together, ahead of every use
-
-    // ---- global screen of the whole series: is this wave dense? ----
-    Accum<T> A;
-    A.reset();
-#pragma unroll
-    for (int t = 0; t < KMAX; ++t)
-        if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
-    const bool flag = in && (z_approx<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
-    const unsigned long long m = __ballot(flag);
-    const unsigned shard = (unsigned)(b % kShards);
-    const int64_t wpx0 = bpx0 + (tid & ~63);                  // first pixel of this wave in its row
-    const int64_t wleft = g.nx - wpx0;
-    const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
-    uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
-
-    bool listed = flag;                                       // pixels that go to pass B
-    const bool dense = __popcll(m) >= g.dense_min;
-    if (dense) {
-        unsigned mask;
-        bool handoff;
-        // (k as a run-time value even when it is known to equal KMAX: with every guard folded
-        // away the search becomes one straight block whose scheduling spills ~230 registers)
-        int ks = g.k;
-        asm volatile("" : "+s"(ks));
-        const ScreenRegs scr = screen_regs_load(scr_lds, lane);
-        dense_search<T, KMAX>(v, ks, in, scr, mask, handoff);
-        if (handoff) mask = 0u;                               // pass B writes that pixel's changes
-        if (change_rows_wave_ok(wob, k, wnp)) {
-            store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * KMAX), k, mask, lane);
-        } else if (in) {
-            uint8_t *res = wob + (int64_t)lane * k;
-            if ((k & 3) == 0 && ((uintptr_t)res & 3) == 0) {
-                uint32_t *w = reinterpret_cast<uint32_t *>(res);
-#pragma unroll
-                for (int q = 0; q < KMAX / 4; ++q)
-                    if (q < (k >> 2)) w[q] = (((mask >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
-            } else {
-                for (int t = 0; t < k; ++t) res[t] = (uint8_t)((mask >> t) & 1u);
-            }
-        }
-        listed = handoff;
-    }
-    if (__any(listed)) {
-        const unsigned long long lm_ = __ballot(listed);
-        unsigned base = 0;
-        if (lane == 0)
-            base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(lm_));
-        base = __shfl(base, 0);
-        if (listed) {
-            const unsigned slot = base + (unsigned)__popcll(lm_ & ((1ull << lane) - 1ull));
-            g.flag_idx[(size_t)shard * g.seg + slot] = (uint32_t)(row * g.nx + x0);
-            if (slot < g.dump_cap) {
-                T *d = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k);
-#pragma unroll
-                for (int t = 0; t < KMAX; ++t) {
-                    if (EXACT || t < k) {
-                        Pack<T, 4> q;
-                        q.v[0] = v[t][0];
-                        q.v[1] = v[t][1];
-                        q.v[2] = v[t][2];
-                        q.v[3] = v[t][3];
-                        *reinterpret_cast<Pack<T, 4> *>(d + 4 * t) = q;
-                    }
-                }
-            }
-        }
-    }
-    // ---- a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275)
-    if (!dense && wnp > 0) zero_fill_span(wob, wnp * k, lane);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -2710,274 +2412,6 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
 }
 
 // -----------------------------------------------------------------------------------------
-// pass B, register form (k <= 32 float / 16 double): the listed pixel's series sits in registers,
-// not in LDS, and the wave walks the dates 0 .. k-1 TOGETHER, once per round of segments:
-//
-//   round r: every unfinished lane folds the dates of its CURRENT segment [l, k) -- dates before l
-//            are masked to zero, so a lane's running sums are (0 + a_l) + a_l+1 + ... in
-//            `floating`, the reference's own additions in its order (nd/_change.pyx:64-69), and the
-//            date index is wave-uniform: register arrays with static indices, straight-line code
-//            the scheduler can interleave.  Per date one test per lane at most (the marginal test
-//            over ts[l:t+1] while none has fired, the global test at the last date), decided by the
-//            float32 / integer screen of dense_search (exact integer sums of per-date log2 parts
-//            instead of the double product, DenseScreenEntry); after the last date a lane commits
-//            its first firing date if the global test fired (nd/_change.pyx:247-256) and starts the
-//            next segment there.
-//   A test the screen cannot decide (about 3e-5 of them) pauses its lane for the rest of the
-//            round.  Behind the unrolled dates, under a WAVE-UNIFORM branch, the wave re-folds
-//            that test with the reference's double product of determinants, evaluates it exactly
-//            (exact_test) and notes the verdict in a pair of bit masks; the segment is then walked
-//            again with the verdict in place of the screen.  The branch is uniform and ends by
-//            loading the series again (from the dump, L2-resident) so that the series registers are
-//            dead while the double-precision log / exp / chi-square code runs: that code needs a
-//            hundred registers and would otherwise set the budget of the whole kernel (in a
-//            divergent branch the registers of the lanes that skip it stay live).
-//   A pixel outside the screen's domain altogether (a determinant <= 0 or non-finite, exponents
-//            summing beyond 900) is marked in `hand_bits` and left to the LDS form, which runs
-//            behind this kernel on the marked pixels only (it returns at once while `hand_count`
-//            says there are none).
-//
-// Against the LDS form: no 24.5 KB image per wave (3 waves per SIMD instead of 1.5) and no double
-// arithmetic in the loop.  Same decisions, same map.
-// -----------------------------------------------------------------------------------------
-// P(z over jj matrices) > alpha, evaluated with the reference's rounding points; `valid` = this
-// lane really has a test (the others ride along under the uniform branch and must not steer the
-// chi-square loop)
-template <typename T>
-__device__ __forceinline__ bool exact_test(const Accum<T> &A, const int jj, const double nlooks,
-                                           const OmniTabEntry *ep, const double alpha, const bool valid)
-{
-    const OmniTabEntry e = *ep;
-    const T zp = z_stat<T>(A, jj, nlooks, e);
-    const double zd = (double)zp;
-    // 0 = cannot fire (z < zlo, or NaN), 1 = fires for certain (zhi < z < inf), 2 = inside the
-    // exact band: needs the chi-square pair
-    int verdict = !valid ? 0 : (!(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2));
-    if (verdict == 2) {
-        double zv[1] = {zd}, P1[1], P2[1];
-        chisq_pair<1>(zv, 4 * (jj - 1), e.lgam, P1, P2);
-        const T P = combine_P<T>(P1[0], P2[0], e.omega2);
-        verdict = ((double)P > alpha) ? 1 : 0;
-    }
-    return verdict == 1;
-}
-
-// waves per SIMD the register budget is held to
-template <typename T, int KMAX>
-constexpr int search_regs_waves()
-{
-    return KMAX * 4 * (int)sizeof(T) / 4 <= 96 ? 3 : 2;
-}
-
-template <typename T, int KMAX>
-__global__ void __launch_bounds__(64, (search_regs_waves<T, KMAX>()))
-omnibus_c2_search_regs_kernel(const OmniSearchArgs<T> s, const DenseScreen scr_arg)
-{
-    static_assert(KMAX <= 32, "the change and verdict masks are 32 bits wide");
-    __shared__ DenseScreenEntry scr_lds[KMAX + 1];
-    const int lane = threadIdx.x;
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j <= KMAX; ++j) scr_lds[j] = scr_arg.e[j];      // static indices only
-    }
-    __syncthreads();
-    // (opaque copy of k: the per-date predicates would otherwise be hoisted out of the loops)
-    int k = s.k;
-    asm volatile("" : "+s"(k));
-    const unsigned shard = blockIdx.x % kShards;
-    const unsigned lblock = blockIdx.x / kShards;
-    const unsigned nlblock = gridDim.x / kShards;
-    const uint32_t n = s.flag_count[shard * kCounterStride];
-    if (n <= s.starts_max) return;             // omnibus_c2_search_starts_kernel searches this shard
-    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
-
-    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
-        const uint32_t idx = base + lane;
-        const bool active = idx < n;
-        const int64_t pix = active ? (int64_t)list[idx] : 0;
-
-        // ---- the series, every load in flight at once ----
-        // (one base address + constant offsets from the dump; four running pointers over the
-        // planes: a 64-bit address per date and plane would not fit the register budget)
-        T v[KMAX][4];
-        auto load_series = [&]() {
-            if (idx < s.dump_cap) {
-                const T *d = s.dump + ((int64_t)shard * s.dump_cap + idx) * (int64_t)(4 * k);
-#pragma unroll
-                for (int t = 0; t < KMAX; ++t) {
-                    if (t < k) {
-                        const Pack<T, 4> q = *reinterpret_cast<const Pack<T, 4> *>(d + 4 * t);
-                        v[t][0] = q.v[0];
-                        v[t][1] = q.v[1];
-                        v[t][2] = q.v[2];
-                        v[t][3] = q.v[3];
-                    } else {
-                        // (every element defined by every call: nothing of an earlier load stays live)
-                        v[t][0] = v[t][1] = v[t][2] = v[t][3] = (T)0;
-                    }
-                }
-            } else {
-                const int64_t row = pix / s.nx;
-                const int64_t col = pix - row * s.nx;
-                const int64_t off = row * s.sy + col * s.sx;
-                const T *p11 = s.c11 + off * s.m11, *p12r = s.c12r + off * s.m12;
-                const T *p12i = s.c12i + off * s.m12, *p22 = s.c22 + off * s.m22;
-                const int64_t d11 = s.st * s.m11, d12 = s.st * s.m12, d22 = s.st * s.m22;
-#pragma unroll
-                for (int t = 0; t < KMAX; ++t) {
-                    if (t < k) {
-                        v[t][0] = *p11;
-                        v[t][1] = *p12r;
-                        v[t][2] = *p12i;
-                        v[t][3] = *p22;
-                        p11 += d11;
-                        p12r += d12;
-                        p12i += d12;
-                        p22 += d22;
-                    } else {
-                        v[t][0] = v[t][1] = v[t][2] = v[t][3] = (T)0;
-                    }
-                }
-            }
-        };
-        load_series();
-
-        // ---- is the pixel inside the screen's domain?  every determinant positive and finite, and
-        // |log2| of every partial product below 900: the reference's double product of determinants
-        // is then a normal number, and the integer sums of the walk model its logarithm
-        bool handoff = false;
-        {
-            int eabs = 0;
-#pragma unroll
-            for (int t = 0; t < KMAX; ++t) {
-                if (t < k) {
-                    const T det = (v[t][0] * v[t][3]) - ((v[t][1] * v[t][1]) + (v[t][2] * v[t][2]));
-                    const bool okd = (det > (T)0) && (det < (T)INFINITY) && (v[t][0] > (T)0);
-                    int e0;
-                    float mf;
-                    log2_parts(okd ? det : (T)1, e0, mf);
-                    eabs += e0 < 0 ? -e0 : e0;
-                    handoff = handoff || !okd;
-                }
-            }
-            handoff = active && (handoff || eabs > 900);
-        }
-
-        bool done = !active || handoff;
-        int l = 0;                 // segment start
-        unsigned cmask = 0u;       // bit t: change detected at date t
-        unsigned ov_m = 0u, ov_f = 0u;   // tests of the current segment decided exactly: which, verdict
-        while (__any(!done)) {
-            T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
-            int Le = 0, Lm = 0;
-            int fire_at = -1;      // first date of this segment whose marginal test fired
-            int und_t = -1;        // date of a test the screen could not decide: lane paused
-            bool gfire = false;    // the global test of ts[l:] fired
-            // The dates in front of every unfinished lane's segment are skipped.  Most lanes are
-            // finished after two rounds; the few whose series keeps firing (half a dozen rounds in
-            // a typical wave) start late in the series, so the later rounds are short.
-            int lmin = done ? KMAX : l;
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) {
-                const int o = __shfl_xor(lmin, sh);
-                lmin = o < lmin ? o : lmin;
-            }
-            lmin = __builtin_amdgcn_readfirstlane(lmin);
-#pragma unroll
-            for (int t = 0; t < KMAX; ++t) {
-                if (t < k && t >= lmin) {
-                    const bool in_seg = !done && (und_t < 0) && (t >= l);
-                    const T a = in_seg ? v[t][0] : (T)0, b = in_seg ? v[t][1] : (T)0;
-                    const T c = in_seg ? v[t][2] : (T)0, d = in_seg ? v[t][3] : (T)0;
-                    const T det = (a * d) - ((b * b) + (c * c));
-                    int e0;
-                    float mf;
-                    log2_parts(in_seg ? det : (T)1, e0, mf);          // (masked dates: e0 + mf = 0, as two parts)
-                    const int m0 = (int)rintf(mf * kLogFix);
-                    s11 = s11 + a;
-                    s12r = s12r + b;
-                    s12i = s12i + c;
-                    s22 = s22 + d;
-                    Le += in_seg ? e0 : 0;
-                    Lm += in_seg ? m0 : 0;
-                    const int jj = t - l + 1;
-                    const bool last = (t == k - 1);
-                    // a marginal test while none has fired yet (j >= 2); at the last date the same
-                    // evaluation is the global test, needed even if a marginal fired earlier
-                    const bool need = in_seg && (jj >= 2) && (fire_at < 0 || last);
-                    if (__any(need)) {
-                        if (need) {
-                            bool fires;
-                            if ((ov_m >> t) & 1u) {
-                                fires = (ov_f >> t) & 1u;
-                            } else {
-                                const T dets = (s11 * s22) - ((s12r * s12r) + (s12i * s12i));
-                                const bool ok = (dets > (T)0) && (dets < (T)INFINITY);
-                                const DenseScreenEntry ce = scr_lds[jj];
-                                const float x = dense_x<T>(dets, ok, Le, Lm, jj, ce);
-                                fires = ok && (x < ce.a);
-                                const bool cant = ok && (x > ce.b);
-                                if (!(fires || cant)) und_t = t;       // exact evaluation behind the dates
-                            }
-                            if (fires && fire_at < 0) fire_at = t;
-                            if (last) gfire = fires;
-                        }
-                    }
-                }
-            }
-            if (__any(und_t >= 0)) {
-                // WAVE-UNIFORM from here to the reload: every lane goes through the exact
-                // evaluation (lanes without an undecided test with valid = false).
-                const bool valid = und_t >= 0;
-                const int te = valid ? und_t : l;
-                Accum<T> A;
-                A.reset();
-#pragma unroll
-                for (int u = 0; u < KMAX; ++u)
-                    if (u < k) {
-                        if (u >= l && u <= te) A.step(v[u][0], v[u][1], v[u][2], v[u][3]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);             // the series is dead from here on
-                int jj = te - l + 1;
-                jj = jj < 1 ? 1 : (jj > k ? k : jj);
-                const bool f = exact_test<T>(A, jj, s.nlooks, s.tab + jj, s.alpha, valid);
-                if (valid) {
-                    ov_m |= 1u << und_t;
-                    ov_f |= f ? (1u << und_t) : 0u;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                load_series();
-            } else if (true) {
-                // (no undecided test in the wave: commit)
-            }
-            if (!done && und_t < 0) {
-                if (gfire) {
-                    cmask |= 1u << fire_at;                // :252, l + r with r = j - 1
-                    l = fire_at;                           // :255
-                    ov_m = 0u;
-                    ov_f = 0u;
-                    if (l >= k - 1) done = true;           // :256
-                } else {
-                    done = true;                           // :241-242
-                }
-            }
-        }
-        {
-            const unsigned long long hm = __ballot(handoff);
-            if (lane == 0) {
-                s.hand_bits[(size_t)shard * s.hand_words + (base >> 6)] = hm;
-                if (hm != 0ull) atomicAdd(s.hand_count, (unsigned)__popcll(hm));
-            }
-        }
-        if (active && !handoff) {
-            uint8_t *res = s.change + pix * (int64_t)k;
-            for (int u = 1; u < k; ++u)                    // the row was zero-filled by pass A
-                if ((cmask >> u) & 1u) res[u] = 1;
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------------------
 // pass B, chain form (k <= 32 float / 16 double; round 3): dense_chain on the listed pixel's
 // series -- one backward pass for the global tests, one forward pass for the marginal tests and
 // the restarts, ~105 vector instructions per date, against one round of the register form above
@@ -3183,37 +2617,6 @@ static void launch_retain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, int6
 }
 
 template <typename T, int KMAX>
-static void launch_fused_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const DenseScreen &scr,
-                           int64_t nblocks, hipStream_t stream)
-{
-    const dim3 grid((unsigned)nblocks), block(kRetainThreads);
-    if (g.k == KMAX && g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0)
-        hipLaunchKernelGGL((omnibus_c2_fused_kernel<T, KMAX, true>), grid, block, 0, stream, g, tab, scr);
-    else
-        hipLaunchKernelGGL((omnibus_c2_fused_kernel<T, KMAX, false>), grid, block, 0, stream, g, tab, scr);
-}
-
-// k <= 32 (float) / 16 (double): the series lengths dense_search is instantiated for
-template <typename T>
-static void launch_fused(const OmniGlobalArgs<T> &g, const OmniTab &tab, const DenseScreen &scr,
-                         int64_t nblocks, hipStream_t stream)
-{
-    const int k = g.k;
-    if (k <= 8)
-        launch_fused_k<T, 8>(g, tab, scr, nblocks, stream);
-    else if (k <= 16)
-        launch_fused_k<T, 16>(g, tab, scr, nblocks, stream);
-    else if (sizeof(T) == 4) {
-        if (k <= 24)
-            launch_fused_k<float, 24>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, scr,
-                                      nblocks, stream);
-        else
-            launch_fused_k<float, 32>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, scr,
-                                      nblocks, stream);
-    }
-}
-
-template <typename T, int KMAX>
 static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const StreamScreen<chain_nj(KMAX)> &ss,
                            int64_t nblocks, hipStream_t stream)
 {
@@ -3275,9 +2678,12 @@ static void launch_retain(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_
 }
 
 // ND_AMD_FUSED_FORM: which fused search serves the thresholds below the sparse regime -- 0 the
-// streaming search, 1 the triangle of dense_search on the retained series, 2 dense_chain on the
-// retained series, 3 dense_chain in two streaming passes (longer series); unset (-1): by threshold
-// and series length.  Speed only: every form gives the same map.
+// streaming search, 2 dense_chain on the retained series, 3 dense_chain in two streaming passes
+// (longer series); unset (-1): by threshold and series length.  Speed only: every form gives the same
+// map.  (Form 1, the triangle of dense_search on the retained series -- 3.9 - 5.4 ms where the chain
+// form takes 1.55 -- and the round-based register form of pass B, ND_AMD_SEARCH_MODE=2 -- 0.097 ms
+// where the chain form takes 0.081 -- lost at every threshold and series length and were deleted in
+// round 4.)
 static int fused_form_env()
 {
     static const int v = [] {
@@ -3552,7 +2958,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         if (per_shard < 1) per_shard = 1;
         const int64_t sblocks = per_shard * kShards;
         static const int mode_env = [] {
-            const char *e = getenv("ND_AMD_SEARCH_MODE");     // 0 LDS image, 1 from memory, 2 registers
+            const char *e = getenv("ND_AMD_SEARCH_MODE");     // 0 LDS image, 1 from memory, 3 chain form
             return e ? atoi(e) : -1;
         }();
         // The register form serves the series lengths of dense_search, as long as the screen can
@@ -3583,9 +2989,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
             hipLaunchKernelGGL((omnibus_c2_search_starts_kernel<T>), dim3((unsigned)sblocks), dim3(64), 0, sq, s);
         }
-        // ND_AMD_SEARCH_MODE: 0 LDS image, 1 from memory, 2 register form (rounds), 3 chain form
+        // ND_AMD_SEARCH_MODE: 0 LDS image, 1 from memory, 3 chain form (the default where it exists)
         const bool chain_form = regs_ok && (mode_env == 3 || mode_env < 0);
-        const bool regs_form = regs_ok && mode_env == 2;
         if (chain_form) {
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
             s.hand_bits = hand;
@@ -3602,23 +3007,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 hipLaunchKernelGGL((omnibus_c2_search_chain_kernel<float, 32>), gr, bl, 0, sq,
                                    reinterpret_cast<const OmniSearchArgs<float> &>(s), ss0);
         }
-        if (regs_form) {
-            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
-            s.hand_bits = hand;
-            const dim3 gr((unsigned)sblocks), bl(64);
-            if (k <= 8)
-                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<T, 8>), gr, bl, 0, sq, s, scr);
-            else if (k <= 16)
-                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<T, 16>), gr, bl, 0, sq, s, scr);
-            else if (sizeof(T) == 4 && k <= 24)
-                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<float, 24>), gr, bl, 0, sq,
-                                   reinterpret_cast<const OmniSearchArgs<float> &>(s), scr);
-            else if (sizeof(T) == 4)
-                hipLaunchKernelGGL((omnibus_c2_search_regs_kernel<float, 32>), gr, bl, 0, sq,
-                                   reinterpret_cast<const OmniSearchArgs<float> &>(s), scr);
-        }
         // the exact form: every listed pixel, or (behind a register form) the marked ones
-        KernelTimer timer((chain_form || regs_form || starts_form) ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
+        KernelTimer timer((chain_form || starts_form) ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
         if (chain_form && k <= 65) {
             // the marked pixels one lane per segment start: their number is small, the time of
             // this step is the dependent chain of one wave
@@ -3627,7 +3017,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }
         // (behind the register form there is usually nothing left: the from-memory form, whose
         // blocks reserve no LDS, and a quarter of the blocks)
-        const bool behind = chain_form || regs_form;
+        const bool behind = chain_form;
         const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !behind) ? 0 : 1);
         const int64_t xblocks = behind ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
         if (mode == 0 && use_lds)
@@ -3848,13 +3238,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // 1e-4); above, dense_chain costs the same at every threshold (1.55 ms) where the streaming
         // search's deep searches take 2.5 ms at 0.05 and 4.6 at 0.2 (24 x 4096^2).
         const int fused_form = fused_form_env();
-        const bool regs_form = fused_form == 1;
         const bool chain_form = fused_form == 2 || (fused_form < 0 && alpha > 0.02);
         if (chain_form) {
             launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream);
-        } else
-        if (regs_form) {
-            launch_fused<T>(g, tab, scr, nblocks, stream);
         } else {
             const dim3 grid((unsigned)nblocks), block(kRetainThreads);
             constexpr int PF = sizeof(T) == 4 ? 6 : 4;

@@ -192,23 +192,36 @@ def test_dense_thresholds_whole_raster_equals_oracle(oracle, stack, alpha):
     assert (want.sum(axis=2) > 0).mean() > 0.4
 
 
-@pytest.mark.parametrize('env', [{'ND_AMD_FUSED_FORM': '0'}, {'ND_AMD_FUSED_FORM': '1'}, {'ND_AMD_FUSED_FORM': '2'},
-                                 {'ND_AMD_SEARCH_STARTS': '0'}, {'ND_AMD_PM_STREAM_LDS': '0', 'ND_AMD_FUSED_FORM': '0'},
-                                 {'ND_AMD_FUSED_ALPHA': '0'}, {'ND_AMD_PM_FORM': '1'}, {'ND_AMD_PM_DIRECT': '0'},
-                                 {'ND_AMD_GATE': '0'}, {'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '1'},
-                                 {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_FUSED_FORM': '0'},
-                                 {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '0'},
-                                 {'ND_AMD_PM_STREAM_SECTOR': '0', 'ND_AMD_FUSED_FORM': '0'},
-                                 {'ND_AMD_PM_STREAM_SECTOR': '1', 'ND_AMD_FUSED_FORM': '0'},
-                                 {'ND_AMD_SEARCH_MODE': '0'}, {'ND_AMD_SEARCH_MODE': '1'},
-                                 {'ND_AMD_SEARCH_MODE': '2'}, {'ND_AMD_SEARCH_MODE': '2', 'ND_AMD_FUSED_ALPHA': '0'}])
-def test_every_kernel_form_gives_the_same_map(env):
-    """The library picks among several forms of the low-threshold search by alpha and by a sample of
-    the data (streaming fused, register fused, separate dense kernel, gate on / off; LDS-DMA or
-    register-staged pixel-major pass A; pixel-major streaming search from memory or from LDS images).  The choice is about speed only: force each form in a
-    fresh process and compare with the oracle.  ND_AMD_SEARCH_MODE: pass B from its LDS image / from
-    memory / from registers (with the exact form behind it), also with every pixel of a
-    low-threshold run going through pass B (ND_AMD_FUSED_ALPHA=0)."""
+_FORMS_24 = [{'ND_AMD_FUSED_FORM': '0'}, {'ND_AMD_FUSED_FORM': '2'},
+             {'ND_AMD_SEARCH_STARTS': '0'}, {'ND_AMD_PM_STREAM_LDS': '0', 'ND_AMD_FUSED_FORM': '0'},
+             {'ND_AMD_FUSED_ALPHA': '0'}, {'ND_AMD_PM_FORM': '1'}, {'ND_AMD_PM_DIRECT': '0'},
+             {'ND_AMD_GATE': '0'}, {'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '0'},
+             {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_FUSED_FORM': '0'},
+             {'ND_AMD_PM_STREAM_LDS': '1', 'ND_AMD_GATE': '0', 'ND_AMD_FUSED_FORM': '0'},
+             {'ND_AMD_PM_STREAM_SECTOR': '0', 'ND_AMD_FUSED_FORM': '0'},
+             {'ND_AMD_PM_STREAM_SECTOR': '1', 'ND_AMD_FUSED_FORM': '0'},
+             {'ND_AMD_SEARCH_MODE': '0'}, {'ND_AMD_SEARCH_MODE': '1'},
+             {'ND_AMD_SEARCH_MODE': '0', 'ND_AMD_FUSED_ALPHA': '0'}]
+# the forms that exist at the other series lengths: 12 dates (every form, reference layout included),
+# 48 and 96 dates (planar only: streaming search with 64- / 128-bit masks, the chain search in two
+# streaming passes, pass B from its LDS image / from memory / one lane per segment start, no fusion)
+_FORMS_12 = [{}, {'ND_AMD_FUSED_FORM': '0', 'ND_AMD_PM_DIRECT': '0'}, {'ND_AMD_FUSED_FORM': '2', 'ND_AMD_PM_FORM': '1'},
+             {'ND_AMD_FUSED_ALPHA': '0', 'ND_AMD_SEARCH_MODE': '1'}]
+_FORMS_LONG = [{}, {'ND_AMD_FUSED_FORM': '0', 'ND_AMD_SEARCH_STARTS': '0'}, {'ND_AMD_FUSED_FORM': '3', 'ND_AMD_GATE': '0'},
+               {'ND_AMD_FUSED_ALPHA': '0', 'ND_AMD_SEARCH_MODE': '1'}]
+
+
+@pytest.mark.parametrize('k,env', [(24, e) for e in _FORMS_24] + [(12, e) for e in _FORMS_12] +
+                         [(48, e) for e in _FORMS_LONG] + [(96, e) for e in _FORMS_LONG])
+def test_every_kernel_form_gives_the_same_map(k, env):
+    """The library picks among several forms of the search by alpha, series length and a sample of the
+    data (streaming fused, chain fused in registers or in two streaming passes, separate dense kernel,
+    gate on / off; LDS-DMA or register-staged pixel-major pass A; pixel-major streaming search from
+    memory or from LDS images; pass B from its LDS image / from memory / chain form / one lane per
+    segment start).  The choice is about speed only: force each form in a fresh process, at 12, 24, 48
+    and 96 dates, and compare with the oracle -- also with every pixel of a low-threshold run going
+    through pass B (ND_AMD_FUSED_ALPHA=0).  (Round 4 deleted the forms that lost everywhere: the
+    register triangle ND_AMD_FUSED_FORM=1 and the round-based pass B ND_AMD_SEARCH_MODE=2.)"""
     import json
     import os
     import subprocess
@@ -216,13 +229,15 @@ def test_every_kernel_form_gives_the_same_map(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ)
     e.update(env)
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py'), '--ny', '512',
-                          '--nx', '2048', '--alphas', '1e-4,0.01,0.2,0.6,0.99', '--steps', '1',
-                          '--cpu-rows', '512', '--layouts', 'planar,pm'],
+    long_ = k > 24
+    layouts = 'planar' if long_ else 'planar,pm'
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py'), '--k', str(k), '--ny',
+                          '256' if long_ else '512', '--nx', '2048', '--alphas', '1e-4,0.01,0.2,0.6,0.99',
+                          '--steps', '1', '--cpu-rows', '256' if long_ else '512', '--layouts', layouts],
                          env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 10, out.stdout[-2000:]
+    assert len(lines) == (5 if long_ else 10), out.stdout[-2000:]
     for r in lines:
         assert r['bytes_differing'] == 0, r
 
