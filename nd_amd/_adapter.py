@@ -134,6 +134,8 @@ def safe_chunks(n, chunks, buffer=0):
     of the data, and xr_merge trims a full `buffer` from it).  The split arithmetic itself is the
     reference's; it has no such guard (nd/utils.py:305-340)."""
     n, chunks, buffer = int(n), max(1, int(chunks)), int(buffer)
+    if n <= 0:                            # an empty dimension: one (empty) chunk, as the reference's split yields
+        return 1
     while chunks > 1:
         cs = int(np.ceil(n / chunks))
         used = int(np.ceil(n / cs))

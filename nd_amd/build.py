@@ -33,7 +33,11 @@ FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=
 # instructions of one date of the streaming search were moves).  Without it: streaming search
 # 2.155 -> 2.089 ms, pass A 1.117 -> 1.082 ms (24 x 4096^2, tools/exp_ablate.py noslp).
 PER_FILE = {'nlmeans.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_NLM_FLAGS', '').split(),
-            'omnibus.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_OMNI_FLAGS', '').split()}
+            'omnibus.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_OMNI_FLAGS', '').split(),
+            # (omnibus_c3.hip: the pass moved 15 values per date between registers to pair scalar operations
+            #  of the 3 x 3 determinants; without it the streaming search needs 133 instead of 155 registers)
+            'omnibus_c3.hip': ['-fno-slp-vectorize'],
+            'omnibus_ml.hip': ['-fno-slp-vectorize']}
 
 
 def sources():

@@ -590,6 +590,17 @@ __device__ __forceinline__ void mask_push(unsigned &m, const bool bit)
     asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(cout) : "v"(m), "s"(cin));
     m = r;
 }
+// 64 bits: two of them, the carry of the low word (a lane mask in a scalar pair) feeding the high one
+__device__ __forceinline__ void mask_push(unsigned long long &m, const bool bit)
+{
+    const unsigned long long cin = __builtin_amdgcn_ballot_w64(bit);
+    unsigned long long c1, c2;
+    const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+    unsigned rlo, rhi;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(rlo), "=s"(c1) : "v"(lo), "s"(cin));
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(rhi), "=s"(c2) : "v"(hi), "s"(c1));
+    m = ((unsigned long long)rhi << 32) | rlo;
+}
 __device__ __forceinline__ void mask_push(Bits128 &m, const bool bit)
 {
     m.hi = (m.hi + m.hi) + (m.lo >> 63);

@@ -320,7 +320,11 @@ def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group
             status.bitwise_or_(scratch)
 
     first, last = lo, ny_ext - hi                  # the block's own rows inside `ext`
-    if pending is not None and pending.reqs:
+    # ND_AMD_HALO_OVERLAP=0: exchange first, then one launch over all rows.  The overlapped form has run
+    # on gloo groups and on ranks sharing one GPU only (no multi-GPU box in development): the switch is
+    # the way back should its stream semantics differ under RCCL.
+    import os
+    if pending is not None and pending.reqs and os.environ.get('ND_AMD_HALO_OVERLAP', '1') != '0':
         in_lo = first + (halo if lo else 0)        # rows whose windows stay inside the block
         in_hi = last - (halo if hi else 0)
         if in_hi > in_lo:

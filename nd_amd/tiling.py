@@ -246,6 +246,11 @@ def map_over_tiles(files, fn, args=(), kwargs=None, path=None, suffix='', merge=
         if os.path.abspath(result_of(f)) == os.path.abspath(f.rstrip('/')):
             raise ValueError('the result would overwrite its input: give `path` or `suffix`')
     produced = {os.path.abspath(result_of(f)) for f in files}
+    dropped = [f for f in files if os.path.abspath(f.rstrip('/')) in produced]
+    if dropped:
+        import warnings
+        warnings.warn('map_over_tiles: %d file(s) match the input pattern but are results of other inputs '
+                      '(name + suffix) and are not processed: %s' % (len(dropped), ', '.join(sorted(dropped)[:8])))
     files = [f for f in files if os.path.abspath(f.rstrip('/')) not in produced]
     if not files:
         raise ValueError('No input tiles left: every file is the result of another one')
