@@ -96,6 +96,7 @@ struct C3Args {
     uint32_t *flag_count, *flag_idx;
     uint32_t seg;
     OmniTabEntry *tab_dev;
+    uint32_t starts_max;      // lists of a shard up to this length are searched one lane per segment start
 };
 
 // ---- pass A ---------------------------------------------------------------------------------
@@ -444,7 +445,45 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
         for (int l = 0; l < k - 1; ++l) {
             const bool act = !done && (cur == l);
             if (!__any(act)) continue;
-            const bool gi = mask_bit(gI, l), gf = mask_bit(gF, l);
+            bool gi = mask_bit(gI, l), gf = mask_bit(gF, l);
+            // A global test the suffix sums cannot decide (their rounding band grows with the length of
+            // the segment: ~1 % of the pixels of a 48-date stack meet one) is decided from the reference's
+            // OWN sums instead of handing the pixel over: the dates of ts[l:] once more, added forward in
+            // `floating` -- bit-identical determinant, the tight band of the marginal tests.  (Round 4:
+            // pass B behind the streaming search gathered and searched those pixels whole: 0.66 ms.)
+            if (__any(act && gi)) {
+                if (act && gi) {
+                    T sg[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) sg[c] = (T)0;
+                    int Lg = 0;
+                    LmT Lmg = 0;
+                    for (int t0 = l; t0 < k; t0 += 2) {
+                        T qb[2][9];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) load(t0 + u < k ? t0 + u : k - 1, qb[u]);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (t0 + u < k) {
+#pragma unroll
+                                for (int c = 0; c < 9; ++c) sg[c] = sg[c] + qb[u][c];
+                                int e0;
+                                float mf;
+                                log2_parts(det3<T>(qb[u]), e0, mf);          // the pixel is not `bad`: det > 0
+                                Lg += e0;
+                                Lmg += (int)rintf(mf * kLogFix);
+                            }
+                        }
+                    }
+                    const int jj = k - l;
+                    const T dets = det3<T>(sg);
+                    const bool oks = (dets > (T)0) && (dets < (T)INFINITY);
+                    const DenseScreenEntry c = scr_lds[jj];
+                    const float x = dense_x<T>(dets, oks, Lg, Lmg, jj, c);
+                    gf = oks && (x < c.a);
+                    gi = !gf && !(oks && (x > c.b));
+                }
+            }
             const bool i2 = mask_bit(m2I, l), f2 = mask_bit(m2F, l);
             const bool i3 = mask_bit(m3I, l), f3 = mask_bit(m3F, l);
             int fire = -1;
@@ -587,6 +626,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
     const uint32_t n = s.flag_count[shard * kC3CounterStride];
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
     if (lblock * (unsigned)LANES >= n) return;            // nothing for this block
+    if (n <= s.starts_max) return;                        // a short list: omnibus_c3_search_starts_kernel's
     // per-j constants of the screen as four LDS arrays behind the series image (omnibus.hip): every
     // lane looks up its own j in every iteration
     const int kp = k + 1;
@@ -712,6 +752,120 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
     }
 }
 
+
+// ---- pass B, one lane per SEGMENT START (short lists behind the streaming search) ------------------
+// The full-pol counterpart of omnibus_c2_search_starts_kernel (omnibus.hip).  What the streaming search
+// hands over are a few thousand pixels of 8 M (2 070 at alpha = 0.01 on config 4's share), nearly every
+// date of them a change: the gather-and-sweep form above walks their 47 segments one after the other,
+// each to the end of the series -- 1 100 dependent date steps, 0.64 ms for any list, the time of ONE
+// wave.  Here lane l of a pixel's group sweeps ts[l:] once, on its own: nxt(l) = the date of the first
+// firing marginal test if the global test over ts[l:] fires, "stop" otherwise -- the same evaluations,
+// in the same order and arithmetic, as the sweep started at l.  The pixel's changes are the chain
+// 0 -> nxt(0) -> nxt(nxt(0)) ... (nd/_change.pyx:235-257), followed through wave shuffles.
+template <typename T>
+__global__ void __launch_bounds__(64) omnibus_c3_search_starts_kernel(const C3Args<T> s)
+{
+    // the series of the wave's pixels (gathered once, every load of a pixel in flight together: the
+    // sweeps then run without a memory access) and the per-j constants of the screen
+    __shared__ T ser[9 * (kTabArgs + 2) + 9 * 64];
+    __shared__ double scr[4 * (kTabArgs + 1)];
+    const int lane = threadIdx.x;
+    const int k = s.k;
+    const int ns = k - 1;                       // segment starts per pixel: 0 .. k - 2
+    const int ppw = ns <= 64 ? 64 / ns : 1;     // pixels per wave
+    const int nsw = ns <= 64 ? ns : 64;         // lanes per pixel
+    const int nsweep = ns <= 64 ? 1 : 2;        // 65 .. 128 starts: lane l takes the starts l and l + 64
+    const int grp = lane / nsw;
+    const int l0 = lane - grp * nsw;
+    const unsigned shard = blockIdx.x % kC3Shards;
+    const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
+    const uint32_t n = s.flag_count[shard * kC3CounterStride];
+    if (n > s.starts_max) return;               // a long list: the gather-and-sweep form's
+    if (lblock * (uint32_t)ppw >= n) return;
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+    const int kp = k + 1;
+    for (int j = lane; j <= k; j += 64) {
+        const OmniTabEntry e = s.tab_dev[j];
+        scr[j] = e.m2rho;
+        scr[kp + j] = e.pklogk;
+        scr[2 * kp + j] = e.zlo_a;
+        scr[3 * kp + j] = e.zhi_a;
+    }
+    for (uint32_t base = lblock * (uint32_t)ppw; base < n; base += nlblock * (uint32_t)ppw) {
+        const uint32_t idx = base + (uint32_t)grp;
+        const bool active = (grp < ppw) && (idx < n);
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+        const int64_t row = pix / s.nx_orig, col = pix - row * s.nx_orig;
+        const int64_t off = row * s.sy + col * s.sx;
+        T *mine = ser + grp * (k * 9);
+        __syncthreads();                        // (one wave per block: orders the LDS accesses of two rounds)
+        if (active)
+            for (int e = l0; e < k * 9; e += nsw) mine[e] = s.pl[e % 9][off + (int64_t)(e / 9) * s.st];
+        __syncthreads();
+        int nxt_a = -1, nxt_b = -1;             // per sweep: the next segment start, or stop
+        for (int sweep = 0; sweep < nsweep; ++sweep) {
+            const int l = l0 + 64 * sweep;
+            const bool lact = active && l < ns;
+            Accum3<T> A;
+            A.reset();
+            int fire_at = -1;
+            int nxt = -1;                       // stop
+            for (int i = 0; i < k; ++i) {       // the lane's dates are l, l + 1, ...
+                const int t = l + i;
+                if (!__any(lact && t < k)) break;
+                const bool on = lact && t < k;
+                T q[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) q[c] = on ? mine[t * 9 + c] : ((c < 3) ? (T)1 : (T)0);
+                if (on) A.step(q);
+                const int jj = i + 1;
+                const bool last = (t == k - 1);
+                const bool need = on && (jj >= 2) && (fire_at < 0 || last);
+                bool fires = false, inband = false;
+                if (need) {
+                    const double za = z_approx3<T>(A, jj, s.nlooks, scr[jj], scr[kp + jj]);
+                    fires = (za > scr[3 * kp + jj]) && (za < INFINITY);
+                    inband = (za >= scr[2 * kp + jj]) && !fires;
+                }
+                if (__any(inband)) {
+                    if (inband) {
+                        const OmniTabEntry e = s.tab_dev[jj];
+                        const T zp = z_stat3<T>(A, jj, s.nlooks, e);
+                        const double zd = (double)zp;
+                        int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                        if (verdict == 2) {
+                            double zv[1] = {zd}, P1[1], P2[1];
+                            chisq_pair<1>(zv, 9 * (jj - 1), e.lgam, P1, P2);
+                            const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                            verdict = ((double)P > s.alpha) ? 1 : 0;
+                        }
+                        fires = (verdict == 1);
+                    }
+                }
+                if (on && fires && fire_at < 0) fire_at = t;
+                if (on && last && fires) nxt = fire_at;      // the global test of ts[l:] fired (jj >= 2 here)
+            }
+            if (sweep == 0) nxt_a = nxt; else nxt_b = nxt;
+        }
+        // follow the chain from l = 0; the group's first lane writes the changes
+        int at = 0;
+        for (int step = 0; step < ns; ++step) {
+            const int ats = (at >= 0 && at < ns) ? at : 0;
+            const int src = grp * nsw + (ats & 63) % nsw;
+            const int na = __shfl(nxt_a, src), nb = __shfl(nxt_b, src);
+            const int n1 = (ns > 64 && ats >= 64) ? nb : na;
+            if (at >= 0 && at < ns) {
+                if (n1 < 0) {
+                    at = -1;                                   // :241-242
+                } else {
+                    if (active && l0 == 0) s.change[pix * (int64_t)k + n1] = 1;  // :252 (the row is all zeros)
+                    at = n1;                                   // :255; n1 = k - 1 ends the search (:256)
+                }
+            }
+        }
+    }
+}
+
 // ---- host -----------------------------------------------------------------------------------
 struct C3Workspace {
     size_t off_count, off_tab, off_idx, total;
@@ -781,6 +935,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     g.tab_dev = reinterpret_cast<OmniTabEntry *>(ws + w.off_tab);
     g.flag_idx = reinterpret_cast<uint32_t *>(ws + w.off_idx);
     g.seg = w.seg;
+    g.starts_max = 0;
     const int64_t nblocks = g.blocks_per_row * g.nrows;
     if (nblocks > 0x7fffffffLL) {
         set_error("nd_amd_omnibus_c3: raster too large for one launch");
@@ -830,6 +985,19 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         ND_HIP_CHECK(hipGetLastError());
     }
 
+    // behind the streaming search: short lists (what its screen could not decide) one lane per segment
+    // start -- ND_AMD_SEARCH_STARTS = list length per shard up to which (0 = never), as for the dual-pol test
+    static const int starts_env = [] {
+        const char *e = getenv("ND_AMD_SEARCH_STARTS");
+        return e ? atoi(e) : 512;
+    }();
+    if (fused && k >= 3 && starts_env > 0) {
+        g.starts_max = (uint32_t)starts_env;
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
+        hipLaunchKernelGGL((omnibus_c3_search_starts_kernel<T>), dim3((unsigned)(32 * kC3Shards)), dim3(64), 0, stream, g);
+        ND_HIP_CHECK(hipGetLastError());
+    }
+
     // the LDS image of 64 series: up to 150 KB of the CU's 160 KB (one wave per CU then, which still
     // beats a dependent, TLB-missing plane access per date and lane)
     const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);
@@ -864,7 +1032,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
                              : (lds_bytes <= 33 * 1024 ? 64 : (lds_bytes <= 66 * 1024 ? 32 : 16));
     const bool halves = use_lds && c3_lanes != 64;
     {
-        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
+        KernelTimer timer(g.starts_max ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
         if (halves) {
             const int lanes = c3_lanes == 16 ? 16 : 32;
             const size_t lds_part = (size_t)k * 9 * lanes * sizeof(T) + scr_bytes;
