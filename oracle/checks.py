@@ -38,8 +38,17 @@ def omnibus_sample(stack, change, alpha, n, nsample=100000, rows=(), seed=5, njo
     else:
         want = O.change_detection_pol(planes, pol, alpha, n, njobs=njobs)[0]
     got = change[yy, xx].cpu().numpy()
-    return {'bad': int((got != want).sum()), 'compared': int(got.size),
-            'flagged_fraction': float((want.sum(axis=1) > 0).mean())}
+    res = {'bad': int((got != want).sum()), 'compared': int(got.size),
+           'flagged_fraction': float((want.sum(axis=1) > 0).mean())}
+    if res['bad']:
+        # what went wrong where: enough to tell a stale / unwritten map from a wrong decision
+        badpx = np.flatnonzero((got != want).any(axis=1))
+        i0 = int(badpx[0])
+        res.update(bad_pixels=int(badpx.size), sampled_pixels=int(got.shape[0]),
+                   first_bad_pixel=int(idx[i0]), got_first=got[i0].tolist(), want_first=want[i0].tolist(),
+                   got_values=np.unique(got)[:8].tolist(),
+                   bad_pixel_index_range=[int(idx[badpx].min()), int(idx[badpx].max())])
+    return res
 
 
 def omnibus_ml_bands(stack, change, ml, alpha, bands, njobs=8):
