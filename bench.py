@@ -148,12 +148,7 @@ def _kernel_avgs(kt):
     by = {}
     for name, ms in kt:
         by.setdefault(name, []).append(ms)
-    LAUNCH_COUNTS.clear()
-    LAUNCH_COUNTS.update({n: len(v) for n, v in by.items()})
     return {n: sum(v) / len(v) for n, v in by.items()}
-
-
-LAUNCH_COUNTS = {}         # launches per kernel name behind the last _kernel_avgs (timed divides by its steps)
 
 
 TRAFFIC_MODE = False       # --traffic-run: plain loops, no events, no checks
@@ -918,9 +913,6 @@ def main():
     per_step = []
     state_before = device_state(local_rank)
     dt, avg, out = timed(w.step, args.steps, args.warmup, barrier, only=[w.dom], per_step=per_step)
-    # (the library cuts a large raster into row slabs, pass B of one under pass A of the next: several
-    # launches of the dominant kernel per step, each over its share of the bytes)
-    dom_launches = max(1, round(LAUNCH_COUNTS.get(w.dom, args.steps) / args.steps))
     state_after = device_state(local_rank)
     _, avg_all, _ = timed(w.step, max(3, min(args.steps, 10)), 1, barrier)
     avg_timed = dict(avg)                      # measured inside the timed region
@@ -1011,20 +1003,13 @@ def main():
             # SURVEY 8(d) / BASELINE.md basis: the planes read once, k * 4 * sizeof(T) bytes per pixel
             # (384 B at k = 24 float32); the same kernel also zero-fills the change map (k bytes per
             # pixel more, 408 B in all): that rate is the secondary figure.
-            nl = dom_launches if dom_k == w.dom else 1
-            res['roofline'] = roofline(dom_k, avg[dom_k], w.read_bytes / nl, traffic=traffic, traffic_source=source,
+            res['roofline'] = roofline(dom_k, avg[dom_k], w.read_bytes, traffic=traffic, traffic_source=source,
                                        note='algorithmic bytes = the four planes read once (%d B per pixel); '
                                             'achieved_read_write adds the change map the same kernel '
                                             'zero-fills (%d B per pixel in all)'
                                        % (w.read_bytes // w.npix, w.alg_bytes // w.npix))
-            res['roofline']['achieved_read_write'] = w.alg_bytes / nl / (avg[dom_k] * 1e-3) / 1e9
+            res['roofline']['achieved_read_write'] = w.alg_bytes / (avg[dom_k] * 1e-3) / 1e9
             res['roofline']['frac_read_write'] = res['roofline']['achieved_read_write'] / HBM_PEAK_GBS
-            res['roofline']['launches_per_step'] = nl
-            res['roofline']['kernel_ms_per_step'] = avg[dom_k] * nl
-            if nl > 1:
-                res['roofline']['note'] += ('; the raster goes through the kernel in %d row slabs (one launch each, '
-                                            'the search of a slab under the next slab\'s launch): kernel_ms, '
-                                            'algorithmic bytes and traffic are per launch' % nl)
         else:
             res['roofline'] = roofline(dom_k, avg[dom_k], w.alg_bytes, traffic=traffic, traffic_source=source,
                                        note='algorithmic bytes = planes read once + change map written once'

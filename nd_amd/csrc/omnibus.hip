@@ -30,9 +30,7 @@
 // gsl_cdf_chisq_P(z, f) and (z, f+4) (nd/_change.pyx:147-148): f = (j-1) p^2 with p = 2 is a
 // multiple of 4, so a = f/2 = 2(j-1) is an integer and the regularised incomplete gamma
 // function has closed recurrences (chisq_pair in omnibus_common.hpp).
-#include <mutex>
 #include <type_traits>
-#include <utility>
 
 #include "omnibus_c2_device.hpp"
 
@@ -2695,27 +2693,14 @@ static int fused_form_env()
     return v;
 }
 
-// threshold below which the search is fused into pass A where the register forms exist
-static double fused_alpha_regs_env()
-{
-    static const double v = [] {
-        const char *e = getenv("ND_AMD_FUSED_ALPHA");
-        return e ? atof(e) : 0.93;
-    }();
-    return v;
-}
-
 template <typename T>
 static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im, const void *c22,
                            int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int64_t st,
                            uint32_t n_looks, double alpha, uint8_t *change, void *z_out,
                            void *p_out, void *workspace, size_t workspace_bytes,
                            hipStream_t stream, const int64_t *pm_ids = nullptr,
-                           const OmniMlPlan *mlp = nullptr, hipStream_t side = nullptr,
-                           bool counters_zeroed = false)
+                           const OmniMlPlan *mlp = nullptr)
 {
-    // side != null: the kernels behind pass A go to that stream (behind an event), so that they run
-    // under the pass A of the caller's next row slab; the caller joins the two streams (omni_slabs)
     // mlp != null: OmnibusTest(ml=w) -- pass A multilooks on the fly (omnibus_ml.hip; float32 only)
     // pm_ids != null: pixel-major inputs, element (y, x, t) of variable v at
     // ptr_v[((y * nx + x) * k + t) * pm_ids[v]]; sy / sx / st then describe the unit-stride case
@@ -2750,7 +2735,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         ND_HIP_CHECK(e);
     }
 
-    if (!counters_zeroed) ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
+    ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
 
     // ---- pass A ----
     OmniGlobalArgs<T> g;
@@ -2795,7 +2780,10 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // 2.9 / 2.5 / 2.1 ms): it is offered up to 0.93, and the device-side sample decides.  The forms
     // that pay more for fusing (pixel-major: the LDS images; longer series: two streaming passes)
     // keep 0.75.
-    const double fused_alpha_regs = fused_alpha_regs_env();
+    static const double fused_alpha_regs = [] {
+        const char *e = getenv("ND_AMD_FUSED_ALPHA");
+        return e ? atof(e) : 0.93;
+    }();
     // (z / P rasters asked for on top: they come from one launch of the plain pass A first, see below)
     const bool fused = retain && dense_ok && g.dense_min <= 64 && alpha < fused_alpha_regs;
     const bool fused_stats = fused && stats;
@@ -3359,108 +3347,18 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     }
     ND_HIP_CHECK(hipGetLastError());
 
-    hipStream_t sq = stream;
-    if (side != nullptr) {
-        hipEvent_t ev;
-        ND_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e = hipEventRecord(ev, stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side, ev, 0);
-        (void)hipEventDestroy(ev);          // released once the recorded work has completed
-        ND_HIP_CHECK(e);
-        sq = side;
-    }
-
     // ---- dense waves (none in the sparse regime: every block then leaves at once) ----
     if (retain && g.dense_min <= 64 && (!fused || gated) && pm_ids == nullptr)
-        launch_dense(sq, flag_count, flag_idx, g.dense_idx, g.dump, g.seg, g.segd, g.dump_cap, npix);
+        launch_dense(stream, flag_count, flag_idx, g.dense_idx, g.dump, g.seg, g.segd, g.dump_cap, npix);
     ND_HIP_CHECK(hipGetLastError());
 
     // ---- pass B ----
     {
-        const int rc = launch_search(sq, flag_count, flag_idx, g.dump, g.seg, g.dump_cap, npix,
+        const int rc = launch_search(stream, flag_count, flag_idx, g.dump, g.seg, g.dump_cap, npix,
                                      hand_ws, g.seg / 64 + 1);
         if (rc != ND_AMD_OK) return rc;
     }
     ND_HIP_CHECK(hipGetLastError());
-    return ND_AMD_OK;
-}
-
-// ---- the sparse regime in row slabs: pass B of slab i under pass A of slab i + 1 ----------------
-// Pass A runs at the rate a copy reaches; the kernels behind it (the chain search of the listed pixels,
-// the pixels it hands on) are short dependent chains that leave HBM idle: 0.09 ms behind 1.15 ms on
-// 24 x 4096^2.  The raster is therefore cut into row slabs, each with its own slice of the workspace
-// (counters, lists, dump); slab i's search goes to a second stream behind an event and runs while
-// slab i + 1's pass A streams, and the caller's stream waits for the last search at the end.  The
-// slabs' results are independent (nd/_change.pyx:263-287: one pixel at a time), so the map is the
-// one-launch map.  ND_AMD_SLABS: number of slabs (default 4; 0 / 1 = one launch as before).
-constexpr int kNotSlabbed = 1;
-
-static hipStream_t omni_side_stream()
-{
-    static std::mutex mu;
-    static std::vector<std::pair<int, hipStream_t>> streams;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    for (const auto &p : streams)
-        if (p.first == dev) return p.second;
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    streams.emplace_back(dev, s);
-    return s;
-}
-
-template <typename T>
-static int omni_slabs(const void *c11, const void *c12re, const void *c12im, const void *c22, int64_t ny,
-                      int64_t nx, int64_t k, int64_t sy, int64_t sx, int64_t st, uint32_t n_looks,
-                      double alpha, uint8_t *change, void *workspace, size_t workspace_bytes,
-                      hipStream_t stream)
-{
-    static const int slabs_env = [] {
-        const char *e = getenv("ND_AMD_SLABS");
-        return e ? atoi(e) : 4;
-    }();
-    const int64_t npix = ny * nx;
-    const int nslab = slabs_env > 16 ? 16 : slabs_env;
-    if (nslab < 2 || npix < (int64_t)nslab * (1 << 20) || ny < 64 * nslab) return kNotSlabbed;
-    if (!(alpha >= fused_alpha_regs_env())) return kNotSlabbed;            // sparse regime only
-    if (k > (sizeof(T) == 4 ? kRetainMaxF32 : kRetainMaxF64)) return kNotSlabbed;
-    if (workspace == nullptr || ((uintptr_t)workspace & 255) != 0) return kNotSlabbed;   // the one-launch path reports it
-    const int64_t rows = ceil_div(ny, (int64_t)nslab);
-    const size_t slice = (workspace_bytes / (size_t)nslab) & ~(size_t)255;
-    {
-        // (a slice a little short of the slab's recommended size only shortens its dump)
-        const OmniWorkspace wl = omni_layout(rows * nx, rows, k, sizeof(T));
-        if (slice < wl.min_total + (wl.recommended - wl.min_total) / 2) return kNotSlabbed;
-    }
-    hipStream_t side = omni_side_stream();
-    if (side == nullptr) return kNotSlabbed;
-    unsigned char *ws = static_cast<unsigned char *>(workspace);
-    // every slab's counter block (the head of its slice) in one call
-    ND_HIP_CHECK(hipMemset2DAsync(ws, slice, 0, kCounterBytes, (size_t)nslab, stream));
-    const size_t es = sizeof(T);
-    for (int i = 0; i < nslab; ++i) {
-        const int64_t r0 = rows * i;
-        const int64_t nr = (r0 + rows <= ny ? rows : ny - r0);
-        if (nr <= 0) break;
-        const int64_t off = r0 * sy * (int64_t)es;
-        const int rc = omnibus_c2_impl<T>((const char *)c11 + off, (const char *)c12re + off,
-                                          (const char *)c12im + off, (const char *)c22 + off, nr, nx, k, sy,
-                                          sx, st, n_looks, alpha, change + r0 * nx * k, nullptr, nullptr,
-                                          ws + (size_t)i * slice, slice, stream, nullptr, nullptr, side, true);
-        if (rc != ND_AMD_OK) return rc;
-    }
-    hipEvent_t ev;
-    ND_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(ev, side);
-    if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev, 0);
-    (void)hipEventDestroy(ev);
-    ND_HIP_CHECK(e);
     return ND_AMD_OK;
 }
 
@@ -3508,14 +3406,6 @@ extern "C" int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void 
         return ND_AMD_EUNSUPPORTED;
     }
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (z_out == nullptr && p_out == nullptr) {
-        const int rc = dtype == ND_AMD_F32
-            ? omni_slabs<float>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x, stride_t, n_looks,
-                                alpha, change, workspace, workspace_bytes, stream)
-            : omni_slabs<double>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x, stride_t, n_looks,
-                                 alpha, change, workspace, workspace_bytes, stream);
-        if (rc != kNotSlabbed) return rc;
-    }
     if (dtype == ND_AMD_F32)
         return omnibus_c2_impl<float>(c11, c12re, c12im, c22, ny, nx, k, stride_y, stride_x,
                                       stride_t, n_looks, alpha, change, z_out, p_out, workspace,
