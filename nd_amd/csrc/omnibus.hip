@@ -638,8 +638,13 @@ __device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int 
 // are shared by neighbouring lanes and consecutive pieces, so they are fetched once -- and the image
 // is half the size: twice the waves per CU (24 x 4096^2: 2.5 -> 2.0 ms).  C12 as well, no image at
 // all: 3.3 ms -- its 192-byte pitch per lane is too much for the address coalescer.
+// (CHAIN, float32: capped at the registers of three waves per SIMD -- the 24-date DIRECT form took 170,
+// two short of it, and ran at two: 1.99 -> 1.86 ms; the float64 forms would spill under the cap.  A
+// persistent form -- as many waves as the chip holds, each walking spans gridDim.x apart, to spare the
+// dispatch gap between 13 us blocks -- was measured at 3.4 ms: with the span loop around it the body
+// needs more than the cap however its invariants are hidden from the hoisting passes.)
 template <typename T, int KMAX, bool STATS, bool CHAIN = false, bool DIRECT = false>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (CHAIN && sizeof(T) == 4) ? 3 : 1)
 omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const OmniPmDmaArgs<T> pm,
                          const StreamScreen<32> ss)
 {
@@ -679,6 +684,25 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     if (g.write_tab && b == 0) {
         for (int j = lane; j <= k; j += 64) g.tab_dev[j] = tab.e[j];
     }
+    const int own = in ? lane : np - 1;
+    // DIRECT: this lane's C11 / C22 pieces are requested behind the transfers and in front of the one
+    // wait, so that both are in flight together
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef T tv __attribute__((ext_vector_type(VE)));
+    tv qa[DIRECT ? KMAX / VE : 1], qd[DIRECT ? KMAX / VE : 1];
+    if (DIRECT) {
+        const T *p11 = g.c11 + (px0 + own) * (int64_t)k;
+        const T *p22 = g.c22 + (px0 + own) * (int64_t)k;
+#pragma unroll
+        for (int u = 0; u < KMAX / VE; ++u) {
+            if (u * VE < k) {
+                qa[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p11) + u);
+                qd[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p22) + u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KMAX / VE; ++u) asm volatile("" : "+v"(qa[u]), "+v"(qd[u]));
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- this lane's series out of the images (idle lanes copy the last pixel) ----
@@ -689,22 +713,14 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         for (int t = 0; t < KMAX; ++t) v[t][0] = v[t][1] = v[t][2] = v[t][3] = (T)1;   // dates behind k: masked
         __syncthreads();
     }
-    const int own = in ? lane : np - 1;
     if (DIRECT) {
-        // (issued before the wait above would be better still; the compiler hoists what it can)
-        constexpr int VE = 16 / (int)sizeof(T);
-        const T *p11 = g.c11 + (px0 + own) * (int64_t)k;
-        const T *p22 = g.c22 + (px0 + own) * (int64_t)k;
 #pragma unroll
         for (int u = 0; u < KMAX / VE; ++u) {
             if (u * VE < k) {
-                typedef T tv __attribute__((ext_vector_type(VE)));
-                const tv qa = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p11) + u);
-                const tv qd = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p22) + u);
 #pragma unroll
                 for (int i = 0; i < VE; ++i) {
-                    v[u * VE + i][0] = qa[i];
-                    v[u * VE + i][3] = qd[i];
+                    v[u * VE + i][0] = qa[u][i];
+                    v[u * VE + i][3] = qd[u][i];
                 }
             }
         }
