@@ -825,11 +825,15 @@ def extras(main, barrier, dev, only=None):
                   dt, steps, x.numel(), km,
                   valu_roofline(roof(key, 'nlmeans', dom, km, 8 * x.numel(),
                                      note='HBM traffic is 8 B per px.t: never the bound'),
-                                x.numel() * nq * (1 if pm == 0 else 49 * 3),
+                                x.numel() * nq * (1 if pm == 0 else 15),
                                 '440 dependent float32 additions per output in the reference\'s visiting order '
                                 '(packed over two outputs)' if pm == 0 else
-                                '440 x 49 patch elements x (subtract, multiply, add) per output before the '
-                                'cross-lane sharing of the patch-row sums (the kernel performs ~1/5 of them)'),
+                                '440 search offsets x 15 float32 operations per output in the algorithm the kernel '
+                                'implements (difference and square 2, 7-wide row sum shared across lanes 3, patch sum '
+                                'over 7 row sums 6, exponent and exponential 2, weighted sum and weight total 2); the '
+                                'naive formula, 49 x 3 per offset, is TFLOPs_naive_formula.  The row sums take DPP '
+                                'operands, which have no packed form: the vector ALUs are busy 97 % of the time '
+                                '(profiles/r02_nlmeans_patch2_pmc_after.txt) at this fraction of the packed rate'),
                   res['bad'] == 0, unit_note='Mpx_per_s counts px.t', **e)
         del x, y
         _free()

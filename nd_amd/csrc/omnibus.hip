@@ -950,7 +950,11 @@ __global__ void __launch_bounds__(64, 2) omnibus_c2_dense_kernel(const OmniDense
 // the reference's default 0.01 and the sparse regime).  Same loads as omnibus_c2_retain_kernel.
 // -----------------------------------------------------------------------------------------
 
-template <typename T, int KMAX, bool EXACT>
+// STATS: the z / P rasters of the whole-series test as well (nd/_change.pyx:46-77) -- the reference's
+// forward fold of the retained series and the exact chi-square pair, as omnibus_c2_retain_kernel<..., true>
+// evaluates them, so that a call with rasters reads the planes once (up to round 3: a pass A of its own
+// for the rasters in front of the search).
+template <typename T, int KMAX, bool EXACT, bool STATS = false>
 __global__ void __launch_bounds__(kRetainThreads, chain_waves(KMAX, sizeof(T)))
 omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const StreamScreen<chain_nj(KMAX)> ss)
 {
@@ -1070,6 +1074,25 @@ omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Stre
     }
     // ---- a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275)
     if (!dense && wnp > 0) zero_fill_span(wob, wnp * k, lane);
+    // (behind the search, where only the series itself is still alive: in front of it the fold's and the
+    // chi-square series' registers pushed the 24-date form over the cap of three waves per SIMD)
+    __builtin_amdgcn_sched_barrier(0);
+    if (STATS) {
+        Accum<T> A;
+        A.reset();
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+            if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+        const T z = z_stat<T>(A, k, g.nlooks, g.e);
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        if (in) {
+            const int64_t pix = row * g.nx + x0;
+            if (g.z_out) g.z_out[pix] = z;
+            if (g.p_out) g.p_out[pix] = P;
+        }
+    }
 }
 
 // -----------------------------------------------------------------------------------------
@@ -2634,10 +2657,16 @@ static void launch_retain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, int6
 
 template <typename T, int KMAX>
 static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const StreamScreen<chain_nj(KMAX)> &ss,
-                           int64_t nblocks, hipStream_t stream)
+                           int64_t nblocks, hipStream_t stream, bool stats = false)
 {
     const dim3 grid((unsigned)nblocks), block(kRetainThreads);
-    if (g.k == KMAX && g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0)
+    const bool exact = g.k == KMAX && g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
+    if (stats) {
+        if (exact)
+            hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, true, true>), grid, block, 0, stream, g, tab, ss);
+        else
+            hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, false, true>), grid, block, 0, stream, g, tab, ss);
+    } else if (exact)
         hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, true>), grid, block, 0, stream, g, tab, ss);
     else
         hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, false>), grid, block, 0, stream, g, tab, ss);
@@ -2646,29 +2675,30 @@ static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const
 // k <= 48 (float) / 24 (double): the series lengths pass A retains in registers
 template <typename T>
 static void launch_chain(const OmniGlobalArgs<T> &g, const OmniTab &tab, const std::vector<OmniTabEntry> &htab,
-                         const DenseScreen &scr, uint32_t n_looks, int64_t nblocks, hipStream_t stream)
+                         const DenseScreen &scr, uint32_t n_looks, int64_t nblocks, hipStream_t stream,
+                         bool stats = false)
 {
     const int k = g.k;
     if (sizeof(T) == 8 && k > 16) {
         const StreamScreen<32> ss = make_stream_screen<T, 32>(htab, scr, k, n_looks);
-        launch_chain_k<double, 24>(reinterpret_cast<const OmniGlobalArgs<double> &>(g), tab, ss, nblocks, stream);
+        launch_chain_k<double, 24>(reinterpret_cast<const OmniGlobalArgs<double> &>(g), tab, ss, nblocks, stream, stats);
         return;
     }
     if (k > 32) {
         const StreamScreen<64> ss = make_stream_screen<T, 64>(htab, scr, k, n_looks);
-        launch_chain_k<float, 48>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream);
+        launch_chain_k<float, 48>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream, stats);
         return;
     }
     const StreamScreen<32> ss = make_stream_screen<T, 32>(htab, scr, k, n_looks);
     if (k <= 8)
-        launch_chain_k<T, 8>(g, tab, ss, nblocks, stream);
+        launch_chain_k<T, 8>(g, tab, ss, nblocks, stream, stats);
     else if (k <= 16)
-        launch_chain_k<T, 16>(g, tab, ss, nblocks, stream);
+        launch_chain_k<T, 16>(g, tab, ss, nblocks, stream, stats);
     else if (sizeof(T) == 4) {
         if (k <= 24)
-            launch_chain_k<float, 24>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream);
+            launch_chain_k<float, 24>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream, stats);
         else
-            launch_chain_k<float, 32>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream);
+            launch_chain_k<float, 32>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream, stats);
     }
 }
 
@@ -3227,10 +3257,16 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
 #undef ND_LAUNCH_PM
         }
     } else if (fused) {
-        if (fused_stats) {
-            // the rasters from the plain pass A (it evaluates the whole-series test of every pixel
-            // anyway), the map from the fused search: without this split a low-threshold call with
-            // rasters sent every pixel through pass B (24 x 2048 x 4096 at alpha = 0.01: 3.2 ms against 0.7)
+        // z / P rasters asked for on top (fused_stats): the chain form evaluates them from the series it
+        // retains (one read of the planes; up to round 3 a plain pass A of its own produced them in front
+        // of the search: 24 x 2048 x 4096 at alpha = 0.01 1.54 ms against 0.77 without rasters).
+        // ND_AMD_STATS_SPLIT=1: the separate pass as before.
+        static const bool stats_split_env = [] {
+            const char *e = getenv("ND_AMD_STATS_SPLIT");
+            return e ? atoi(e) != 0 : false;
+        }();
+        const bool stats_in_chain = fused_stats && !stats_split_env;
+        if (fused_stats && !stats_in_chain) {
             const int dm = g.dense_min;
             g.dense_min = 65;
             {
@@ -3254,9 +3290,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // 1e-4); above, dense_chain costs the same at every threshold (1.55 ms) where the streaming
         // search's deep searches take 2.5 ms at 0.05 and 4.6 at 0.2 (24 x 4096^2).
         const int fused_form = fused_form_env();
-        const bool chain_form = fused_form == 2 || (fused_form < 0 && alpha > 0.02);
+        const bool chain_form = stats_in_chain || fused_form == 2 || (fused_form < 0 && alpha > 0.02);
         if (chain_form) {
-            launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream);
+            launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream, stats_in_chain);
         } else {
             const dim3 grid((unsigned)nblocks), block(kRetainThreads);
             constexpr int PF = sizeof(T) == 4 ? 6 : 4;
@@ -3272,10 +3308,11 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }
         if (gated) {
             // the sparse design, should the sample say so (dense waves it still meets go to the
-            // separate dense kernel below)
+            // separate dense kernel below); with the rasters in the chain form, exactly one of the two
+            // kernels runs and writes them
             g.gate_mode = 2;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-            launch_retain<T>(g, tab, nblocks, stats && !fused_stats, stream);
+            launch_retain<T>(g, tab, nblocks, stats && (!fused_stats || stats_in_chain), stream);
         }
         g.gate_mode = 0;
     } else if (stream_long) {
