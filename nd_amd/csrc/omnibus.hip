@@ -3268,17 +3268,20 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const bool stats_in_chain = fused_stats && !stats_split_env;
         if (fused_stats && !stats_in_chain) {
             const int dm = g.dense_min;
+            const uint32_t cap = g.dump_cap;
             g.dense_min = 65;
+            g.dump_cap = 0;             // its candidate lists are not used: no series dumped for them
             {
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
                 launch_retain<T>(g, tab, nblocks, true, stream);
             }
             ND_HIP_CHECK(hipGetLastError());
-            // its candidate lists are not used: the search below makes its own
+            // the search below makes its own lists
             ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
             g.z_out = nullptr;
             g.p_out = nullptr;
             g.dense_min = dm;
+            g.dump_cap = cap;
         }
         gated = take_sample();
         const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
@@ -3316,8 +3319,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }
         g.gate_mode = 0;
     } else if (stream_long) {
+        const uint32_t cap_keep = g.dump_cap;
         if (stats_split) {
             g.dense_min = 65;
+            // (this pass lists 1 - alpha of the pixels at a low threshold; its lists are not used, so no
+            // series is dumped for them: at alpha = 0.01 that was a write of the whole stack)
+            g.dump_cap = 0;
             {
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
                 if (retain)
@@ -3332,6 +3339,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             ND_HIP_CHECK(hipMemsetAsync(flag_count, 0, kCounterBytes, stream));
             g.z_out = nullptr;
             g.p_out = nullptr;
+            g.dump_cap = cap_keep;
         }
         g.dense_min = dense_env;
         gated = take_sample();                      // only where the sparse form can retain (k <= 48)
