@@ -97,10 +97,16 @@ omnibus_c2_global_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
                             v[tt][2].v[0] = g.c12i[off];
                             v[tt][3].v[0] = g.c22[off];
                         } else {
-                            v[tt][0] = *reinterpret_cast<const Pack<T, PPT> *>(g.c11 + off);
-                            v[tt][1] = *reinterpret_cast<const Pack<T, PPT> *>(g.c12r + off);
-                            v[tt][2] = *reinterpret_cast<const Pack<T, PPT> *>(g.c12i + off);
-                            v[tt][3] = *reinterpret_cast<const Pack<T, PPT> *>(g.c22 + off);
+                            // read once: past the caches' retention, as in the retaining form (96 dates
+                            // on 8.4 Mpx: 2.69 -> 2.21 ms, 0.60 -> 0.73 of the HBM peak)
+                            typedef T tvec __attribute__((ext_vector_type(PPT)));
+                            const T *const src[4] = {g.c11 + off, g.c12r + off, g.c12i + off, g.c22 + off};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const tvec q = __builtin_nontemporal_load(reinterpret_cast<const tvec *>(src[c]));
+#pragma unroll
+                                for (int i = 0; i < PPT; ++i) v[tt][c].v[i] = q[i];
+                            }
                         }
                     } else {
 #pragma unroll
