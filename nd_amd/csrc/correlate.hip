@@ -17,6 +17,13 @@
 
 #include "common.hpp"
 
+// cache policy of the window kernels' 16-byte output stores: 2 = non-temporal (written once, never read
+// back by the kernel; boxcar 3 x 3 / 5 x 5 on 24 x 4096^2: 0.632 / 0.640 -> 0.612 / 0.620 ms, the fused
+// Gaussian unchanged).  Non-temporal LOADS of the rows measured slower (0.611 -> 0.623 ms).
+#ifndef ND_CORR_ST_AUX
+#define ND_CORR_ST_AUX 2
+#endif
+
 namespace nd_amd {
 
 constexpr int kTapsArgs = 128;   // taps that travel as a kernel argument
@@ -577,7 +584,7 @@ __global__ void __launch_bounds__(256, (K == 3 ? 6 : (K == 5 ? 4 : 2))) correlat
                     if (writer) {
                         if (store_vec) {
                             const f32x4 o = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, x * 4, ooff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rout, x * 4, ooff, ND_CORR_ST_AUX);
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
@@ -1484,7 +1491,7 @@ __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs
                     if (writer) {
                         if (store_vec) {
                             const f32x4 o4 = {res[0], res[1], res[2], res[3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rout, x * 4, ooff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rout, x * 4, ooff, ND_CORR_ST_AUX);
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
