@@ -2084,7 +2084,10 @@ struct OmniSearchArgs {
 // MODE 0: series staged in LDS; MODE 1: no LDS, each date read straight from the dump (or the
 // planes) with the next date's load issued one iteration ahead -- 4 waves per SIMD instead of the
 // 1.5 the 24.5 KB LDS image allows.
-template <typename T, int MODE>
+// PXW: pixels per wave (64, or 32 / 16 with the upper lanes idle: the LDS image of PXW series of a long
+// stack is what limits the waves per CU -- 98 KB for 64 series of 96 dates, one wave; the sweep costs a wave
+// the same whatever its number of live lanes, so narrower waves, more of them per CU, finish the list sooner)
+template <typename T, int MODE, int PXW = 64>
 __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchArgs<T> s)
 {
     constexpr bool USE_LDS = (MODE == 0);
@@ -2097,7 +2100,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     // consecutive banks (as 64-byte records all j of one parity would share a bank).
     const OmniTabEntry *tabp = s.tab;          // full records, read only on the rare exact path
     const int kp = k + 1;
-    double *scr = reinterpret_cast<double *>(nd_smem + (size_t)k * 4 * 64 * sizeof(T));
+    double *scr = reinterpret_cast<double *>(nd_smem + (size_t)k * 4 * PXW * sizeof(T));
     if (USE_LDS) {
         for (int j = lane; j <= k; j += 64) {
             const OmniTabEntry e = s.tab[j];
@@ -2122,9 +2125,9 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
     if (n <= s.starts_max) return;             // omnibus_c2_search_starts_kernel searches this shard
 
-    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+    for (uint32_t base = lblock * (unsigned)PXW; base < n; base += nlblock * (unsigned)PXW) {
         const uint32_t idx = base + lane;
-        bool active = idx < n;
+        bool active = idx < n && lane < PXW;
         if (s.hand_bits != nullptr) {
             // behind the register form: only the pixels it marked (usually none at all)
             if (__builtin_nontemporal_load(s.hand_count) == 0u) return;
@@ -2137,8 +2140,8 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
         const int64_t col = pix - row * s.nx;
         const int64_t off = row * s.sy + col * s.sx;
 
-        if (USE_LDS) {
-            // stage this lane's series: lds[(t*4+v)*64 + lane]; each lane reads back only its
+        if (USE_LDS && (PXW == 64 || lane < PXW)) {
+            // stage this lane's series: lds[(t*4+v)*PXW + lane]; each lane reads back only its
             // own column, so no barrier is needed.  Source: the dump pass A wrote (one 16/32-byte
             // load per date, eight dates in flight), or the planes for pixels beyond the dump
             // capacity.
@@ -2154,10 +2157,10 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     for (int u = 0; u < 8; ++u)
                         if (t0 + u < k) {
                             const int t = t0 + u;
-                            lds[(t * 4 + 0) * 64 + lane] = q[u].v[0];
-                            lds[(t * 4 + 1) * 64 + lane] = q[u].v[1];
-                            lds[(t * 4 + 2) * 64 + lane] = q[u].v[2];
-                            lds[(t * 4 + 3) * 64 + lane] = q[u].v[3];
+                            lds[(t * 4 + 0) * PXW + lane] = q[u].v[0];
+                            lds[(t * 4 + 1) * PXW + lane] = q[u].v[1];
+                            lds[(t * 4 + 2) * PXW + lane] = q[u].v[2];
+                            lds[(t * 4 + 3) * PXW + lane] = q[u].v[3];
                         }
                 }
             } else {
@@ -2176,10 +2179,10 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     for (int u = 0; u < 4; ++u)
                         if (t0 + u < k) {
                             const int t = t0 + u;
-                            lds[(t * 4 + 0) * 64 + lane] = q[u][0];
-                            lds[(t * 4 + 1) * 64 + lane] = q[u][1];
-                            lds[(t * 4 + 2) * 64 + lane] = q[u][2];
-                            lds[(t * 4 + 3) * 64 + lane] = q[u][3];
+                            lds[(t * 4 + 0) * PXW + lane] = q[u][0];
+                            lds[(t * 4 + 1) * PXW + lane] = q[u][1];
+                            lds[(t * 4 + 2) * PXW + lane] = q[u][2];
+                            lds[(t * 4 + 3) * PXW + lane] = q[u][3];
                         }
                 }
             }
@@ -2204,8 +2207,8 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
         };
         auto load_step = [&](Accum<T> &A, int t) {
             if (USE_LDS) {
-                A.step(lds[(t * 4 + 0) * 64 + lane], lds[(t * 4 + 1) * 64 + lane],
-                       lds[(t * 4 + 2) * 64 + lane], lds[(t * 4 + 3) * 64 + lane]);
+                A.step(lds[(t * 4 + 0) * PXW + lane], lds[(t * 4 + 1) * PXW + lane],
+                       lds[(t * 4 + 2) * PXW + lane], lds[(t * 4 + 3) * PXW + lane]);
             } else {
                 const Pack<T, 4> cur = (nxt_t == t) ? nxt : fetch(t);
                 const int tn = t + 1 < k ? t + 1 : t;
@@ -3072,6 +3075,33 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const bool behind = chain_form;
         const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !behind) ? 0 : 1);
         const int64_t xblocks = behind ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
+        // images beyond 48 KB (three waves per CU or fewer at 64 series per wave): 16 series per wave
+        // (96 dates x 8.4 Mpx at alpha = 0.99: pass B 1.84 ms with 64, 1.35 with 32, 1.30 with 16)
+        static const int pxw_env = [] {
+            const char *e = getenv("ND_AMD_SEARCH_PXW");        // 64: always full waves; 32 / 16
+            return e ? atoi(e) : 0;
+        }();
+        const int pxw = pxw_env ? pxw_env : (lds_bytes > 48 * 1024 ? 16 : 64);
+        if (mode == 0 && use_lds && !behind && (pxw == 32 || pxw == 16)) {
+            const size_t lds_n = (size_t)k * 4 * (size_t)pxw * sizeof(T) + scr_bytes;
+            int64_t ps = ceil_div(ceil_div(npix_listed, kShards), (int64_t)pxw);
+            if (ps > 256) ps = 256;
+            if (ps < 1) ps = 1;
+            const dim3 gn((unsigned)(ps * kShards));
+#define ND_LAUNCH_PXW(P)                                                                                   \
+    do {                                                                                                  \
+        if (lds_n > 64 * 1024)                                                                            \
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0, P>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));    \
+        hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0, P>), gn, dim3(64), lds_n, sq, s);              \
+    } while (0)
+            if (pxw == 32)
+                ND_LAUNCH_PXW(32);
+            else
+                ND_LAUNCH_PXW(16);      // (8 per wave measured the same: the gather's sector traffic bounds it)
+#undef ND_LAUNCH_PXW
+            return ND_AMD_OK;
+        }
         if (mode == 0 && use_lds)
             hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0>), dim3((unsigned)xblocks), dim3(64),
                                lds_bytes, sq, s);
