@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     import time, hashlib, torch
     from nd_amd import synth, kernels, _lib
     dev = torch.device('cuda:0')
-    for k in (64, 96, 128):
+    for k in [int(v) for v in os.environ.get("ND_EXP_KS", "64,96,128").split(",")]:
         st = synth.wishart_c2_stack(k, 2048, 4096, looks=9, seed=3, device=dev, change_frac=0.01)
         fn = lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=0.99, n=9)
         for _ in range(2):
