@@ -199,6 +199,10 @@ def timed(fn, steps, warmup, barrier, launches_per_step=32, only=None, per_step=
 def device_state(index):
     """Clocks, temperature and power of the device as rocm-smi reports them (None where it does not)."""
     import subprocess
+    # under rocprofv3 the profiler's preloaded library initialises the GPU in every child process as well,
+    # and rocm-smi (a script: env -> python3) would then replace a GPU-initialised program: not started there
+    if 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
+        return {'skipped': 'running under rocprofv3'}
     try:
         r = subprocess.run(['rocm-smi', '-d', str(index), '--showclocks', '--showtemp', '--showpower', '--json'],
                            capture_output=True, text=True, timeout=20)
