@@ -2681,7 +2681,7 @@ static void launch_chain_k(const OmniGlobalArgs<T> &g, const OmniTab &tab, const
         hipLaunchKernelGGL((omnibus_c2_chain_kernel<T, KMAX, false>), grid, block, 0, stream, g, tab, ss);
 }
 
-// k <= 48 (float) / 24 (double): the series lengths pass A retains in registers
+// k <= 32 (float) / 24 (double): the series lengths the chain form keeps in registers
 template <typename T>
 static void launch_chain(const OmniGlobalArgs<T> &g, const OmniTab &tab, const std::vector<OmniTabEntry> &htab,
                          const DenseScreen &scr, uint32_t n_looks, int64_t nblocks, hipStream_t stream,
@@ -2691,11 +2691,6 @@ static void launch_chain(const OmniGlobalArgs<T> &g, const OmniTab &tab, const s
     if (sizeof(T) == 8 && k > 16) {
         const StreamScreen<32> ss = make_stream_screen<T, 32>(htab, scr, k, n_looks);
         launch_chain_k<double, 24>(reinterpret_cast<const OmniGlobalArgs<double> &>(g), tab, ss, nblocks, stream, stats);
-        return;
-    }
-    if (k > 32) {
-        const StreamScreen<64> ss = make_stream_screen<T, 64>(htab, scr, k, n_looks);
-        launch_chain_k<float, 48>(reinterpret_cast<const OmniGlobalArgs<float> &>(g), tab, ss, nblocks, stream, stats);
         return;
     }
     const StreamScreen<32> ss = make_stream_screen<T, 32>(htab, scr, k, n_looks);
@@ -3394,11 +3389,10 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             const bool buf = g.sx == 1 && (int64_t)g.k * g.st * (int64_t)sizeof(T) < 0x7fffffffLL && g.st >= 0;
             const int fused_form_long = fused_form_env();
             // float64 series of 17 .. 24 dates still fit the registers (as 32 float32 dates do): the
-            // chain form.  (33 .. 48 float32 dates: the instantiation exists -- ND_AMD_FUSED_FORM=2 --
-            // but spills 2 KB per lane under the 256-register cap of two waves per SIMD and is no
-            // faster than the streaming search with its deep searches: 6.9 against 6.6 ms at alpha = 0.2
-            // on 48 x 2048 x 4096.)
-            if (retain && (fused_form_long == 2 || (fused_form_long < 0 && alpha > 0.02 && sizeof(T) == 8))) {
+            // chain form.  (33 .. 48 float32 dates: that instantiation spilled 2 KB per lane under the
+            // 256-register cap of two waves per SIMD and was no faster than the streaming search with
+            // its deep searches -- 6.9 against 6.6 ms at alpha = 0.2 on 48 x 2048 x 4096; deleted in round 4.)
+            if (retain && sizeof(T) == 8 && (fused_form_long == 2 || (fused_form_long < 0 && alpha > 0.02))) {
                 launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream);
             } else if (fused_form_long == 3 || (fused_form_long < 0 && alpha > 0.02)) {
                 // longer series between the streaming search's thresholds and the sparse regime: the
