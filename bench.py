@@ -631,9 +631,9 @@ def extras(main, barrier, dev, only=None):
         dom = max(km, key=km.get)
         entry(key, 'OmnibusTest C2 %dt x %d x %d f32, alpha=%g (dense regime: %.3f of pixels change)'
               % (main.k, main.rows, main.nx, alpha, res['flagged_fraction']), dt, 10, main.npix, km,
-              roof(key, 'chain_kernel' if alpha > 0.02 else 'stream_kernel', dom, km, main.alg_bytes,
+              roof(key, 'chain_kernel' if alpha > 0.007 else 'stream_kernel', dom, km, main.alg_bytes,
                    note=('search fused into pass A, two linear passes over the retained series (dense_chain)'
-                         if alpha > 0.02 else
+                         if alpha > 0.007 else
                          'search fused into the streaming pass over the planes (vector issue and HBM both '
                          'near their floors)') + '; bytes = planes read once + change map written once'),
               res['bad'] == 0, sample=res)

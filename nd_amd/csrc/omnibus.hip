@@ -3324,7 +3324,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // 1e-4); above, dense_chain costs the same at every threshold (1.55 ms) where the streaming
         // search's deep searches take 2.5 ms at 0.05 and 4.6 at 0.2 (24 x 4096^2).
         const int fused_form = fused_form_env();
-        const bool chain_form = stats_in_chain || fused_form == 2 || (fused_form < 0 && alpha > 0.02);
+        // Where the chain form overtakes the streaming one (tools/exp_form_switch.py, float32, 4096^2): the
+        // chain search costs the same at every threshold, the streaming search's deep searches grow with it --
+        // 8 dates: the chain form wins everywhere (0.38 against 0.40 ms at alpha = 1e-4, 0.42 against 0.52 at
+        // 0.01); 16: from 0.002; 24: from 0.007 (at the reference's default 0.01: 1.32 against 1.41 ms of kernel
+        // and 6.9 against 8.3 GB of traffic; at 0.02: 1.30 against 1.69).  Series that do not fill their
+        // instantiation (the chain form walks KMAX dates), 32 dates (two waves per SIMD) and float64 keep 0.02.
+        const double chain_alpha = sizeof(T) == 4 ? (k == 8 ? 0.0 : (k == 16 ? 0.002 : (k == 24 ? 0.007 : 0.02))) : 0.02;
+        const bool chain_form = stats_in_chain || fused_form == 2 || (fused_form < 0 && alpha > chain_alpha);
         if (chain_form) {
             launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream, stats_in_chain);
         } else {

@@ -7,8 +7,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     import time, hashlib, torch
     from nd_amd import synth, kernels, _lib
     dev = torch.device('cuda:0')
-    st = synth.wishart_c2_stack(24, 4096, 4096, looks=9, seed=1234, device=dev, change_frac=0.01)
-    for alpha in (1e-4, 1e-3, 5e-3, 0.01, 0.02):
+    K = int(os.environ.get('ND_EXP_K', '24'))
+    st = synth.wishart_c2_stack(K, 4096, 4096 if K <= 24 else 2048, looks=9, seed=1234, device=dev, change_frac=0.01)
+    for alpha in [float(v) for v in os.environ.get('ND_EXP_ALPHAS', '1e-4,1e-3,5e-3,0.01,0.02').split(',')]:
         fn = lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
         for _ in range(5):
             out = fn()
@@ -26,6 +27,6 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
         h = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:10]
         print('alpha %g: %.3f ms per call, fused kernel %.3f, map %s' % (alpha, dt, sum(by['omnibus_c2_fused']) / 20, h), flush=True)
 else:
-    for form in ('0', '2', '0', '2'):
+    for form in ('0', '2'):
         print('ND_AMD_FUSED_FORM =', form, flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), 'child'], env=dict(os.environ, ND_AMD_FUSED_FORM=form), check=True)
