@@ -208,7 +208,9 @@ _FORMS_24 = [{'ND_AMD_FUSED_FORM': '0'}, {'ND_AMD_FUSED_FORM': '2'},
 _FORMS_12 = [{}, {'ND_AMD_FUSED_FORM': '0', 'ND_AMD_PM_DIRECT': '0'}, {'ND_AMD_FUSED_FORM': '2', 'ND_AMD_PM_FORM': '1'},
              {'ND_AMD_FUSED_ALPHA': '0', 'ND_AMD_SEARCH_MODE': '1'}]
 _FORMS_LONG = [{}, {'ND_AMD_FUSED_FORM': '0', 'ND_AMD_SEARCH_STARTS': '0'}, {'ND_AMD_FUSED_FORM': '3', 'ND_AMD_GATE': '0'},
-               {'ND_AMD_FUSED_ALPHA': '0', 'ND_AMD_SEARCH_MODE': '1'}]
+               {'ND_AMD_FUSED_ALPHA': '0', 'ND_AMD_SEARCH_MODE': '1'},
+               # pass B's LDS image with 64 / 32 series per wave (default from 48 dates on: 16)
+               {'ND_AMD_SEARCH_PXW': '64'}, {'ND_AMD_SEARCH_PXW': '32', 'ND_AMD_FUSED_ALPHA': '0'}]
 
 
 @pytest.mark.parametrize('k,env', [(24, e) for e in _FORMS_24] + [(12, e) for e in _FORMS_12] +
@@ -242,17 +244,16 @@ def test_every_kernel_form_gives_the_same_map(k, env):
         assert r['bytes_differing'] == 0, r
 
 
-@pytest.mark.parametrize('k,dtype,env', [(20, 'f64', {}), (24, 'f64', {}), (40, 'f32', {'ND_AMD_FUSED_FORM': '2'}),
-                                         (33, 'f32', {'ND_AMD_FUSED_FORM': '2'}), (32, 'f32', {}), (12, 'f64', {}),
+@pytest.mark.parametrize('k,dtype,env', [(20, 'f64', {}), (24, 'f64', {}), (33, 'f32', {}), (32, 'f32', {}), (12, 'f64', {}),
                                          (40, 'f32', {}), (63, 'f32', {}), (96, 'f32', {}), (128, 'f32', {}), (40, 'f64', {}),
                                          (96, 'f32', {'ND_AMD_FUSED_FORM': '3', 'ND_AMD_SEARCH_STARTS': '0'})])
 def test_chain_form_series_lengths(k, dtype, env):
     """dense_chain beyond the 24 float32 dates of the benchmark: 32 float32 / 16 float64 dates (two
-    waves per SIMD), the 64-bit-mask instantiations for 17 .. 24 float64 dates (default between the
-    streaming search's thresholds and the sparse regime) and 33 .. 48 float32 dates (forced; a series
-    shorter than the instantiation's 48 dates exercises the masked tail), and beyond the registers
-    the chain search in two streaming passes (33 .. 128 dates: 64- and 128-bit masks, pending global
-    tests, the per-start pass B with two starts per lane), each against the oracle."""
+    waves per SIMD), the 64-bit-mask instantiation for 17 .. 24 float64 dates (default between the
+    streaming search's thresholds and the sparse regime), and beyond the registers the chain search in
+    two streaming passes (33 .. 128 dates: 64- and 128-bit masks, pending global tests, the per-start
+    pass B with two starts per lane), each against the oracle.  (The 33 .. 48-date float32 register
+    instantiation was deleted in round 4: it spilled and never was the default.)"""
     import json
     import os
     import subprocess
@@ -294,6 +295,44 @@ def test_long_series_statistics_at_scale(oracle, dtype, k):
     res = checks.omnibus_sample(st, ch, 0.01, 9, nsample=3000, rows=(0, ny - 1), seed=3)
     assert res['bad'] == 0, res
     assert res['flagged_fraction'] > 0.5
+
+
+_RASTER_SCRIPT = r'''
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from nd_amd import kernels, synth
+dev = torch.device('cuda:0')
+for k, dt in ((24, torch.float32), (16, torch.float32), (12, torch.float64)):
+    st = synth.wishart_c2_stack(k, 1536, 2048, looks=9, seed=40 + k, device=dev, change_frac=0.02).to(dt)
+    for alpha in (1e-4, 0.01, 0.3):
+        ch, z, P = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9, stats=True)
+        ch0 = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
+        assert torch.equal(ch, ch0)
+        h = hashlib.sha1()
+        for t in (ch, z, P):
+            h.update(t.cpu().numpy().tobytes())
+        print('RASTERS', k, str(dt), alpha, h.hexdigest())
+'''
+
+
+def test_rasters_from_chain_form_equal_separate_pass():
+    """Below the sparse regime the z / P rasters come from the chain form's retained series (round 4: one
+    read of the planes); ND_AMD_STATS_SPLIT=1 restores the separate pass A in front of the search.  Both give
+    the same map and bit-identical rasters, at the thresholds of the streaming and of the chain form, on a
+    raster large enough for the device-side density gate (each mode in a fresh process: the switch is read
+    once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for split in ('0', '1'):
+        e = dict(os.environ, ND_AMD_STATS_SPLIT=split)
+        r = subprocess.run([sys.executable, '-c', _RASTER_SCRIPT % root], env=e, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith('RASTERS')])
+    assert len(outs[0]) == 9 and outs[0] == outs[1], (outs[0], outs[1])
 
 
 @pytest.mark.parametrize('ml', [3, 5])
