@@ -2901,7 +2901,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         sa.nx = g.nx;
         sa.blocks_per_row = ceil_div(g.nx, (int64_t)kRetainThreads);
         const int64_t total = sa.blocks_per_row * g.nrows;
-        const int64_t nsb = 512;
+        // (pixel-major: a lane's dates are 4-byte loads k x 4 bytes apart from its neighbour's, 64 lines per
+        //  instruction -- the sample's time is its line requests: 128 blocks, 32 768 pixels, are plenty)
+        const int64_t nsb = pm_ids ? 128 : 512;
         sa.block_stride = total / nsb;
         sa.sy = sy;
         sa.sx = sx;
