@@ -23,11 +23,15 @@ Scaling (--scaling): weak (default) = every rank owns a raster of the stated siz
 is N times as tall; strong = the stated raster is split over the ranks by tiles.row_partition.
 
 At N = 1 with the default workload the line also carries `cpu_baseline` (the C oracle on the host's
-cores) and `extra`: the other kernels of the path (dense-threshold omnibus, C3, boxcar, non-local
-means in both patch modes, Gaussian, the pipeline) each with ms, Mpx/s, roofline and a sampled
-oracle check.
+cores).  `--extras` (its own invocation) adds the other kernels of the path (dense-threshold omnibus,
+multilooking, pixel-major, C3, boxcar, non-local means in both patch modes, Gaussian, the pipeline),
+each with ms, Mpx/s, roofline and a sampled oracle check: they are written to bench_extras.json, the
+long form of the headline (notes, per-step durations, N > 1 per-rank records) to bench_detail.json.
 
-Prints ONE JSON line on rank 0.
+`--gpus N` with N > 1 and no launcher around it starts the N ranks itself (the launch line above, as a
+child process) and relays rank 0's line; a WORLD_SIZE that differs from --gpus is an error.
+
+Prints ONE JSON line on rank 0: the headline object only, strict JSON, under 4 KB.
 """
 import argparse
 import json
@@ -78,13 +82,9 @@ def profiled_traffic(key, hint):
     if not rows:
         return None, None
     if tab.get('csrc_sha') != csrc_sha():
-        return None, ('stale: %s was measured on kernel sources %s (commit %s), this build is %s'
-                      % (os.path.relpath(TRAFFIC_FILE, ROOT), tab.get('csrc_sha'), tab.get('commit', '?'), csrc_sha()))
+        return None, 'stale: %s@%s is of other kernel sources' % (os.path.relpath(TRAFFIC_FILE, ROOT), tab.get('commit', '?'))
     r = max(rows, key=lambda r: r['traffic_bytes'])
-    return r['traffic_bytes'], ('%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py '
-                                '--traffic-run %s` at commit %s; kernel %s)'
-                                % (os.path.relpath(TRAFFIC_FILE, ROOT), key, tab.get('commit', '?'),
-                                   r['kernel'][:60]))
+    return r['traffic_bytes'], '%s@%s' % (os.path.relpath(TRAFFIC_FILE, ROOT), tab.get('commit', '?'))
 
 DEFAULTS = {'omnibus': (24, 4096, 4096), 'c3': (48, 1024, 8192), 'pipeline': (24, 2048, 16384)}
 # tutorial parameters (examples/tutorial_s1.ipynb cells 11, 15; NLMeansFilter defaults sigma=h=f=1)
@@ -108,7 +108,12 @@ def parse():
     ap.add_argument('--patch-mode', type=int, default=0, help='pipeline: 0 reference, 1 signed')
     ap.add_argument('--cpu-rows', type=int, default=4096,
                     help='rows of the stack the all-core CPU baseline is timed on (0 = skip)')
-    ap.add_argument('--no-extra', action='store_true', help='skip the secondary workloads')
+    ap.add_argument('--extras', action='store_true',
+                    help='N = 1, default workload: also run the secondary workloads (dense thresholds, '
+                         'multilooking, pixel-major, C3, boxcar, Gaussian, non-local means, the pipeline), '
+                         'device clocks and transfer rates; they go to bench_extras.json / '
+                         'bench_detail.json, never into the line')
+    ap.add_argument('--no-extra', action='store_true', help='(accepted, ignored: extras are opt-in now)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch of the dominant kernel from a separate '
                          'rocprofv3 --pmc pass, copied into roofline.traffic')
@@ -413,6 +418,11 @@ class OmnibusC2(Workload):
     def metric(self):
         return 'Mpixels/s OmnibusTest dual-pol %dt x %d x %d' % (self.k, self.a.ny, self.nx)
 
+    def config(self):
+        return {'workload': 'OmnibusTest C2 %dt x %d x %d f32 %s (BASELINE configs[1]), resident in HBM'
+                            % (self.k, self.a.ny, self.nx, 'per GPU' if self.a.scaling == 'weak' else 'in all'),
+                'looks': self.a.looks, 'alpha': self.a.alpha, 'change_frac': self.a.change_frac}
+
     def describe(self):
         return ('OmnibusTest dual-pol C2, synthetic %dt x %d x %d float32 %s (BASELINE.json '
                 'configs[1]), n=%d looks, alpha=%g, %.3g of pixels with a x4 step; inputs resident '
@@ -453,6 +463,11 @@ class OmnibusC3(Workload):
 
     def metric(self):
         return 'Mpixels/s OmnibusTest full-pol C3 %dt x %d x %d' % (self.k, self.a.ny, self.nx)
+
+    def config(self):
+        return {'workload': 'OmnibusTest C3 %dt x %d x %d f32 x 9 planes %s (share of BASELINE configs[3])'
+                            % (self.k, self.a.ny, self.nx, 'per GPU' if self.a.scaling == 'weak' else 'in all'),
+                'looks': self.a.looks, 'alpha': self.a.alpha, 'change_frac': self.a.change_frac}
 
     def describe(self):
         return ('OmnibusTest full-pol C3 (extension, no reference implementation), synthetic '
@@ -505,11 +520,17 @@ class Pipeline(Workload):
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.status_any = torch.zeros(1, dtype=torch.int32, device=dev)
 
+    overlap = None            # None: the library's default form; first_contact() may force False
+
+    def filter_once(self, overlap=None):
+        from nd_amd import tiles
+        return tiles.nlmeans_rows(self.shard, self.global_ny, TUT['r'], TUT['f'],
+                                  TUT['sigma'], TUT['h'], n_eff=TUT['n_eff'],
+                                  patch_mode=self.a.patch_mode, status=self.status, overlap=overlap)
+
     def step(self):
         from nd_amd import tiles
-        self.filtered = tiles.nlmeans_rows(self.shard, self.global_ny, TUT['r'], TUT['f'],
-                                           TUT['sigma'], TUT['h'], n_eff=TUT['n_eff'],
-                                           patch_mode=self.a.patch_mode, status=self.status)
+        self.filtered = self.filter_once(self.overlap)
         self.status_any.bitwise_or_(self.status)
         return tiles.omnibus_rows(self.filtered, self.a.alpha, TUT['n'])
 
@@ -532,6 +553,12 @@ class Pipeline(Workload):
 
     def metric(self):
         return 'Mpixels/s NLMeans->OmnibusTest %dt x %d x %d' % (self.k, self.a.ny, self.nx)
+
+    def config(self):
+        return {'workload': 'NLMeansFilter(r=(1,3,3), f=1, sigma=1, h=1, n_eff=50) -> OmnibusTest(n=50) on '
+                            '%dt x %d x %d f32 x 4 variables %s (share of BASELINE configs[4])'
+                            % (self.k, self.a.ny, self.nx, 'per GPU' if self.a.scaling == 'weak' else 'in all'),
+                'alpha': self.a.alpha, 'patch_mode': self.a.patch_mode, 'change_frac': self.a.change_frac}
 
     def describe(self):
         return ('NLMeansFilter(dims=(time,y,x), r=(1,3,3), f=1, sigma=1, h=1, n_eff=50, patch '
@@ -591,6 +618,8 @@ def cpu_baseline_omnibus(w, out):
     npx = rows * stack.shape[3]
     res = {
         'value': npx / dt / 1e6, 'unit': 'Mpixels/s', 'cores': int(cores), 'kind': 'port',
+        'sample_short': 'oracle/nd_oracle.c (OpenMP) on the first %d rows of the same stack, %.2f s; '
+                        'one_thread_value: %d rows, %.2f s' % (rows, dt, rows1, dt1),
         'sample': 'oracle/nd_oracle.c (C port of nd/_change.pyx, reference-order arithmetic, '
                   'OpenMP over rows) on the first %d rows x %d cols x %d dates of the same '
                   'stack: %.2f s wall' % (rows, stack.shape[3], stack.shape[1], dt),
@@ -889,12 +918,161 @@ def extras(main, barrier, dev, only=None):
     return out
 
 
+LINE_LIMIT = 4096           # bytes; the driver keeps only the tail of stdout and parses its last line
+
+
+def _r(x, nd=4):
+    """numbers of the line: 6 significant digits are plenty and keep it short"""
+    if isinstance(x, float):
+        return float('%.6g' % x)
+    if isinstance(x, dict):
+        return {k: _r(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v) for v in x]
+    return x
+
+
+def headline(m):
+    """The ONE line: the headline object only, from the measurements `m` (a dict main() fills).  Pure
+    host code (tests/test_host_logic.py builds it from stub numbers).  Everything explanatory -- notes,
+    device clocks, transfer rates, per-kernel second-loop figures, the secondary workloads -- goes to
+    the sidecar files (bench_detail.json, bench_extras.json), never into the line."""
+    roof = m['roofline']
+    line = {
+        'metric': m['metric'], 'value': m['value'], 'unit': 'Mpixels/s', 'n_gpus': m['n_gpus'],
+        'steps': m['steps'], 'warmup': m['warmup'], 'ms_per_step': m['ms_per_step'],
+        'step_ms': m.get('step_ms'),
+        'higher_is_better': True, 'scaling': m['scaling'], 'vs_baseline': None,
+        'dtype': 'f32', 'data': m['data'],
+        'config': m['config'],
+        'roofline': {k: roof[k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                                          'traffic_source', 'kernel_ms', 'algorithmic_bytes_per_launch',
+                                          'frac_read_write', 'hbm') if k in roof},
+        'kernels_ms': m['kernels_ms'],
+    }
+    if m.get('cpu_baseline') is not None:
+        c = m['cpu_baseline']
+        line['cpu_baseline'] = {k: c[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'one_thread_value',
+                                                  'gpu_matches_cpu_on_sample') if k in c}
+    if m.get('comm') is not None:
+        line['comm'] = m['comm']
+    if m.get('matches_oracle_on_sample') is not None:
+        line['matches_oracle_on_sample'] = m['matches_oracle_on_sample']
+    for k in ('detail_file', 'extras_file'):
+        if m.get(k):
+            line[k] = m[k]
+    return _r(line)
+
+
+def emit(line):
+    """strict JSON, one line, under LINE_LIMIT bytes -- or no line at all (a line the driver cannot
+    parse leaves the round unmeasured: better to fail here, loudly)"""
+    text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    if '\n' in text or len(text.encode()) >= LINE_LIMIT:
+        raise RuntimeError('bench line is %d bytes (limit %d)' % (len(text.encode()), LINE_LIMIT))
+    return text
+
+
+def _write_sidecar(name, obj):
+    """bench_detail.json / bench_extras.json next to bench.py (and a copy under gpurun_out/ when that
+    directory exists, so that a gpurun call brings it back).  -> file name, or None if not writable."""
+    text = json.dumps(obj, indent=1, default=str)
+    wrote = None
+    for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        if not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, name), 'w') as fh:
+                fh.write(text)
+            wrote = wrote or name
+        except OSError:
+            pass
+    return wrote
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks the way the
+    driver does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same arguments>) as a CHILD process, before this process has made any GPU
+    call (torch is not even imported here), relay rank 0's line and the launcher's exit code.  Never
+    continues single-rank: the reference's multi-worker entry is one call as well
+    (nd/algorithm.py:57-68 -> nd/utils.py:343-401)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    # the ranks' stdout goes through a file, not a pipe: a pipe stays open for as long as any
+    # descendant of the launcher holds it
+    import tempfile
+    with tempfile.TemporaryFile('w+') as fo:
+        rc = subprocess.call(cmd, env=env, stdout=fo, stdin=subprocess.DEVNULL, cwd=os.getcwd())
+        fo.seek(0)
+        lines = [ln for ln in fo.read().splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith('{')]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            print(ln, file=sys.stderr)              # transports' banners: not this program's output
+    if rc != 0:
+        raise SystemExit(rc if 0 < rc < 256 else 1)
+    if not js:
+        print('bench.py: the %d ranks printed no result line' % args.gpus, file=sys.stderr)
+        raise SystemExit(1)
+    print(js[-1])
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
+def first_contact(w, dist, rdev):
+    """N > 1, before anything is timed: the filter's two forms on a shard with neighbours -- halo
+    exchange first, then one launch (sequential) against interior rows while the halo travels
+    (overlapped) -- must give the same filtered values bit for bit on EVERY rank (the reference's
+    split -> map -> merge equals the unsplit result, nd/utils.py:288-340,
+    nd/tests/test_filters_common.py:54-60).  The overlapped form had only ever run over gloo when this
+    was written; under RCCL the transfers run on the communicator's stream.  -> dict for `comm`;
+    on a difference the workload is switched to the sequential form for the timed region."""
+    import torch
+    if not hasattr(w, 'filter_once'):
+        return None
+    seq = w.filter_once(overlap=False).clone()
+    torch.cuda.synchronize()
+    ovl = w.filter_once(overlap=True)
+    torch.cuda.synchronize()
+    if os.environ.get('ND_AMD_BENCH_FORCE_OVERLAP_DIFF') == str(w.rank):
+        # test hook (tests/test_multigpu_gpu.py): pretend this rank's overlapped launch read a halo row
+        # before it had landed
+        ovl = ovl.clone()
+        ovl[0, 0, 0, :8] += 1.0
+    ndiff = int((seq.view(torch.int32) != ovl.view(torch.int32)).sum().item())
+    del seq, ovl
+    worst = torch.tensor([ndiff], dtype=torch.int64, device=rdev)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    same = int(worst.item()) == 0
+    res = {'overlap_equals_sequential': same, 'timed_form': 'overlapped' if same else 'sequential'}
+    if not same:
+        res['values_differing_max_over_ranks'] = int(worst.item())
+        res['values_differing_this_rank'] = ndiff
+        w.overlap = False
+    return res
+
+
 def main():
     args = parse()
-    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        launch_ranks(args, sys.argv[1:])           # does not return
+    # first contact with N > 1 must not be taken on trust: as many ranks as asked for, or no number
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE is %d: refusing to run (and to report) another '
+                         'job size than the one asked for' % (args.gpus, world))
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (nd_amd has no CPU path)')
     # ND_AMD_BENCH_REHEARSE=gloo: the N > 1 code path on a box with fewer GPUs than ranks (ranks
@@ -938,14 +1116,22 @@ def main():
             extras(w, barrier, dev, only=args.traffic_run)
         print(json.dumps({'traffic_run': args.traffic_run}))
         return
+    contact = None
+    if dist is not None and world > 1:
+        if not rehearse:
+            devs = [None] * world
+            dist.all_gather_object(devs, local_rank)
+            if len(set(devs)) != world:
+                raise RuntimeError('ranks share devices: %r' % devs)
+        contact = first_contact(w, dist, rdev)
     # The timed region: every step is the whole call; inside it only the dominant kernel carries
     # the library's event pair (each pair costs a few microseconds of stream time, and the
     # roofline needs that kernel's duration measured live here), plus one torch event per step
     # boundary for the spread.  The other kernels' durations come from a second, untimed loop.
     per_step = []
-    state_before = device_state(local_rank)
+    state_before = device_state(local_rank) if args.extras else None
     dt, avg, out = timed(w.step, args.steps, args.warmup, barrier, only=[w.dom], per_step=per_step, settle=False)
-    state_after = device_state(local_rank)
+    state_after = device_state(local_rank) if args.extras else None
     _, avg_all, _ = timed(w.step, max(3, min(args.steps, 10)), 1, barrier, settle=False)
     avg_timed = dict(avg)                      # measured inside the timed region
     for name, ms in avg_all.items():
@@ -963,7 +1149,7 @@ def main():
         total_px = float(w.npix)
     value = total_px * args.steps / dt / 1e6
     flagged = float((out.sum(dim=2) > 0).float().mean().item())
-    comm = None
+    comm = comm_detail = None
     if dist is not None:
         # who took part, over what, and what travelled: gathered from every rank so that the line
         # carries its own evidence of the N > 1 run
@@ -977,18 +1163,28 @@ def main():
                 kernels.raise_if_no_solution(w.status_any)
         ranks = [None] * world
         dist.all_gather_object(ranks, mine)
-        # first contact with N > 1 must not be taken on trust: one rank per GPU, as many as asked for
-        if dist.get_world_size() != args.gpus:
-            raise RuntimeError('--gpus %d but the process group has %d ranks' % (args.gpus, dist.get_world_size()))
-        if not rehearse and len({r_['device_index'] for r_ in ranks}) != world:
-            raise RuntimeError('ranks share devices: %r' % [(r_['rank'], r_['device_index']) for r_ in ranks])
         bcheck = boundary_check(w, out, dist, rank, world, rdev)
-        comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
-                'data_path_collective': 'none (per-pixel path: every rank runs its own rows)'
-                if w.name != 'pipeline' else
-                'one point-to-point halo exchange per step (batch_isend_irecv with the row neighbours, '
-                'overlapped with the filter on the rows that need no halo)',
-                'ranks': ranks, 'boundary_check': bcheck}
+        comm_detail = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                       'data_path_collective': 'none (per-pixel path: every rank runs its own rows)'
+                       if w.name != 'pipeline' else
+                       'one point-to-point halo exchange per step (batch_isend_irecv with the row neighbours, '
+                       'overlapped with the filter on the rows that need no halo)',
+                       'ranks': ranks, 'boundary_check': bcheck, 'first_contact': contact}
+        if rank == 0:
+            # the line's form: one short row per rank
+            comm = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                    'collective': 'none' if w.name != 'pipeline' else 'p2p halo exchange per step',
+                    'rank_cols': ['rank', 'device_index', 'row0', 'row1', 'step_ms'],
+                    'ranks': [[r_['rank'], r_['device_index'], r_['rows'][0], r_['rows'][1], r_['step_ms']]
+                              for r_ in ranks],
+                    'device': ranks[0]['device'],
+                    'boundary_check': {k_: bcheck[k_] for k_ in ('boundaries', 'map_bytes_compared',
+                                                                 'map_bytes_differing', 'filtered_values_differing')}}
+            if 'halo_bytes_sent_per_step' in ranks[0]:
+                comm['halo_bytes_sent_per_step'] = [r_['halo_bytes_sent_per_step'] for r_ in ranks]
+                comm['exchange_ms_alone'] = [r_['exchange_ms_alone'] for r_ in ranks]
+            if contact is not None:
+                comm.update(contact)
 
     if rank == 0:
         is_default = (w.name == 'omnibus' and (w.k, args.ny, w.nx, args.alpha, args.looks, args.change_frac)
@@ -1001,63 +1197,71 @@ def main():
         # search is fused into the one streaming kernel) whichever kernel takes the time
         dom_k = w.dom if w.dom in avg else max(avg, key=avg.get)
         ps = sorted(per_step)
-        res = {
-            'metric': w.metric(), 'value': value, 'unit': 'Mpixels/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'step_ms': {'min': ps[0], 'median': ps[len(ps) // 2], 'max': ps[-1],
-                        'note': 'per-step durations from one event per step boundary on the launch '
-                                'stream, this rank'} if ps else None,
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic' if not rehearse else
-            'synthetic; REHEARSAL: ranks share devices over gloo, not a measurement',
-            'config': {
-                'workload': w.describe(),
-                'arithmetic': 'float32 planes and running sums; float64 product of determinants, '
-                              'logs and chi-square pair (the reference\'s rounding points)',
-                'flagged_pixel_fraction': flagged,
-                'sharding': 'rows [%d, %d) of %d on rank 0; tiles.row_partition over %d rank(s); %s'
-                            % (w.r0, w.r1, w.global_ny, world,
-                               'no collective' if w.name != 'pipeline' or world == 1 else
-                               'one point-to-point halo exchange per step'),
-            },
-            'comm': comm,
-            'kernels_ms': avg,
-            'kernels_ms_timed_region': avg_timed,
-            'kernels_ms_second_loop': {n_: m_ for n_, m_ in avg_all.items() if n_ not in avg_timed},
-            'kernels_ms_note': 'kernels_ms_timed_region: HIP events inside the timed region (the dominant '
-                               'kernel only: an event pair costs stream time); kernels_ms_second_loop: the '
-                               'same step run again behind it; kernels_ms: both together',
-            'device_state': {'before_timed_region': state_before, 'after_timed_region': state_after,
-                             'note': 'rocm-smi clocks / temperature / power around the timed region: the same '
-                                     'code ran pass A in 1.11 - 1.20 ms from box to box in round 3'},
-        }
         if w.name == 'omnibus':
             # SURVEY 8(d) / BASELINE.md basis: the planes read once, k * 4 * sizeof(T) bytes per pixel
             # (384 B at k = 24 float32); the same kernel also zero-fills the change map (k bytes per
             # pixel more, 408 B in all): that rate is the secondary figure.
-            res['roofline'] = roofline(dom_k, avg[dom_k], w.read_bytes, traffic=traffic, traffic_source=source,
-                                       note='algorithmic bytes = the four planes read once (%d B per pixel); '
-                                            'achieved_read_write adds the change map the same kernel '
-                                            'zero-fills (%d B per pixel in all)'
-                                       % (w.read_bytes // w.npix, w.alg_bytes // w.npix))
-            res['roofline']['achieved_read_write'] = w.alg_bytes / (avg[dom_k] * 1e-3) / 1e9
-            res['roofline']['frac_read_write'] = res['roofline']['achieved_read_write'] / HBM_PEAK_GBS
+            roof = roofline(dom_k, avg[dom_k], w.read_bytes, traffic=traffic, traffic_source=source,
+                            note='algorithmic bytes = the four planes read once (%d B per pixel); '
+                                 'achieved_read_write adds the change map the same kernel '
+                                 'zero-fills (%d B per pixel in all)'
+                                 % (w.read_bytes // w.npix, w.alg_bytes // w.npix))
+            roof['achieved_read_write'] = w.alg_bytes / (avg[dom_k] * 1e-3) / 1e9
+            roof['frac_read_write'] = roof['achieved_read_write'] / HBM_PEAK_GBS
         else:
-            res['roofline'] = roofline(dom_k, avg[dom_k], w.alg_bytes, traffic=traffic, traffic_source=source,
-                                       note='algorithmic bytes = planes read once + change map written once'
-                                       if w.name != 'pipeline' else 'algorithmic bytes = filter input + output')
+            roof = roofline(dom_k, avg[dom_k], w.alg_bytes, traffic=traffic, traffic_source=source,
+                            note='algorithmic bytes = planes read once + change map written once'
+                            if w.name != 'pipeline' else 'algorithmic bytes = filter input + output')
             if w.name == 'pipeline':
-                res['roofline'] = valu_roofline(res['roofline'], w.npix * w.k * 4 * (3 * 7 * 7 - 1),
-                                                '146 dependent float32 additions per output, packed over two outputs')
+                roof = valu_roofline(roof, w.npix * w.k * 4 * (3 * 7 * 7 - 1),
+                                     '146 dependent float32 additions per output, packed over two outputs')
+                roof['hbm'] = {'achieved': roof['hbm']['achieved'], 'frac': roof['hbm']['frac']}
+        m = {
+            'metric': w.metric(), 'value': value, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'step_ms': {'min': ps[0], 'median': ps[len(ps) // 2], 'max': ps[-1]} if ps else None,
+            'scaling': args.scaling,
+            'data': 'synthetic' if not rehearse else
+            'synthetic; REHEARSAL: ranks share devices over gloo, not a measurement',
+            'config': dict(w.config(), flagged_pixel_fraction=flagged,
+                           rows_per_rank=w.rows, sharding='row blocks (tiles.row_partition), %s'
+                           % ('no collective' if w.name != 'pipeline' or world == 1 else
+                              'p2p halo exchange per step')),
+            'roofline': roof, 'kernels_ms': avg, 'comm': comm,
+        }
+        detail = {
+            'describe': w.describe(),
+            'arithmetic': 'float32 planes and running sums; float64 product of determinants, logs and '
+                          'chi-square pair (the reference\'s rounding points)',
+            'roofline': roof, 'comm': comm_detail,
+            'kernels_ms_timed_region': avg_timed,
+            'kernels_ms_second_loop': {n_: m_ for n_, m_ in avg_all.items() if n_ not in avg_timed},
+            'kernels_ms_note': 'kernels_ms_timed_region: HIP events inside the timed region (the dominant '
+                               'kernel only: an event pair costs stream time); kernels_ms_second_loop: the '
+                               'same step run again behind it; kernels_ms (the line): both together',
+            'step_ms_all': per_step,
+        }
         if world == 1 and w.name == 'omnibus':
-            res['transfer'] = transfer_rates(dev)
             if args.cpu_rows > 0:
-                res['cpu_baseline'] = cpu_baseline_omnibus(w, out)
-            if not args.no_extra:
-                res['extra'] = extras(w, barrier, dev)
+                cb = cpu_baseline_omnibus(w, out)
+                detail['cpu_baseline'] = cb
+                m['cpu_baseline'] = dict(cb, sample=cb['sample_short'],
+                                         one_thread_value=cb['one_thread']['value'])
+                if not cb['gpu_matches_cpu_on_sample']:
+                    raise RuntimeError('the GPU change map differs from the oracle on the CPU baseline\'s rows')
         elif world == 1:
-            res['matches_oracle_on_sample'] = w.check(out)
-        print(json.dumps(res))
+            chk = w.check(out)
+            detail['check'] = chk
+            m['matches_oracle_on_sample'] = bool(chk.get('bad', 1) == 0 and chk.get('change_bad', 0) == 0)
+        if args.extras and world == 1 and w.name == 'omnibus':
+            # the secondary workloads: their own invocation (`bench.py --extras`), their own file
+            detail['device_state'] = {'before_timed_region': state_before, 'after_timed_region': state_after}
+            detail['transfer'] = transfer_rates(dev)
+            ex = extras(w, barrier, dev)
+            m['extras_file'] = _write_sidecar('bench_extras.json', {'headline': headline(m), 'extra': ex})
+        detail['line'] = headline(m)
+        m['detail_file'] = _write_sidecar('bench_detail.json', detail)
+        print(emit(headline(m)))
         sys.stdout.flush()
     if dist is not None:
         dist.barrier()

@@ -128,7 +128,7 @@ int nd_amd_omnibus_c2(const void *c11, const void *c12re, const void *c12im,
  * in footprint order, rounded to float32) and exists only in registers; the
  * number of looks is ml * ml.  Results equal nd_amd_correlate on every plane
  * followed by nd_amd_omnibus_c2 bit for bit.
- * Covered: float32, stride_x == 1, ml = 3 or 5, 2 <= k <= 24, ny, nx > ml;
+ * Covered: float32, stride_x == 1, ml = 3 or 5, 2 <= k <= 24, ny, nx >= ml;
  * anything else returns ND_AMD_EUNSUPPORTED (and the workspace query 0): the
  * caller then multilooks with nd_amd_correlate and calls nd_amd_omnibus_c2.
  * The workspace must hold the multilooked series of every pixel the test can

@@ -40,6 +40,47 @@ PER_FILE = {'nlmeans.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_NLM_F
             'omnibus_ml.hip': ['-fno-slp-vectorize']}
 
 
+# Scratch guard.  omnibus_c2_ml_kernel waits for its LDS-DMA transfers by COUNT (s_waitcnt vmcnt(4 | 16),
+# omnibus_ml.hip ml_wait_vm), and on gfx9 scratch spills and reloads count in vmcnt as well.  Loads
+# return in order, so a spill or reload anywhere around stage() can only make a counted wait stricter
+# (the N newest operations it leaves outstanding then include the scratch access, never an OLDER
+# transfer), i.e. cost time, not correctness -- but time is what this kernel is about, and a compiler
+# or flag change that pushes the step loop into scratch should not pass unnoticed.  The build reads the
+# compiler's own resource report (-Rpass-analysis=kernel-resource-usage) and fails if an instantiation
+# exceeds its budget: none for the sparse form (pass A of the benchmark regime), what the fused-search
+# and statistics forms are known to spill in their tails (bytes per lane) otherwise.
+NO_SCRATCH = {'omnibus_ml.hip': 'omnibus_c2_ml_kernel'}
+# template arguments <K, KMAX, STATS, CHAIN> as they appear in the mangled name
+SCRATCH_BUDGET = {'Lb0ELb0E': 0, 'Lb0ELb1E': 96, 'Lb1ELb0E': 256}
+
+
+def check_no_scratch(remarks_path, symbol):
+    """-> [(function, bytes per lane)] of the kernels whose mangled name contains `symbol`; raises if
+    any of them exceeds its scratch budget, or if the report holds none of them (a renamed kernel must
+    not pass)."""
+    import re
+    found, cur = [], None
+    for ln in open(remarks_path, errors='replace'):
+        m = re.search(r'Function Name: (\S+)', ln)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', ln)
+        if m and cur is not None and symbol in cur:
+            found.append((cur, int(m.group(1))))
+    if not found:
+        raise RuntimeError('%s: no resource report for %s (is -Rpass-analysis=kernel-resource-usage on?)'
+                           % (remarks_path, symbol))
+    bad = []
+    for f, n in found:
+        budget = next((b for key, b in SCRATCH_BUDGET.items() if key + 'EEvNS' in f), 0)
+        if n > budget:
+            bad.append((f, n, budget))
+    if bad and os.environ.get('ND_AMD_ALLOW_SCRATCH', '') != '1':
+        raise RuntimeError('scratch use (bytes per lane) over budget: %s' % bad)
+    return found
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
@@ -75,13 +116,27 @@ def _build(force, verbose, extra_flags, LIB, OBJ):
                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), dep_mtime)):
             continue
         cmd = [HIPCC] + FLAGS + PER_FILE.get(os.path.basename(src), []) + list(extra_flags) + ['-c', src, '-o', obj]
+        err = None
+        if os.path.basename(src) in NO_SCRATCH:
+            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+            err = open(obj + '.remarks', 'w')
         if verbose:
             print(' '.join(cmd))
-        procs.append((src, subprocess.Popen(cmd)))
+        procs.append((src, subprocess.Popen(cmd, stderr=err), err))
         rebuilt.append(os.path.basename(src))
-    for src, p in procs:
-        if p.wait() != 0:
+    for src, p, err in procs:
+        rc = p.wait()
+        if err is not None:
+            err.close()
+            if rc != 0 or verbose:
+                sys.stderr.write(''.join(ln for ln in open(err.name, errors='replace')
+                                         if 'remark:' not in ln or verbose))
+        if rc != 0:
             raise RuntimeError('hipcc failed on %s' % src)
+    for src in sources():
+        sym = NO_SCRATCH.get(os.path.basename(src))
+        if sym:
+            check_no_scratch(os.path.join(OBJ, os.path.basename(src)[:-4] + '.o.remarks'), sym)
     linked = False
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs

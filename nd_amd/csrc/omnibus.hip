@@ -3118,17 +3118,20 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             if (ml_chain) {
                 if (stats) {            // the rasters from a pass of their own, the map from the fused search
                     KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-                    launch_ml_pass_a(g, tab, *mlp, nullptr, true, false, stream);
+                    const int rc = launch_ml_pass_a(g, tab, *mlp, nullptr, true, false, stream);
+                    if (rc != ND_AMD_OK) return rc;
                     g.z_out = nullptr;
                     g.p_out = nullptr;
                 }
                 const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
                 const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
-                launch_ml_pass_a(g, tab, *mlp, &ss0, false, true, stream);
+                const int rc = launch_ml_pass_a(g, tab, *mlp, &ss0, false, true, stream);
+                if (rc != ND_AMD_OK) return rc;
             } else {
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-                launch_ml_pass_a(g, tab, *mlp, nullptr, stats, true, stream);
+                const int rc = launch_ml_pass_a(g, tab, *mlp, nullptr, stats, true, stream);
+                if (rc != ND_AMD_OK) return rc;
             }
         } else {
             set_error("nd_amd_omnibus_c2_ml: float32 only");

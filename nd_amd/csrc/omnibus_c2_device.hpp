@@ -343,7 +343,8 @@ bool omni_ml_plan(int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int
                   OmniMlPlan *p);
 // ss != null: the search fused in (dense_chain); else the sparse design's pass A (stats: with the z / P
 // rasters; list = false: rasters only, no candidate list and no zero-fill)
-void launch_ml_pass_a(const OmniGlobalArgs<float> &g, const OmniTab &tab, const OmniMlPlan &p,
-                      const StreamScreen<32> *ss, bool stats, bool list, hipStream_t stream);
+// -> ND_AMD_OK or ND_AMD_EHIP (the dynamic-LDS opt-in of the current device failed)
+int launch_ml_pass_a(const OmniGlobalArgs<float> &g, const OmniTab &tab, const OmniMlPlan &p,
+                     const StreamScreen<32> *ss, bool stats, bool list, hipStream_t stream);
 
 }  // namespace nd_amd

@@ -314,6 +314,9 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     }
     const int total_steps = ntiles * nstep_k;
     constexpr int PF = M::NSLOT - 1;                             // steps of transfers in flight
+    // rowtab / tab_lds (written by wave 0 above) are read by the per-element form of stage() in the
+    // other staging waves: one barrier in front of the first transfers
+    ml_barrier();
     {
         int sp = 0, Xp = Xs, c1 = 0;
         for (int j = 0; j < PF; ++j) {
@@ -608,7 +611,7 @@ bool omni_ml_plan(int64_t ny, int64_t nx, int64_t k, int64_t sy, int64_t sx, int
 }
 
 template <int K, int KMAX>
-static void launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, const OmniMlArgs &a,
+static int launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, const OmniMlArgs &a,
                         const StreamScreen<32> *ss, bool stats, int64_t nblocks, hipStream_t stream)
 {
     typedef MlGeom<K> M;
@@ -623,10 +626,11 @@ static void launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, cons
     if (!ss) memset(&none, 0, sizeof(none));
 #define ND_ML_LAUNCH(STATS_, CHAIN_)                                                                          \
     do {                                                                                                      \
-        static const hipError_t attr_ = hipFuncSetAttribute(                                                  \
+        /* on every launch: the attribute belongs to the CURRENT device's function object (one thread */     \
+        /* per device in algorithm.parallel(devices=...)), and a failure must not go unnoticed */            \
+        ND_HIP_CHECK(hipFuncSetAttribute(                                                                     \
             reinterpret_cast<const void *>(&omnibus_c2_ml_kernel<K, KMAX, STATS_, CHAIN_>),                   \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                            \
-        (void)attr_;                                                                                          \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                           \
         hipLaunchKernelGGL((omnibus_c2_ml_kernel<K, KMAX, STATS_, CHAIN_>), grid, block, lds, stream, g, tab, a, \
                            ss ? *ss : none);                                                                  \
     } while (0)
@@ -637,10 +641,11 @@ static void launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, cons
     else
         ND_ML_LAUNCH(false, false);
 #undef ND_ML_LAUNCH
+    return ND_AMD_OK;
 }
 
-void launch_ml_pass_a(const OmniGlobalArgs<float> &g, const OmniTab &tab, const OmniMlPlan &p,
-                      const StreamScreen<32> *ss, bool stats, bool list, hipStream_t stream)
+int launch_ml_pass_a(const OmniGlobalArgs<float> &g, const OmniTab &tab, const OmniMlPlan &p,
+                     const StreamScreen<32> *ss, bool stats, bool list, hipStream_t stream)
 {
     OmniMlArgs a;
     a.ny = p.ny;
@@ -656,21 +661,25 @@ void launch_ml_pass_a(const OmniGlobalArgs<float> &g, const OmniTab &tab, const 
     }
     a.wt = 1.0 / (double)(p.ml * p.ml);
     a.list = list ? 1 : 0;
+    a.trace = nullptr;
+    a.trace_block = 1000;
+#ifdef ND_ML_TRACE
     {
         const char *e = getenv("ND_AMD_ML_TRACE");       // device pointer (hex) of >= 147456 bytes, diagnostic builds
         a.trace = e ? reinterpret_cast<unsigned long long *>(strtoull(e, nullptr, 16)) : nullptr;
         const char *eb = getenv("ND_AMD_ML_TRACE_BLOCK");
         a.trace_block = eb ? atoi(eb) : 1000;
     }
+#endif
     const int k = g.k;
 #define ND_ML_K(KK)                                                                       \
     do {                                                                                  \
         if (k <= 8)                                                                       \
-            launch_ml_k<KK, 8>(g, tab, a, ss, stats, p.nblocks, stream);                  \
+            return launch_ml_k<KK, 8>(g, tab, a, ss, stats, p.nblocks, stream);           \
         else if (k <= 16)                                                                 \
-            launch_ml_k<KK, 16>(g, tab, a, ss, stats, p.nblocks, stream);                 \
+            return launch_ml_k<KK, 16>(g, tab, a, ss, stats, p.nblocks, stream);          \
         else                                                                              \
-            launch_ml_k<KK, 24>(g, tab, a, ss, stats, p.nblocks, stream);                 \
+            return launch_ml_k<KK, 24>(g, tab, a, ss, stats, p.nblocks, stream);          \
     } while (0)
     if (p.ml == 3)
         ND_ML_K(3);

@@ -20,9 +20,15 @@ exchange receives straight into those margins; the block itself is never copied,
 in the exchange follows from `row_partition` arithmetic -- no size collective, no host sync.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
+
+
+# the windowed filters' default form on a shard with neighbours: filter the rows that need no halo
+# while the halo rows travel (True), or exchange first and filter in one launch (False)
+HALO_OVERLAP = os.environ.get('ND_AMD_HALO_OVERLAP', '1') != '0'
 
 
 def row_partition(n, parts):
@@ -268,7 +274,8 @@ def boxcar_rows(stack, w, global_ny=None, group=None):
     return filter_rows(lambda e: kernels.convolve(e, k), stack, w // 2, t.dim() - 2, global_ny, group)
 
 
-def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group=None, status=None):
+def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group=None, status=None,
+                 overlap=None):
     """NLMeansFilter on a row-sharded planar stack (var, time, y_local, x), joint weights over the
     variables.  r, f: (time, y, x) radii like NLMeansFilter(dims=('time', 'y', 'x')).  The halo
     rows (r_y + f_y) are exchanged once for all variables and dates; reflection happens at the
@@ -279,7 +286,11 @@ def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group
     exchange is in flight, then the two edge bands (a pixel's value does not depend on how the
     raster is cut, so the result is the single launch's, bit for bit).
     status: int32 device tensor of one element that collects the find_weight flag of n_eff >= 0
-    without a host synchronisation (kernels.raise_if_no_solution reads it later)."""
+    without a host synchronisation (kernels.raise_if_no_solution reads it later).
+    overlap: False = exchange first, then ONE launch over all rows; True = the three-launch form
+    above; None = HALO_OVERLAP (module switch, ND_AMD_HALO_OVERLAP=0 in the environment turns it
+    off).  bench.py compares the two forms bit for bit on every rank before it times anything
+    (first contact with RCCL) and falls back to the sequential form on a difference."""
     from . import kernels, synth
     rt, ry, rx = (int(v) for v in r)
     ft, fy, fx = (int(v) for v in f)
@@ -320,11 +331,12 @@ def nlmeans_rows(stack, global_ny, r, f, sigma, h, n_eff=-1, patch_mode=0, group
             status.bitwise_or_(scratch)
 
     first, last = lo, ny_ext - hi                  # the block's own rows inside `ext`
-    # ND_AMD_HALO_OVERLAP=0: exchange first, then one launch over all rows.  The overlapped form has run
-    # on gloo groups and on ranks sharing one GPU only (no multi-GPU box in development): the switch is
-    # the way back should its stream semantics differ under RCCL.
-    import os
-    if pending is not None and pending.reqs and os.environ.get('ND_AMD_HALO_OVERLAP', '1') != '0':
+    # The overlapped form has run on gloo groups and on ranks sharing one GPU only (no multi-GPU box in
+    # development): `overlap=False` / HALO_OVERLAP is the way back should its stream semantics differ
+    # under RCCL.
+    if overlap is None:
+        overlap = HALO_OVERLAP
+    if pending is not None and pending.reqs and overlap:
         in_lo = first + (halo if lo else 0)        # rows whose windows stay inside the block
         in_hi = last - (halo if hi else 0)
         if in_hi > in_lo:
