@@ -774,7 +774,7 @@ def extras(main, barrier, dev, only=None):
             if quick:
                 continue
             res = w.check(ch)
-            dom = w.dom if alpha > 0.5 else max(km, key=km.get)
+            dom = w.dom if (alpha > 0.5 and w.dom in km) else max(km, key=km.get)
             entry(key, w.describe(), dt, 10, w.npix, km,
                   roof(key, 'omnibus_c3_global' if alpha > 0.5 else 'omnibus_c3_stream', dom, km, w.alg_bytes,
                        note=None if alpha > 0.5 else 'search fused into the streaming pass (omnibus_c3_stream_kernel)'),

@@ -1,0 +1,61 @@
+"""Timing / traffic variants of single translation units, built HERE (no GPU) as _variants/lib_<name>.so
+(other objects come from nd_amd/csrc/_build) and selected on the GPU box with ND_AMD_LIB.
+
+    python tools/variants_r5.py build [names...]
+
+A variant = (file, [(old text, new text), ...]).  Round 5's experiments; the ones that won are in the
+sources, the table stays as the record of what was tried."""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, '_variants')
+
+VARIANTS = {
+    # pixel-major dense form: C11 / C22 pieces with plain (temporal) loads instead of non-temporal ones
+    'pm_temporal': ('omnibus.hip', [
+        ("                qa[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p11) + u);\n"
+         "                qd[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p22) + u);",
+         "                qa[u] = *(reinterpret_cast<const tv *>(p11) + u);\n"
+         "                qd[u] = *(reinterpret_cast<const tv *>(p22) + u);")]),
+}
+
+
+def build(names):
+    from nd_amd import build as B
+    os.makedirs(VDIR, exist_ok=True)
+    procs = []
+    for name in names:
+        fname, patches = VARIANTS[name]
+        d = os.path.join(VDIR, 'src_' + name)
+        shutil.rmtree(d, ignore_errors=True)
+        shutil.copytree(B.CSRC, d, ignore=shutil.ignore_patterns('_build'))
+        hp = os.path.join(d, 'common.hpp')
+        h = open(hp).read().replace('../../include/nd_amd.h', os.path.join(ROOT, 'include', 'nd_amd.h'))
+        open(hp, 'w').write(h)
+        p = os.path.join(d, fname)
+        s = open(p).read()
+        for old, new in patches:
+            assert s.count(old) == 1, (name, s.count(old), old[:70])
+            s = s.replace(old, new)
+        open(p, 'w').write(s)
+        obj = os.path.join(VDIR, '%s_%s.o' % (fname[:-4], name))
+        cmd = [B.HIPCC] + B.FLAGS + B.PER_FILE.get(fname, []) + ['-c', p, '-o', obj]
+        procs.append((name, fname, obj, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
+    for name, fname, obj, pr in procs:
+        assert pr.wait() == 0, name
+        objs = [os.path.join(B.OBJ, f) for f in sorted(os.listdir(B.OBJ))
+                if f.endswith('.o') and f != fname[:-4] + '.o']
+        so = os.path.join(VDIR, 'lib_%s.so' % name)
+        subprocess.check_call([B.HIPCC, '--offload-arch=' + B.ARCH, '-shared', '-fPIC', '-o', so, obj] + objs)
+        os.remove(obj)
+        shutil.rmtree(os.path.join(VDIR, 'src_' + name))
+        print('built', so)
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'build':
+        build(sys.argv[2:] or list(VARIANTS))
