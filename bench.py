@@ -51,11 +51,12 @@ os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
 os.environ.setdefault('GOMP_SPINCOUNT', '0')
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction) of every
+# HBM bytes per launch (fetch_factor x FETCH_SIZE + WRITE_SIZE: the guide's gfx950 correction, calibrated
+# per access pattern in tools/summarize_traffic.py) of every
 # workload's kernels, from separate rocprofv3 --pmc passes over `bench.py --traffic-run KEY`
 # (tools/collect_traffic.sh writes the file, with the commit it was taken at).  Reported with its
 # source; a workload or kernel the file does not hold gets traffic = null.
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r04_traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05_traffic.json')
 
 
 def csrc_sha():

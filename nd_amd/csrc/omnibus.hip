@@ -684,8 +684,13 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         stage(g.c11, 0);
         stage(g.c22, 3);
     }
-    stage(g.c12r, 1);
-    if (!pm.c12_joint) stage(g.c12i, 2);
+#ifdef ND_PM_DIRECT_C12
+    if (!(DIRECT && pm.c12_joint))
+#endif
+    {
+        stage(g.c12r, 1);
+        if (!pm.c12_joint) stage(g.c12i, 2);
+    }
 
     if (g.write_tab && b == 0) {
         for (int j = lane; j <= k; j += 64) g.tab_dev[j] = tab.e[j];
@@ -702,13 +707,32 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
 #pragma unroll
         for (int u = 0; u < KMAX / VE; ++u) {
             if (u * VE < k) {
-                qa[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p11) + u);
-                qd[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p22) + u);
+                // PLAIN loads, not non-temporal ones: a wave instruction takes 16 bytes of every lane's
+                // series (pitch 4 k bytes), i.e. a part of each 128-byte line, and the other parts of
+                // the line are asked for by the instructions that follow.  A non-temporal line is dropped
+                // from the L2 after its first use and fetched again for the next piece: 8.19 GB of
+                // traffic for 6.44 GB of data, 1.86 ms; plain loads: 6.44 GB, 1.49 ms
+                // (tools/probe_fetch.hip, pitch96: 0.62 against 0.50 of FETCH_SIZE per byte, 758 against
+                // 339 us; gpurun_out/r5_exp1 -> profiles/r05_fetch_calibration.json).
+                qa[u] = *(reinterpret_cast<const tv *>(p11) + u);
+                qd[u] = *(reinterpret_cast<const tv *>(p22) + u);
             }
         }
 #pragma unroll
         for (int u = 0; u < KMAX / VE; ++u) asm volatile("" : "+v"(qa[u]), "+v"(qd[u]));
     }
+#ifdef ND_PM_DIRECT_C12
+    // experiment: C12 (interleaved complex) straight into registers as well, no LDS image
+    tv qx[(DIRECT && CHAIN) ? 2 * KMAX / VE : 1];
+    if (DIRECT && pm.c12_joint) {
+        const T *p12 = g.c12r + (px0 + own) * (int64_t)(2 * k);
+#pragma unroll
+        for (int u = 0; u < 2 * KMAX / VE; ++u)
+            if (u * VE < 2 * k) qx[u] = *(reinterpret_cast<const tv *>(p12) + u);
+#pragma unroll
+        for (int u = 0; u < 2 * KMAX / VE; ++u) asm volatile("" : "+v"(qx[u]));
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- this lane's series out of the images (idle lanes copy the last pixel) ----
@@ -734,6 +758,16 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     pm_pick<T, KMAX, 0, false>(v, img + pm.img_off[0] + own * k * pm.ids[0], k, pm.ids[0]);
     pm_pick<T, KMAX, 3, false>(v, img + pm.img_off[3] + own * k * pm.ids[3], k, pm.ids[3]);
     }
+#ifdef ND_PM_DIRECT_C12
+    if (DIRECT && pm.c12_joint) {
+#pragma unroll
+        for (int u = 0; u < 2 * KMAX / VE; ++u)
+            if (u * VE < 2 * k) {
+#pragma unroll
+                for (int i = 0; i < VE; ++i) v[(u * VE + i) / 2][1 + ((u * VE + i) & 1)] = qx[u][i];
+            }
+    } else
+#endif
     if (pm.c12_joint) {
         pm_pick<T, KMAX, 1, true>(v, img + pm.img_off[1] + own * k * 2, k, 2);
     } else {

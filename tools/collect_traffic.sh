@@ -2,7 +2,7 @@
 # HBM traffic of every bench workload's kernels: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes (with --kernel-trace only, as MI355X_MICROARCH.md prescribes) over `bench.py --traffic-run KEY`.
 #   bash tools/collect_traffic.sh gpurun_out/traffic [commit] [KEY ...]    (on the GPU box)
-# writes <outdir>/traffic.json -- copy it to profiles/r04_traffic.json, which bench.py reads.
+# writes <outdir>/traffic.json -- copy it to profiles/r05_traffic.json, which bench.py reads.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/$1; COMMIT=${2:-unknown}; shift; shift
 KEYS="$@"

@@ -3,12 +3,34 @@
 launch from the FETCH_SIZE / WRITE_SIZE passes of tools/collect_traffic.sh.
 
 Units and correction as in MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KiB;
-on gfx950 FETCH_SIZE tallies 64 B per 128-B request of a coalesced streaming read, so it is doubled.
+on gfx950 FETCH_SIZE tallies 64 B per request.
+
+THE RULE (calibrated on this pool with tools/probe_fetch.hip, a 2 GiB buffer read exactly once per
+pattern; profiles/r05_fetch_calibration.json):
+  * coalesced reads -- 16 B or 4 B per lane, global_load / buffer_load to registers or `... lds`
+    (LDS-DMA) alike, and a lane's own 16-byte pieces at a 96-byte pitch with plain loads --
+    FETCH_SIZE = 0.500 x the bytes read: requests of 128 B tallied at 64 B.  Factor 2.
+  * isolated 4-byte reads (one per 64 B, 128 B, 256 B or 4 KiB): FETCH_SIZE = 64.0 B per read, i.e.
+    ONE request per read.  How many bytes that request moves is not observable from this counter;
+    doubling it would claim 128 B per 4-byte read.  Kernels whose reads are gathers (GATHER_KERNELS
+    below: the change-point searches that pick listed pixels out of the planes) are reported with
+    factor 1 = 64 B per request, and `fetch_factor` says so per kernel.
+  * non-temporal 16-byte pieces at a 96-byte pitch: 0.62 (the line is dropped after its first use and
+    fetched again) -- the re-fetch is real traffic, the factor stays 2.
 """
 import collections
 import csv
 import json
 import sys
+
+
+# kernels whose memory reads are gathers of isolated elements: factor 1 (see THE RULE)
+# (the dual-pol searches read the compact dump pass A wrote, 16 bytes per date and lane: coalesced)
+GATHER_KERNELS = ('omnibus_c3_search_kernel', 'omnibus_c3_search_starts_kernel')
+
+
+def fetch_factor(kernel_name):
+    return 1.0 if any(g in kernel_name for g in GATHER_KERNELS) else 2.0
 
 
 def per_kernel(path, counter):
@@ -26,8 +48,10 @@ def main():
     import bench
     out = {'commit': commit, 'csrc_sha': bench.csrc_sha(), 'unit': 'bytes per launch',
            'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of '
-                     '`python3 bench.py --traffic-run KEY`; traffic = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 '
-                     '(gfx950 correction of MI355X_MICROARCH.md), mean over the launches of the run',
+                     '`python3 bench.py --traffic-run KEY`; traffic = fetch_factor x FETCH_SIZE x 1024 + WRITE_SIZE '
+                     'x 1024, fetch_factor = 2 for coalesced reads, 1 for the gather kernels (calibration: '
+                     'profiles/r05_fetch_calibration.json, rule: tools/summarize_traffic.py), mean over the '
+                     'launches of the run',
            'workloads': {}}
     for k in keys:
         try:
@@ -42,8 +66,9 @@ def main():
             f = sum(v) / len(v) * 1024.0
             w = wr.get(name, [0.0])
             w = sum(w) / len(w) * 1024.0
-            rows.append({'kernel': name, 'launches': len(v), 'fetch_bytes_x2': 2.0 * f, 'write_bytes': w,
-                         'traffic_bytes': 2.0 * f + w})
+            ff = fetch_factor(name)
+            rows.append({'kernel': name, 'launches': len(v), 'fetch_size_bytes': f, 'fetch_factor': ff,
+                         'fetch_bytes': ff * f, 'write_bytes': w, 'traffic_bytes': ff * f + w})
         out['workloads'][k] = sorted(rows, key=lambda r: -r['traffic_bytes'])
     print(json.dumps(out, indent=1))
 

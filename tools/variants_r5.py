@@ -3,7 +3,7 @@
 
     python tools/variants_r5.py build [names...]
 
-A variant = (file, [(old text, new text), ...]).  Round 5's experiments; the ones that won are in the
+A variant = (file, [(old text, new text), ...], [extra compiler flags]).  Round 5's experiments; the ones that won are in the
 sources, the table stays as the record of what was tried."""
 import os
 import shutil
@@ -16,11 +16,10 @@ VDIR = os.path.join(ROOT, '_variants')
 
 VARIANTS = {
     # pixel-major dense form: C11 / C22 pieces with plain (temporal) loads instead of non-temporal ones
-    'pm_temporal': ('omnibus.hip', [
-        ("                qa[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p11) + u);\n"
-         "                qd[u] = __builtin_nontemporal_load(reinterpret_cast<const tv *>(p22) + u);",
-         "                qa[u] = *(reinterpret_cast<const tv *>(p11) + u);\n"
-         "                qd[u] = *(reinterpret_cast<const tv *>(p22) + u);")]),
+    # pm_temporal (C11 / C22 pieces with plain instead of non-temporal loads): adopted in round 5,
+    # 1.86 -> 1.49 ms, 8.19 -> 6.44 GB of traffic (gpurun_out/r5_exp1)
+    # C12 straight into registers as well (no LDS image):
+    'pm_direct_c12': ('omnibus.hip', [], ['-DND_PM_DIRECT_C12']),
 }
 
 
@@ -29,7 +28,7 @@ def build(names):
     os.makedirs(VDIR, exist_ok=True)
     procs = []
     for name in names:
-        fname, patches = VARIANTS[name]
+        fname, patches, flags = VARIANTS[name]
         d = os.path.join(VDIR, 'src_' + name)
         shutil.rmtree(d, ignore_errors=True)
         shutil.copytree(B.CSRC, d, ignore=shutil.ignore_patterns('_build'))
@@ -43,7 +42,7 @@ def build(names):
             s = s.replace(old, new)
         open(p, 'w').write(s)
         obj = os.path.join(VDIR, '%s_%s.o' % (fname[:-4], name))
-        cmd = [B.HIPCC] + B.FLAGS + B.PER_FILE.get(fname, []) + ['-c', p, '-o', obj]
+        cmd = [B.HIPCC] + B.FLAGS + B.PER_FILE.get(fname, []) + flags + ['-c', p, '-o', obj]
         procs.append((name, fname, obj, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
     for name, fname, obj, pr in procs:
         assert pr.wait() == 0, name
