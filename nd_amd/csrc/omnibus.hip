@@ -643,7 +643,7 @@ __device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int 
 // (k contiguous values) straight into registers, every 16-byte piece in flight at once -- the lines
 // are shared by neighbouring lanes and consecutive pieces, so they are fetched once -- and the image
 // is half the size: twice the waves per CU (24 x 4096^2: 2.5 -> 2.0 ms).  C12 as well, no image at
-// all: 3.3 ms -- its 192-byte pitch per lane is too much for the address coalescer.
+// all: 3.3 ms with non-temporal loads (round 3), 1.49 against 1.45 ms with plain ones (round 5): no gain.
 // (CHAIN, float32: capped at the registers of three waves per SIMD -- the 24-date DIRECT form took 170,
 // two short of it, and ran at two: 1.99 -> 1.86 ms; the float64 forms would spill under the cap.  A
 // persistent form -- as many waves as the chip holds, each walking spans gridDim.x apart, to spare the
@@ -684,13 +684,8 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
         stage(g.c11, 0);
         stage(g.c22, 3);
     }
-#ifdef ND_PM_DIRECT_C12
-    if (!(DIRECT && pm.c12_joint))
-#endif
-    {
-        stage(g.c12r, 1);
-        if (!pm.c12_joint) stage(g.c12i, 2);
-    }
+    stage(g.c12r, 1);
+    if (!pm.c12_joint) stage(g.c12i, 2);
 
     if (g.write_tab && b == 0) {
         for (int j = lane; j <= k; j += 64) g.tab_dev[j] = tab.e[j];
@@ -721,18 +716,6 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
 #pragma unroll
         for (int u = 0; u < KMAX / VE; ++u) asm volatile("" : "+v"(qa[u]), "+v"(qd[u]));
     }
-#ifdef ND_PM_DIRECT_C12
-    // experiment: C12 (interleaved complex) straight into registers as well, no LDS image
-    tv qx[(DIRECT && CHAIN) ? 2 * KMAX / VE : 1];
-    if (DIRECT && pm.c12_joint) {
-        const T *p12 = g.c12r + (px0 + own) * (int64_t)(2 * k);
-#pragma unroll
-        for (int u = 0; u < 2 * KMAX / VE; ++u)
-            if (u * VE < 2 * k) qx[u] = *(reinterpret_cast<const tv *>(p12) + u);
-#pragma unroll
-        for (int u = 0; u < 2 * KMAX / VE; ++u) asm volatile("" : "+v"(qx[u]));
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- this lane's series out of the images (idle lanes copy the last pixel) ----
@@ -758,16 +741,6 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     pm_pick<T, KMAX, 0, false>(v, img + pm.img_off[0] + own * k * pm.ids[0], k, pm.ids[0]);
     pm_pick<T, KMAX, 3, false>(v, img + pm.img_off[3] + own * k * pm.ids[3], k, pm.ids[3]);
     }
-#ifdef ND_PM_DIRECT_C12
-    if (DIRECT && pm.c12_joint) {
-#pragma unroll
-        for (int u = 0; u < 2 * KMAX / VE; ++u)
-            if (u * VE < 2 * k) {
-#pragma unroll
-                for (int i = 0; i < VE; ++i) v[(u * VE + i) / 2][1 + ((u * VE + i) & 1)] = qx[u][i];
-            }
-    } else
-#endif
     if (pm.c12_joint) {
         pm_pick<T, KMAX, 1, true>(v, img + pm.img_off[1] + own * k * 2, k, 2);
     } else {

@@ -44,11 +44,23 @@
 // Traffic: 4 k planes x (12 + 2h) / 12 rows, nothing else.  Work: w^2 dependent double additions per
 // value (scipy's order leaves no sharing between neighbouring windows) -- vector issue, not memory,
 // is what bounds the kernel.
-#include "omnibus_c2_device.hpp"
+#include "omnibus_ml_common.hpp"
 
 namespace nd_amd {
 
-typedef __attribute__((address_space(3))) float ml_lds_f32;
+// Steps the L2 prefetch of the idle waves (8 .. 11) runs ahead of the transfers.  0 = none, the default:
+// measured in round 5 (24 x 4096^2, 3 x 3 / 5 x 5 window, one box): none 2.03 / 3.13 ms, one step ahead
+// 2.14 / 3.27, two 2.15 / 3.22, three 2.14 / 3.34, five 2.23 / 3.34, eight 2.31 / 3.36 -- the more requests
+// in flight the slower: the walk is not waiting for memory (a staging-only probe of the same walk,
+// tools/probe_tiles.hip, moves the 3 x 3 kernel's bytes in 1.24 ms).
+#ifndef ND_ML_PREFETCH
+#define ND_ML_PREFETCH 0
+#endif
+#ifdef ND_ML_TRACE
+#define ND_ML_TRC_WORDS (12 * 16 * 5)
+#else
+#define ND_ML_TRC_WORDS 0
+#endif
 
 template <int K>
 struct MlGeom {
@@ -62,18 +74,6 @@ struct MlGeom {
     static constexpr int NCAR = G * ROWS * 2 * HALO;              // carried elements per step
     static constexpr int NSLOT = K == 3 ? 3 : 2;                  // NSLOT - 1 steps of transfers in flight (LDS budget)
     static_assert(ROWS <= PROWS, "window too tall for the plane image");
-};
-
-struct OmniMlArgs {
-    int64_t ny, nx;           // raster
-    int segw;                 // columns per segment (multiple of 64)
-    int xsegs;                // segments per strip
-    int tmax;                 // tile numbers per strip: ceil(nx / 64) + 2
-    int x4;                   // rows and planes 16-byte aligned: 16-byte transfers allowed
-    double wt;                // 1 / ml^2 (nd/filters.py:297)
-    int list;                 // 0: no candidate list (z / P rasters only)
-    unsigned long long *trace;   // ND_ML_TRACE builds: time stamps of one block (tools/exp_ml_trace.py)
-    int trace_block;
 };
 
 // all LDS operations of this wave done, then the workgroup barrier (no wait for the LDS-DMA transfers
@@ -97,19 +97,6 @@ __device__ __forceinline__ void ml_wait_vm(const int n)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-__device__ __forceinline__ int ml_reflect(int cc, const int len)     // scipy 'reflect': d c b a | a b c d | d c b a
-{
-    if (cc >= 0 && cc < len) return cc;
-    const int sz2 = 2 * len;
-    // (no division: the columns asked for lie within a tile of the raster, the loops run at most a
-    //  few times, and only for rasters narrower than a tile)
-    while (cc < -len) cc += sz2;
-    while (cc >= sz2) cc -= sz2;
-    if (cc < 0) return -cc - 1;
-    if (cc >= len) return sz2 - cc - 1;
-    return cc;
 }
 
 // LDS-DMA from inline assembly (see the header): memory -> LDS at `lds_addr` + (4 | 16) * lane.
@@ -181,36 +168,6 @@ __device__ __forceinline__ ml_v4i ml_make_rsrc(const float *p)
     return r;
 }
 
-// The rows of the change map of `n` consecutive pixels, lanes lo .. lo + n - 1 of the wave, from the
-// lanes' masks: through a wave-private LDS image (k / 4 words per lane), then 16-byte pieces of
-// consecutive lanes wherever the destination allows (the span of a shifted tile starts on a 4-byte
-// boundary only).  k a multiple of 4.
-template <typename MT>
-__device__ __forceinline__ void ml_store_change_rows(uint8_t *ob, uint32_t *img, const int k, const MT &mask,
-                                                     const int lane, const int lo, const int n)
-{
-    const int kq = k >> 2;
-    for (int q = 0; q < kq; ++q)
-        img[lane * kq + q] = (mask_nibble(mask, q) * 0x00204081u) & 0x01010101u;     // bit i -> byte i
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const uint32_t *src = img + lo * kq;
-    uint32_t *dst = reinterpret_cast<uint32_t *>(ob);
-    const int nw = n * kq;                                       // words to write
-    int head = (int)(((16 - ((uintptr_t)ob & 15)) & 15) >> 2);
-    if (head > nw) head = nw;
-    if (lane < head) dst[lane] = src[lane];
-    const int nvec = (nw - head) >> 2;
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    for (int c = lane; c < nvec; c += 64) {
-        const uint32_t *s = src + head + 4 * c;
-        const u4 q = {s[0], s[1], s[2], s[3]};
-        __builtin_nontemporal_store(q, reinterpret_cast<u4 *>(dst + head) + c);
-    }
-    const int tail0 = head + 4 * nvec;
-    if (tail0 + lane < nw) dst[tail0 + lane] = src[tail0 + lane];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
 template <int K, int KMAX, bool STATS, bool CHAIN>
 __global__ void __launch_bounds__(64 * kMlTileRows)
 omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const OmniMlArgs ml,
@@ -225,6 +182,7 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     float *carry = slots + M::NSLOT * M::SLOT;                            // [NSTEP][8][ROWS][2h]
     StreamEntry *tab_lds = reinterpret_cast<StreamEntry *>(carry + NSTEP * M::NCAR);
     int *rowtab = reinterpret_cast<int *>(tab_lds + 33);                  // byte offsets of the 16 image rows
+
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -253,6 +211,11 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
     // ---- staging ----
     const float *vp[4] = {g.c11, g.c12r, g.c12i, g.c22};
     const unsigned lds0 = (unsigned)(uintptr_t)(ml_lds_f32 *)slots;       // LDS byte address of the slots
+#if ND_ML_PREFETCH > 0
+    // 256 bytes behind the table (and the trace area of diagnostic builds): where the prefetch reads land
+    const unsigned pf_dump = lds0 + (unsigned)(reinterpret_cast<unsigned char *>(rowtab + 16 + ND_ML_TRC_WORDS) -
+                                               reinterpret_cast<unsigned char *>(slots));
+#endif
     const int sstep = (int)g.st * 4;                             // bytes between dates (host: k * st * 4 < 2^31)
     // Waves 0 .. 7 stage: wave w the plane w of the step (variable w & 3, date w >> 2), whose LDS image
     // (16 rows x 256 bytes) is within reach of the transfers' 12-bit offset from one value of M0.
@@ -396,6 +359,36 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                     cnt_new = stage(s2, X2, slot_p);
                 }
 #endif
+#if ND_ML_PREFETCH > 0
+                // ---- the waves that stage nothing (8 .. 11) ask for the planes of step S + PF + D: one
+                //      4-byte LDS-DMA read per 128-byte line into a dump area nobody reads (no register
+                //      to keep, nothing to wait for).  The lines then sit in the L2 (or the Infinity Cache)
+                //      when the transfers of that step are issued D steps later ----
+                if (!stager && S + PF + ND_ML_PREFETCH < total_steps) {
+                    int s3 = s + PF + ND_ML_PREFETCH, X3 = Xi;
+                    while (s3 >= nstep_k) {
+                        s3 -= nstep_k;
+                        X3 += 64;
+                    }
+                    constexpr int PFL = 2 * ROWS;                // lines of a plane's 64 new columns
+                    const int hi = lane >= PFL ? 1 : 0;
+                    const int pl = 2 * (wave - 8) + hi, lr = lane - hi * PFL;
+                    if (lane < 2 * PFL && X3 < nx) {
+                        int t = 2 * s3 + (pl >> 2);
+                        t = t < k ? t : k - 1;
+                        int xc = X3 + 32 * (lr & 1);
+                        xc = xc < nx ? xc : nx - 1;
+                        const int var = pl & 3;
+                        const float *pb = var == 0 ? g.c11 : (var == 1 ? g.c12r : (var == 2 ? g.c12i : g.c22));
+                        const float *pp = pb + (int64_t)t * g.st + (rowtab[lr >> 1] >> 2) + xc;
+                        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                                     "global_load_lds_dword %1, off"
+                                     :
+                                     : "s"(__builtin_amdgcn_readfirstlane((int)pf_dump)), "v"(pp)
+                                     : "memory");
+                    }
+                }
+#endif
                 // (a series of one step per tile: the columns saved above are the ones this very step
                 //  reads -- the only case in which A and B of one step touch the same carry entries)
                 if (nstep_k == 1) ml_barrier();
@@ -457,7 +450,8 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
                 }
                 ML_STAMP(2);
                 // ---- C: the transfers of the next step have landed (this wave's), then everybody's ----
-                ml_wait_vm(PF >= 2 ? cnt_new : 0);
+                // (the waves that stage nothing have nothing to wait for: their prefetch reads go nowhere)
+                if (stager || ND_ML_PREFETCH == 0) ml_wait_vm(PF >= 2 ? cnt_new : 0);
                 ML_STAMP(3);
                 ml_barrier();
                 ML_STAMP(4);
@@ -616,11 +610,7 @@ static int launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, const
 {
     typedef MlGeom<K> M;
     const size_t lds = ((size_t)M::NSLOT * M::SLOT + 2 * M::RES + (size_t)(KMAX / 2) * M::NCAR) * sizeof(float) +
-                       33 * sizeof(StreamEntry) + 16 * sizeof(int)
-#ifdef ND_ML_TRACE
-                       + 12 * 16 * 5 * 4
-#endif
-        ;
+                       33 * sizeof(StreamEntry) + 16 * sizeof(int) + ND_ML_TRC_WORDS * 4 + (ND_ML_PREFETCH > 0 ? 256 : 0);
     const dim3 grid((unsigned)nblocks), block(M::NT);
     StreamScreen<32> none;
     if (!ss) memset(&none, 0, sizeof(none));
@@ -661,6 +651,7 @@ int launch_ml_pass_a(const OmniGlobalArgs<float> &g, const OmniTab &tab, const O
     }
     a.wt = 1.0 / (double)(p.ml * p.ml);
     a.list = list ? 1 : 0;
+    a.spx = a.nstrips = 0;
     a.trace = nullptr;
     a.trace_block = 1000;
 #ifdef ND_ML_TRACE

@@ -18,8 +18,17 @@ VARIANTS = {
     # pixel-major dense form: C11 / C22 pieces with plain (temporal) loads instead of non-temporal ones
     # pm_temporal (C11 / C22 pieces with plain instead of non-temporal loads): adopted in round 5,
     # 1.86 -> 1.49 ms, 8.19 -> 6.44 GB of traffic (gpurun_out/r5_exp1)
-    # C12 straight into registers as well (no LDS image):
-    'pm_direct_c12': ('omnibus.hip', [], ['-DND_PM_DIRECT_C12']),
+    # pm_direct_c12 (C12 straight into registers as well, no LDS image; -DND_PM_DIRECT_C12, code since removed):
+    # 1.49 against 1.45 ms -- no gain (gpurun_out/r5_exp2)
+    # mlw_* (the wave-private form of the fused multilooking kernel, tools/experiments/omnibus_mlw.hip, as
+    # omnibus_mlw.hip in csrc at the time): 6 waves x 2 slots 2.69 ms, 4 waves x 3 slots 2.30 ms, two waves
+    # per SIMD 2.67 ms, against 2.04 ms for the block form on the same box (gpurun_out/r5_ml)
+    # the block form: L2 prefetch by the idle waves, steps ahead of the transfers
+    'ml_pf0': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=0']),
+    'ml_pf1': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=1']),
+    'ml_pf2': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=2']),
+    'ml_pf5': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=5']),
+    'ml_pf8': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=8']),
 }
 
 
