@@ -273,10 +273,13 @@ int nd_amd_nlmeans3d(const void *arr, void *out, int dtype,
  *     ptr_v[((y * nx + x) * k + t) * date_stride[v]]
  * (order C11, C12re, C12im, C22).  date_stride = 1 for a real (y, x, time)
  * array; 2, with c12im == c12re + 1, for the two halves of an interleaved
- * complex C12 (read once).  k <= 24 (float32; float64: k <= 12); larger
- * series return ND_AMD_EUNSUPPORTED -- transpose with
- * nd_amd_relayout_planar and call nd_amd_omnibus_c2.  Workspace as for
- * nd_amd_omnibus_c2.
+ * complex C12 (read once).  Every threshold up to k = 24 dates (float32;
+ * float64: 12).  Longer series (up to 192 dates, a multiple of 4 -- float64:
+ * of 2 --, 16-byte aligned variables) in the sparse regime, alpha >= 0.75:
+ * the series is folded out of LDS images instead of being retained, and the
+ * search reads a listed pixel's series where it lies.  Everything else
+ * returns ND_AMD_EUNSUPPORTED -- transpose with nd_amd_relayout_planar and
+ * call nd_amd_omnibus_c2.  Workspace as for nd_amd_omnibus_c2.
  * ---------------------------------------------------------------------- */
 int nd_amd_omnibus_c2_pixel_major(const void *c11, const void *c12re, const void *c12im,
                                   const void *c22, int dtype,

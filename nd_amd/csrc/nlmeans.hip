@@ -721,11 +721,22 @@ __global__ void __launch_bounds__(32 * (kWinTY / OY), WPE) nlmeans_window_stream
             cen[py][i] = 0.f;
         }
 
+    // (round 5) Two things the first and last steps do not need.  (i) At the ends of the axis the staged
+    // sequence repeats a plane (whole-sample reflection: -1 -> 0, N -> N - 1): the plane is already in the
+    // current slot, so nothing is transferred and the slots do not swap -- 2 of k + 2 planes of reads.
+    // (ii) Step 0 only starts slice `first` (the sums `c`): the slices q - 1 and q of `ab` do not exist, and
+    // the last two steps start no slice: their `c` sums would be thrown away -- 784 of the 16 016 vector
+    // additions a thread issues per tile at 24 dates.
+    int slot = 0;
+    int64_t pcur = zmap(first - 1);
     for (int s = 0; s < nsteps; ++s) {
         const int64_t q = first - 1 + s;
         const bool has_next = s + 1 < nsteps;
-        if (has_next) stage(zmap(q + 1), (s + 1) & 1);
-        const float *P = slots + (s & 1) * PSZ + ly * COLSP + lx;
+        const int64_t pnext = has_next ? zmap(q + 1) : pcur;
+        const bool same = pnext == pcur;
+        if (has_next && !same) stage(pnext, slot ^ 1);
+        const bool do_ab = s >= 1, do_c = s + 2 < nsteps;
+        const float *P = slots + slot * PSZ + ly * COLSP + lx;
 #pragma unroll
         for (int pr = 0; pr < OY / 2; ++pr)
 #pragma unroll
@@ -744,6 +755,7 @@ __global__ void __launch_bounds__(32 * (kWinTY / OY), WPE) nlmeans_window_stream
                 w[4 * cc + 3] = t.w;
             }
             // slices q - 1 and q: this row is window row d of output row py
+            if (do_ab) {
 #pragma unroll
             for (int py = 0; py < OY; ++py) {
                 const int d = ry - py;
@@ -758,7 +770,9 @@ __global__ void __launch_bounds__(32 * (kWinTY / OY), WPE) nlmeans_window_stream
                         }
                 }
             }
+            }
             // slice q + 1 (no centre in its first plane): vertical pairs
+            if (do_c) {
 #pragma unroll
             for (int pr = 0; pr < OY / 2; ++pr) {
                 const int du = ry - 2 * pr, dl = du - 1;
@@ -782,6 +796,7 @@ __global__ void __launch_bounds__(32 * (kWinTY / OY), WPE) nlmeans_window_stream
 #pragma unroll
                         for (int i = 0; i < 4; ++i) c[pr][i].y = c[pr][i].y + w[dx + i];
                 }
+            }
             }
             // Keep the rows apart.  The sums of slice q + 1 are only needed when the roles move on,
             // and left alone the optimiser sinks all their additions below the output code -- with
@@ -837,8 +852,12 @@ __global__ void __launch_bounds__(32 * (kWinTY / OY), WPE) nlmeans_window_stream
             }
         }
         // the next plane has landed (this wave's transfers) and every wave is done with this one
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!same) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            slot ^= 1;
+        }
+        pcur = pnext;
     }
 }
 

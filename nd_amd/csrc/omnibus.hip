@@ -823,6 +823,113 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     if (!dense) zero_fill_span(g.change + px0 * (int64_t)k, np * k, lane);
 }
 
+
+// -----------------------------------------------------------------------------------------
+// pass A for the reference's layout BEYOND the register-retaining sizes (25 .. 192 dates): the wave's span
+// of every variable (PXW pixels x k dates, contiguous in memory) goes into wave-private LDS images exactly
+// as in omnibus_c2_pm_dma_kernel -- every transfer in flight at once, no barrier -- and each lane folds
+// its pixel's series out of the images in time order (16-byte LDS reads) instead of retaining it.  PXW =
+// 64, 32 or 16 pixels per wave (the upper lanes idle), whatever keeps the images within 48 KB: three
+// waves per CU and 144 KB of transfers in flight.  No dump: pass B reads a listed pixel's series from the
+// variables themselves, where it is contiguous (nd/change.py:66-67 hands the native code this layout for
+// any series length; up to round 4 such inputs went through the transpose kernels and the planar path:
+// three trips over the stack).
+// -----------------------------------------------------------------------------------------
+// JOINT: C12 is one interleaved complex array (one image, re at the even places); otherwise four real
+// arrays.  (Other mixes of date strides are left to the transpose route.)
+template <typename T, int PXW, bool STATS, bool JOINT>
+__global__ void __launch_bounds__(64) omnibus_c2_pm_long_kernel(const OmniGlobalArgs<T> g, const OmniTab tab,
+                                                             const OmniPmDmaArgs<T> pm)
+{
+    constexpr int VE = 16 / (int)sizeof(T);
+    extern __shared__ __align__(16) unsigned char nd_smem_dma[];
+    T *img = reinterpret_cast<T *>(nd_smem_dma);
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t px0 = b * PXW;
+    const int64_t x0 = px0 + lane;
+    const int k = g.k;
+    const bool in = lane < PXW && x0 < g.nx;
+    const int64_t left = g.nx - px0;
+    const int np = left > PXW ? PXW : (int)left;
+
+    // ---- every transfer of the wave in flight ----
+    auto stage = [&](const T *base, int vi) {
+        const int wpp = k * pm.ids[vi];                     // elements per pixel in memory
+        const int bytes = np * wpp * (int)sizeof(T);        // multiple of 16 (host checks k)
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(base + px0 * wpp);
+        unsigned char *dst = reinterpret_cast<unsigned char *>(img + pm.img_off[vi]);
+        for (int c0 = 0; c0 < bytes; c0 += 1024) {
+            const int eb = c0 + lane * 16;
+            if (eb < bytes)
+                __builtin_amdgcn_global_load_lds((glb_u8_t *)(src + eb), (lds_u8_t *)(dst + c0), 16, 0, kNtAux);
+        }
+    };
+    stage(g.c11, 0);
+    stage(g.c12r, 1);
+    if (!JOINT) stage(g.c12i, 2);
+    stage(g.c22, 3);
+    if (g.write_tab && b == 0) {
+        for (int j = lane; j <= k; j += 64) g.tab_dev[j] = tab.e[j];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- fold this lane's series in time order (idle lanes fold the last pixel of the span) ----
+    const int own = (lane < np) ? lane : np - 1;
+    typedef Pack<T, VE> PV;
+    const PV *i11 = reinterpret_cast<const PV *>(img + pm.img_off[0] + own * k);
+    const PV *i22 = reinterpret_cast<const PV *>(img + pm.img_off[3] + own * k);
+    const PV *i12 = reinterpret_cast<const PV *>(img + pm.img_off[1] + own * k * (JOINT ? 2 : 1));
+    const PV *i12i = reinterpret_cast<const PV *>(img + pm.img_off[2] + own * k);        // (not JOINT)
+    Accum<T> A;
+    A.reset();
+    const int nv = k / VE;
+    for (int u = 0; u < nv; ++u) {
+        const PV a = i11[u], d = i22[u];
+        PV br, bi;
+        if (JOINT) {
+            const PV q0 = i12[2 * u], q1 = i12[2 * u + 1];      // (re, im) pairs of VE dates
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                br.v[j] = (j < VE / 2 ? q0 : q1).v[2 * (j % (VE / 2))];
+                bi.v[j] = (j < VE / 2 ? q0 : q1).v[2 * (j % (VE / 2)) + 1];
+            }
+        } else {
+            br = i12[u];
+            bi = i12i[u];
+        }
+#pragma unroll
+        for (int j = 0; j < VE; ++j) A.step(a.v[j], br.v[j], bi.v[j], d.v[j]);
+    }
+
+    bool flag;
+    if (STATS) {
+        const T z = z_stat<T>(A, k, g.nlooks, g.e);
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        flag = in && ((double)P > g.alpha);
+        if (in) {
+            if (g.z_out) g.z_out[x0] = z;
+            if (g.p_out) g.p_out[x0] = P;
+        }
+    } else {
+        flag = in && (z_approx<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
+    }
+
+    // ---- list (no dump: the series of a listed pixel is contiguous in the variables themselves) ----
+    const unsigned long long m = __ballot(flag);
+    if (m != 0ull) {
+        const unsigned shard = (unsigned)(b % kShards);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag) g.flag_idx[(size_t)shard * g.seg + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)x0;
+    }
+    // ---- zero-fill this wave's slice of the change map (np.zeros at nd/_change.pyx:275) ----
+    zero_fill_span(g.change + px0 * (int64_t)k, np * k, lane);
+}
+
 // =========================================================================================
 // dense waves: the change-point search from registers
 // =========================================================================================
@@ -3144,10 +3251,65 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             set_error("nd_amd_omnibus_c2_ml: float32 only");
             return ND_AMD_EUNSUPPORTED;
         }
+    } else if (pm_ids != nullptr && k > (sizeof(T) == 4 ? 24 : 12)) {       // (the pixel-major register forms end there)
+        // beyond the register-retaining sizes: LDS images folded in place, in the sparse regime; at low
+        // thresholds (nearly every pixel changes) the caller transposes and takes the planar streaming search
+        constexpr int VE = 16 / (int)sizeof(T);
+        OmniPmDmaArgs<T> dm;
+        for (int vi = 0; vi < 4; ++vi) dm.ids[vi] = (int)pm_ids[vi];
+        dm.c12_joint = (pm_ids[1] == 2 && pm_ids[2] == 2 &&
+                        static_cast<const T *>(c12im) == static_cast<const T *>(c12re) + 1) ? 1 : 0;
+        const bool dma_ok = (k % VE) == 0 &&
+                            (((uintptr_t)c11 | (uintptr_t)c22 | (uintptr_t)c12re) & 15) == 0 &&
+                            (dm.c12_joint || ((uintptr_t)c12im & 15) == 0);
+        const int64_t per_px = k * (pm_ids[0] + pm_ids[3] + pm_ids[1] + (dm.c12_joint ? 0 : pm_ids[2]));   // elements
+        const int pxw = 64 * per_px * (int64_t)sizeof(T) <= 48 * 1024 ? 64
+                        : (32 * per_px * (int64_t)sizeof(T) <= 48 * 1024 ? 32
+                           : (16 * per_px * (int64_t)sizeof(T) <= 48 * 1024 ? 16 : 0));
+        const bool four_real = pm_ids[0] == 1 && pm_ids[1] == 1 && pm_ids[2] == 1 && pm_ids[3] == 1;
+        const bool joint = pm_ids[0] == 1 && pm_ids[3] == 1 && dm.c12_joint;
+        if (!dma_ok || pxw == 0 || !(alpha >= fused_alpha) || !(four_real || joint)) {
+            set_error("nd_amd_omnibus_c2_pixel_major: %lld dates: beyond the register-retaining sizes only 16-byte "
+                      "aligned series of a multiple of %d dates, up to 48 KB per 16 pixels, at alpha >= %g "
+                      "(transpose and call nd_amd_omnibus_c2 otherwise)", (long long)k, VE, fused_alpha);
+            return ND_AMD_EUNSUPPORTED;
+        }
+        int off = 0;
+        const int order[4] = {0, 1, 2, 3};
+        for (int oi = 0; oi < 4; ++oi) {
+            const int vi = order[oi];
+            dm.img_off[vi] = off;
+            if (vi == 2 && dm.c12_joint) {
+                dm.img_off[2] = dm.img_off[1];               // shares the image of C12 re
+                continue;
+            }
+            off += pxw * (int)k * dm.ids[vi];
+        }
+        const size_t lds_long = (size_t)off * sizeof(T);
+        g.dump_cap = 0;                          // nothing is dumped: pass B reads the series where they lie
+        const dim3 gridw((unsigned)ceil_div(npix, (int64_t)pxw)), blockw(64);
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+#define ND_LAUNCH_PM_LONG(PXW_)                                                                               \
+    do {                                                                                                      \
+        if (stats && joint)                                                                                   \
+            hipLaunchKernelGGL((omnibus_c2_pm_long_kernel<T, PXW_, true, true>), gridw, blockw, lds_long, stream, g, tab, dm);   \
+        else if (stats)                                                                                       \
+            hipLaunchKernelGGL((omnibus_c2_pm_long_kernel<T, PXW_, true, false>), gridw, blockw, lds_long, stream, g, tab, dm);  \
+        else if (joint)                                                                                       \
+            hipLaunchKernelGGL((omnibus_c2_pm_long_kernel<T, PXW_, false, true>), gridw, blockw, lds_long, stream, g, tab, dm);  \
+        else                                                                                                  \
+            hipLaunchKernelGGL((omnibus_c2_pm_long_kernel<T, PXW_, false, false>), gridw, blockw, lds_long, stream, g, tab, dm); \
+    } while (0)
+        if (pxw == 64)
+            ND_LAUNCH_PM_LONG(64);
+        else if (pxw == 32)
+            ND_LAUNCH_PM_LONG(32);
+        else
+            ND_LAUNCH_PM_LONG(16);
+#undef ND_LAUNCH_PM_LONG
     } else if (pm_ids != nullptr) {
-        if (!retain || !flat) {
-            set_error("nd_amd_omnibus_c2_pixel_major: %lld dates exceed the register-retaining sizes",
-                      (long long)k);
+        if (!flat) {
+            set_error("nd_amd_omnibus_c2_pixel_major: the variables must be contiguous");
             return ND_AMD_EUNSUPPORTED;
         }
         OmniPmArgs<T> pm;
@@ -3598,8 +3760,8 @@ extern "C" int nd_amd_omnibus_c2_pixel_major(const void *c11, const void *c12re,
         set_error("nd_amd_omnibus_c2_pixel_major: n_looks must be >= 1");
         return ND_AMD_EINVAL;
     }
-    if (ny * nx >= 0xffffffffLL || k > 24) {
-        set_error("nd_amd_omnibus_c2_pixel_major: at most 24 dates and 2^32 - 1 pixels");
+    if (ny * nx >= 0xffffffffLL || k > 192) {
+        set_error("nd_amd_omnibus_c2_pixel_major: at most 192 dates and 2^32 - 1 pixels");
         return ND_AMD_EUNSUPPORTED;
     }
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);

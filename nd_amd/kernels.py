@@ -120,7 +120,14 @@ def change_detection_multilooked(c11, c12re, c12im, c22, alpha, ml, stats=False)
         change = torch.empty((ny, nx, k), dtype=torch.uint8, device=dev)
         z = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
         P = torch.empty((ny, nx), dtype=c11.dtype, device=dev) if stats else None
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # The dump of the fused path has a slot for every pixel of the raster (the multilooked series exists
+        # nowhere else), about the size of the input, of which only the listed part is ever touched.  torch's
+        # caching allocator hands the same block back from call to call; where the memory is not there the
+        # caller takes the two-step path (boxcar kernel, then the plain test), which needs none.
+        try:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            return None
         rc = L.nd_amd_omnibus_c2_ml(_ptr(c11), _ptr(c12re), _ptr(c12im), _ptr(c22), _lib.F32, ny, nx, k,
                                     sy, sx, st, int(ml), float(alpha), _ptr(change), _ptr(z), _ptr(P),
                                     _ptr(ws), nbytes, _stream_ptr(dev))
@@ -141,8 +148,10 @@ def change_detection_pixel_major(c11, c12re, c12im, c22, alpha, n=1, stats=False
         return None
     ny, nx, k = c11.shape
     dt = c11.dtype
-    if dt not in _DT or k > (24 if dt == torch.float32 else 12) or ny * nx * k == 0:
+    if dt not in _DT or k > 192 or ny * nx * k == 0:
         return None
+    # beyond the register-retaining sizes the kernel takes the sparse regime only (include/nd_amd.h)
+    long_series = k > (24 if dt == torch.float32 else 12)
     ids = []
     for t in vs:
         if t.shape != c11.shape or t.dtype != dt or t.device != c11.device:
@@ -164,10 +173,13 @@ def change_detection_pixel_major(c11, c12re, c12im, c22, alpha, n=1, stats=False
         P = torch.empty((ny, nx), dtype=dt, device=dev) if stats else None
         nbytes = L.nd_amd_omnibus_c2_workspace_bytes(_DT[dt], ny, nx, k, None)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _lib.check(L.nd_amd_omnibus_c2_pixel_major(
+        rc = L.nd_amd_omnibus_c2_pixel_major(
             _ptr(c11), _ptr(c12re), _ptr(c12im), _ptr(c22), _DT[dt], ny, nx, k,
             _lib.i64_array(ids), int(n), float(alpha), _ptr(change), _ptr(z), _ptr(P), _ptr(ws), nbytes,
-            _stream_ptr(dev)))
+            _stream_ptr(dev))
+        if long_series and rc == _lib.EUNSUPPORTED:
+            return None                   # the caller transposes and takes the planar path
+        _lib.check(rc)
         ws.record_stream(torch.cuda.current_stream(dev))
     return (change, z, P) if stats else change
 

@@ -164,6 +164,40 @@ def test_pixel_major_kernel_equals_planar(oracle, device, dtype, k):
     assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
 
 
+@pytest.mark.parametrize('dtype,k', [(np.float32, 28), (np.float32, 48), (np.float32, 96), (np.float32, 128),
+                                     (np.float32, 192), (np.float64, 16), (np.float64, 48), (np.float64, 96)])
+def test_pixel_major_long_series(oracle, device, dtype, k):
+    """The reference's layout beyond the register-retaining sizes (nd/change.py:66-67 hands the native code
+    (y, x, time) arrays of any length): in the sparse regime the pixel-major entry point folds the series
+    out of LDS images (64, 32 or 16 pixels per wave) and the search reads the listed series in place.
+    Interleaved complex C12 and two real arrays, ragged rasters, z / P rasters; below the sparse regime and
+    for lengths that are not whole 16-byte vectors the entry point declines (the caller transposes)."""
+    import torch
+    from nd_amd import kernels
+    from tests import synth as tsynth
+    for ny, nx in [(1, 5), (7, 70), (20, 131)]:
+        planes = tsynth.omnibus_stack(seed=ny + nx + k, k=k, ny=ny, nx=nx, dtype=dtype, change_frac=0.3)
+        yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+        dev = [torch.from_numpy(a).to(device) for a in yxt]
+        c12 = torch.complex(dev[1], dev[2])
+        for alpha in (0.8, 0.99):
+            want, zw, pw = oracle.change_detection_planes(yxt, alpha, 9, njobs=4, stats=True)
+            got = kernels.change_detection_pixel_major(dev[0], dev[1], dev[2], dev[3], alpha=alpha, n=9)
+            assert got is not None
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
+            res = kernels.change_detection_pixel_major(dev[0], c12.real, c12.imag, dev[3], alpha=alpha, n=9,
+                                                       stats=True)
+            np.testing.assert_array_equal(res[0].cpu().numpy(), want)
+            np.testing.assert_allclose(res[1].cpu().numpy(), zw, rtol=1e-5, equal_nan=True)
+            np.testing.assert_allclose(res[2].cpu().numpy(), pw, rtol=1e-5, atol=1e-7, equal_nan=True)
+        # low thresholds: declined (the planar streaming search behind a transpose is the form for them)
+        assert kernels.change_detection_pixel_major(dev[0], dev[1], dev[2], dev[3], alpha=0.01, n=9) is None
+    t = torch.ones((4, 5, 30), device=device)                     # 30 dates: not whole 16-byte vectors
+    assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
+    t = torch.ones((2, 3, 196), device=device)
+    assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
+
+
 @pytest.mark.parametrize('dtype,k', [(np.float32, 33), (np.float32, 40), (np.float32, 48), (np.float32, 57),
                                      (np.float32, 64), (np.float64, 17), (np.float64, 40), (np.float64, 64),
                                      (np.float32, 65), (np.float32, 96), (np.float32, 127), (np.float32, 128),
