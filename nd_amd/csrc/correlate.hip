@@ -153,14 +153,16 @@ struct TiledArgs {
     const T *in;
     T *out;
     int64_t ny, nx;             // plane size
-    int64_t sin_b, sin_y;       // element strides of batch and y (x stride is 1)
-    int64_t sout_b, sout_y;
+    int64_t sin_v, sin_t, sin_y;   // element strides of the two batch axes and y (x stride is 1)
+    int64_t sout_v, sout_t, sout_y;
+    int64_t nt;                 // planes along the second batch axis (the one a 3-D window runs along)
     int kh, oy0, ox0;           // window: input row = y + oy0 + i, input col = x + ox0 + j
+    int kt, ot0;                // 3-D windows: kt planes, input plane = t + ot0 + dt (1, 0: a 2-D window)
     int mode;
     int tiles_x, tiles_y;
     int64_t nbatch;             // planes
     int ppb;                    // planes one block walks through
-    double w[kMaxKH * kMaxKH];  // dense KH x KW weights, row-major (0 = tap absent)
+    double w[kMaxKH * kMaxKH];  // dense KT x KH x KW weights, row-major (0 = tap absent)
     double cval;                // mode `constant`: the value of every sample outside the plane
 };
 
@@ -168,6 +170,11 @@ struct TiledArgs {
 // maps and every thread's source offsets are computed once, and the loads of plane b+1 are in
 // flight (held in registers) while plane b is computed and stored.  KHB bounds the kernel height
 // the instantiation can stage (register array sizes).
+// 3-D windows (round 5; the reference hands scipy N-D kernels as they are, nd/filters.py:256-267): a
+// window of kt planes along the second batch axis is a walk over kt staged planes PER OUTPUT plane --
+// plane extend(t + ot0 + dt) for dt = 0 .. kt - 1, the border rule applied to the plane index -- with
+// the running sums kept across them: scipy's footprint order is plane-major, so the terms arrive in
+// its order.  Same prefetch (the next staged plane's loads in flight while this one is summed).
 template <typename T, int KW, bool BOX, int KHB>
 __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T> a)
 {
@@ -182,6 +189,7 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     const int ty = (int)(b % a.tiles_y);
     const int64_t b0 = (b / a.tiles_y) * a.ppb;
     const int64_t b1 = b0 + a.ppb < a.nbatch ? b0 + a.ppb : a.nbatch;
+    const int kt = a.kt;
     const int64_t x_base = (int64_t)tx * kTileX, y_base = (int64_t)ty * kTileY;
 
     // ---- once per block: the border rule is separable -- one source row per staged row and one
@@ -249,8 +257,14 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
     const double cval = a.cval;
 
     T buf[NR], buf2[NE > 0 ? NE : 1];
-    auto load_plane = [&](int64_t bb) {
-        const T *plane = a.in + bb * a.sin_b;
+    bool plane_ok = true;              // the plane in `buf` lies inside the array (mode `constant`: else cval)
+    // the plane staged for output plane bb and window plane dt
+    auto load_plane = [&](int64_t bb, int dt) {
+        const int64_t v = bb / a.nt, t = bb - v * a.nt;
+        // (a single tap plane may still lie off the output's own: a sparse kernel whose other planes are zero)
+        const int64_t ts = (kt == 1 && a.ot0 == 0) ? t : extend_index(t + a.ot0 + dt, a.nt, a.mode);
+        plane_ok = ts >= 0;
+        const T *plane = a.in + v * a.sin_v + (ts < 0 ? 0 : ts) * a.sin_t;
 #pragma unroll
         for (int i = 0; i < NR; ++i)
             if (wrow + 2 * i < th) buf[i] = (plane + rowoff[i])[xo];
@@ -262,33 +276,36 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
 #pragma unroll
         for (int i = 0; i < NR; ++i)
             if (wrow + 2 * i < th) {
-                const double v = (colok && ((rowok >> i) & 1ull)) ? (double)buf[i] : cval;
+                const double v = (plane_ok && colok && ((rowok >> i) & 1ull)) ? (double)buf[i] : cval;
                 tile[(wrow + 2 * i) * 4 * TWQ + dlane] = BOX ? wbox * v : v;
             }
 #pragma unroll
         for (int j = 0; j < NE; ++j)
             if (tid + 256 * j < n_edge) {
-                const double v = ((edgeok >> j) & 1u) ? (double)buf2[j] : cval;
+                const double v = (plane_ok && ((edgeok >> j) & 1u)) ? (double)buf2[j] : cval;
                 tile[doff2[j]] = BOX ? wbox * v : v;
             }
     };
     if (b0 < b1) {
-        load_plane(b0);
+        load_plane(b0, 0);
         store_plane();
     }
     __syncthreads();
 
     const int lx = (tid % 32) * kOX, ly = (tid / 32) * kOY;
     for (int64_t bb = b0; bb < b1; ++bb) {
-        const bool has_next = bb + 1 < b1;
-        if (has_next) load_plane(bb + 1);
-
         // ---- 4 x 4 outputs per thread ----
         double acc[kOY][kOX];
 #pragma unroll
         for (int oy = 0; oy < kOY; ++oy)
 #pragma unroll
             for (int ox = 0; ox < kOX; ++ox) acc[oy][ox] = 0.0;
+
+        for (int dt = 0; dt < kt; ++dt) {
+        const bool last_dt = dt + 1 == kt;
+        const bool has_next = !last_dt || bb + 1 < b1;
+        if (has_next) load_plane(last_dt ? bb + 1 : bb, last_dt ? 0 : dt + 1);
+        const double *wd = a.w + dt * kh * KW;
 
         for (int r = 0; r < kOY + kh - 1; ++r) {
             double v[kOX + KW - 1];
@@ -301,7 +318,7 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
                 if (i >= 0 && i < kh) {
 #pragma unroll
                     for (int j = 0; j < KW; ++j) {
-                        const double w = a.w[i * KW + j];
+                        const double w = wd[i * KW + j];
                         if (BOX || w != 0.0) {
 #pragma unroll
                             for (int ox = 0; ox < kOX; ++ox) {
@@ -316,7 +333,15 @@ __global__ void __launch_bounds__(256) correlate_tiled_kernel(const TiledArgs<T>
             }
         }
 
-        T *oplane = a.out + bb * a.sout_b;
+        if (has_next && !last_dt) {
+            __syncthreads();               // every thread is done reading this plane's image
+            store_plane();
+            __syncthreads();
+        }
+        }          // dt
+
+        const bool has_next = bb + 1 < b1;
+        T *oplane = a.out + (bb / a.nt) * a.sout_v + (bb % a.nt) * a.sout_t;
 #pragma unroll
         for (int oy = 0; oy < kOY; ++oy) {
             const int64_t y = y_base + ly + oy;
@@ -698,23 +723,26 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     static const bool disabled = getenv("ND_AMD_NO_TILED") != nullptr;
     if (disabled || ntaps < 1) return 0;
     if (si[3] != 1 || so[3] != 1) return 0;
-    int64_t ymin = 0, ymax = 0, xmin = 0, xmax = 0;
+    int64_t ymin = 0, ymax = 0, xmin = 0, xmax = 0, tmin = 0, tmax = 0;
     for (int64_t t = 0; t < ntaps; ++t) {
-        if (offsets[4 * t + 0] != 0 || offsets[4 * t + 1] != 0) return 0;
-        const int64_t oy = offsets[4 * t + 2], ox = offsets[4 * t + 3];
+        if (offsets[4 * t + 0] != 0) return 0;
+        const int64_t ot = offsets[4 * t + 1], oy = offsets[4 * t + 2], ox = offsets[4 * t + 3];
         if (t == 0) {
+            tmin = tmax = ot;
             ymin = ymax = oy;
             xmin = xmax = ox;
         }
+        tmin = ot < tmin ? ot : tmin;
+        tmax = ot > tmax ? ot : tmax;
         ymin = oy < ymin ? oy : ymin;
         ymax = oy > ymax ? oy : ymax;
         xmin = ox < xmin ? ox : xmin;
         xmax = ox > xmax ? ox : xmax;
-        // scipy's order is row-major over the window: the dense walk below must visit the taps
-        // in the order they were given
+        // scipy's order is plane-major, then row-major over the window: the dense walk below must visit
+        // the taps in the order they were given
         if (t > 0) {
-            const int64_t py = offsets[4 * (t - 1) + 2], px = offsets[4 * (t - 1) + 3];
-            if (oy < py || (oy == py && ox <= px)) return 0;
+            const int64_t pt = offsets[4 * (t - 1) + 1], py = offsets[4 * (t - 1) + 2], px = offsets[4 * (t - 1) + 3];
+            if (ot < pt || (ot == pt && (oy < py || (oy == py && ox <= px)))) return 0;
         }
     }
     // An even-width window (scipy shifts its origin, nd_amd.kernels.footprint) runs as the next odd
@@ -722,37 +750,33 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     // zero weights, so the sums are the same, term for term.
     const int64_t kh = ymax - ymin + 1, kw_taps = xmax - xmin + 1;
     const int64_t kw = (kw_taps & 1) ? kw_taps : kw_taps + 1;
-    if (kh > kMaxKH || kw > kMaxKH) return 0;
+    const int64_t kt = tmax - tmin + 1;
+    if (kh > kMaxKH || kw > kMaxKH || kt * kh * kw > kMaxKH * kMaxKH) return 0;
     if (dims[2] < 1 || dims[3] < 1 || dims[2] > 0x7fffffffLL || dims[3] > 0x7fffffffLL) return 0;
     // windows reaching farther than twice the plane from it hit the non-periodic corner of
     // scipy's offset table: leave those to the generic kernel, which restates the table as is
     {
         const int64_t ry = (-ymin > ymax ? -ymin : ymax), rx = (-xmin > xmax ? -xmin : xmax);
-        if (ry >= 2 * dims[2] || rx >= 2 * dims[3]) return 0;
+        const int64_t rt = (-tmin > tmax ? -tmin : tmax);
+        if (ry >= 2 * dims[2] || rx >= 2 * dims[3] || (rt > 0 && rt >= 2 * dims[1])) return 0;
     }
-    // batch = dims[0] x dims[1] must be addressable with one stride
-    int64_t nb = dims[0] * dims[1], sbi, sbo;
-    if (dims[0] == 1) {
-        sbi = si[1];
-        sbo = so[1];
-    } else if (dims[1] == 1) {
-        sbi = si[0];
-        sbo = so[0];
-    } else if (si[0] == si[1] * dims[1] && so[0] == so[1] * dims[1]) {
-        sbi = si[1];
-        sbo = so[1];
-    } else {
-        return 0;
-    }
+    // batch = dims[0] x dims[1], addressed as (v, t): a 3-D window runs along the second of them
+    const int64_t nb = dims[0] * dims[1];
+    if (dims[1] < 1) return 0;
     TiledArgs<T> a;
     a.in = static_cast<const T *>(in);
     a.out = static_cast<T *>(out);
     a.ny = dims[2];
     a.nx = dims[3];
-    a.sin_b = sbi;
+    a.sin_v = si[0];
+    a.sin_t = si[1];
     a.sin_y = si[2];
-    a.sout_b = sbo;
+    a.sout_v = so[0];
+    a.sout_t = so[1];
     a.sout_y = so[2];
+    a.nt = dims[1];
+    a.kt = (int)kt;
+    a.ot0 = (int)tmin;
     a.kh = (int)kh;
     a.oy0 = (int)ymin;
     a.ox0 = (int)xmin;
@@ -761,9 +785,9 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     a.tiles_x = (int)ceil_div(dims[3], kTileX);
     a.tiles_y = (int)ceil_div(dims[2], kTileY);
     for (int i = 0; i < kMaxKH * kMaxKH; ++i) a.w[i] = 0.0;
-    bool box = (ntaps == kh * kw);
+    bool box = (ntaps == kt * kh * kw);
     for (int64_t t = 0; t < ntaps; ++t) {
-        a.w[(offsets[4 * t + 2] - ymin) * kw + (offsets[4 * t + 3] - xmin)] = weights[t];
+        a.w[((offsets[4 * t + 1] - tmin) * kh + (offsets[4 * t + 2] - ymin)) * kw + (offsets[4 * t + 3] - xmin)] = weights[t];
         if (weights[t] != weights[0]) box = false;
     }
     // source offsets inside one plane are kept as 32-bit integers

@@ -55,6 +55,39 @@ def test_live_scipy_random(device, dtype, mode):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('mode', ['reflect', 'constant', 'nearest', 'mirror', 'wrap'])
+def test_three_dimensional_windows(device, dtype, mode):
+    """Kernels with an extent along time as well (the reference hands scipy N-D kernels as they are,
+    nd/filters.py:256-267): the tiled kernel walks the window's planes per output plane with the sums kept
+    across them, scipy's plane-major footprint order -- bit-equal to scipy, every border mode, boxcars,
+    even sizes, absent taps, a series shorter than the window's reach, a leading variable axis."""
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(11)
+    cases = [((6, 37, 141), (3, 3, 3)), ((9, 40, 130), (5, 3, 5)), ((4, 33, 70), (3, 7, 7)), ((12, 20, 40), (5, 1, 1)),
+             ((7, 35, 66), (2, 4, 4)), ((2, 30, 50), (3, 5, 3)), ((3, 3, 8, 150), (1, 3, 3, 3)), ((1, 17, 19), (3, 3, 3)),
+             ((5, 64, 129), (7, 5, 5))]
+    for shape, kshape in cases:
+        a = rng.normal(size=shape).astype(dtype)
+        for k in (rng.normal(size=kshape), np.ones(kshape) / float(np.prod(kshape))):
+            want = ndi.convolve(a, k, mode=mode, cval=0.75)
+            got = _gpu_convolve(a, k, device, mode=mode, cval=0.75)
+            np.testing.assert_array_equal(got, want, err_msg='%s %s' % (shape, kshape))
+    a = rng.normal(size=(6, 21, 45)).astype(dtype)
+    k = rng.normal(size=(3, 3, 5))
+    k[1, 1, 2] = 0.0                   # scipy drops zero taps from the footprint
+    k[2, 0, 4] = 0.0
+    k1 = np.zeros((2, 1, 1)); k1[0, 0, 0] = 0.5           # one tap, one plane off the output's own
+    k2 = np.zeros((3, 2, 1)); k2[0, 1, 0] = 2.0; k2[2, 0, 0] = -1.0      # the middle plane absent
+    for kk in (k1, k1[::-1], k2):
+        np.testing.assert_array_equal(_gpu_convolve(a, kk, device, mode=mode, cval=0.75),
+                                      ndi.convolve(a, kk, mode=mode, cval=0.75))
+    np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode, cval=0.75), ndi.convolve(a, k, mode=mode, cval=0.75))
+    for origin in ((1, 0, -1), (-1, 1, 0)):
+        np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode, cval=0.75, origin=origin),
+                                      ndi.convolve(a, k, mode=mode, cval=0.75, origin=origin))
+
+
 def test_origin_and_zero_taps(device):
     import scipy.ndimage as ndi
     rng = np.random.default_rng(4)

@@ -24,6 +24,8 @@ VARIANTS = {
     # omnibus_mlw.hip in csrc at the time): 6 waves x 2 slots 2.69 ms, 4 waves x 3 slots 2.30 ms, two waves
     # per SIMD 2.67 ms, against 2.04 ms for the block form on the same box (gpurun_out/r5_ml)
     # the block form: L2 prefetch by the idle waves, steps ahead of the transfers
+    # non-local means as of round 4 (A/B of the stream3 kernel's skipped edge planes on one box)
+    'nlm_r04': ('nlmeans.hip', 'git:d879eb2', []),
     'ml_pf0': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=0']),
     'ml_pf1': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=1']),
     'ml_pf2': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=2']),
@@ -46,6 +48,9 @@ def build(names):
         open(hp, 'w').write(h)
         p = os.path.join(d, fname)
         s = open(p).read()
+        if isinstance(patches, str) and patches.startswith('git:'):
+            s = subprocess.check_output(['git', 'show', '%s:nd_amd/csrc/%s' % (patches[4:], fname)], cwd=ROOT).decode()
+            patches = []
         for old, new in patches:
             assert s.count(old) == 1, (name, s.count(old), old[:70])
             s = s.replace(old, new)
