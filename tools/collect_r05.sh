@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-5 profile collection (run on the GPU box): writes everything under gpurun_out/<dir>.
+#   bash tools/collect_r05.sh gpurun_out/r05prof <commit>
+# 1. rocprofv3 --kernel-trace --stats of the headline bench command + separate --pmc FETCH_SIZE / WRITE_SIZE
+#    passes of the same command -> omnibus_rocprof.txt
+# 2. HBM traffic of every bench workload's kernels (tools/collect_traffic.sh) -> traffic.json, copied to
+#    profiles/r05_traffic.json on the box so that the bench runs below report it
+# 3. the bench line as the driver runs it, and the --extras run -> bench_line.json, bench_detail.json,
+#    bench_extras.json
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/$1; COMMIT=${2:-unknown}; mkdir -p $OUT
+CMD="python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-rows 0"
+timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $OUT/stats -o p --output-format csv -- $CMD > $OUT/stats.log 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-rows 0 > $OUT/fetch.log 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-rows 0 > $OUT/write.log 2>&1
+python3 $R/tools/summarize_prof.py $OUT/stats $OUT/fetch $OUT/write $OUT/omnibus_rocprof.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-rows 0   (PMC passes: --pmc FETCH_SIZE / --pmc WRITE_SIZE with --kernel-trace, --steps 5 --warmup 1); commit $COMMIT" > /dev/null
+cp $(find $OUT/stats -name 'p_kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null
+rm -rf $OUT/stats $OUT/fetch $OUT/write
+echo "headline profiled"
+bash $R/tools/collect_traffic.sh $1/traffic $COMMIT > $OUT/traffic.log 2>&1
+cp $OUT/traffic/traffic.json $OUT/traffic.json
+mkdir -p $R/profiles && cp $OUT/traffic.json $R/profiles/r05_traffic.json     # bench.py reads it from there
+echo "traffic collected"
+cd $R
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err; cp bench_detail.json $OUT/bench_detail.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --extras > $OUT/bench_line_extras_run.json 2> $OUT/bench_extras.err; cp bench_extras.json $OUT/bench_extras.json
+ls $OUT
+cat $OUT/omnibus_rocprof.txt | head -40
+tail -c 600 $OUT/bench_line.json

@@ -26,6 +26,7 @@ VARIANTS = {
     # the block form: L2 prefetch by the idle waves, steps ahead of the transfers
     # non-local means as of round 4 (A/B of the stream3 kernel's skipped edge planes on one box)
     'nlm_r04': ('nlmeans.hip', 'git:d879eb2', []),
+    'ml_trace': ('omnibus_ml.hip', [], ['-DND_ML_TRACE']),
     'ml_pf0': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=0']),
     'ml_pf1': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=1']),
     'ml_pf2': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=2']),
