@@ -11,7 +11,7 @@ mkdir -p $OUT
 for K in $KEYS; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/tr_$C
-    timeout -k 5 420 rocprofv3 --kernel-trace --pmc $C -d /tmp/tr_$C -o p --output-format csv -- python3 $R/bench.py --traffic-run $K > $OUT/run_${K}_$C.log 2>&1
+    timeout -k 5 1000 rocprofv3 --kernel-trace --pmc $C -d /tmp/tr_$C -o p --output-format csv -- python3 $R/bench.py --traffic-run $K > $OUT/run_${K}_$C.log 2>&1
     F=$(ls /tmp/tr_$C/*/p_counter_collection.csv /tmp/tr_$C/p_counter_collection.csv 2>/dev/null | head -1)
     cp "$F" $OUT/${K}_$C.csv
   done
