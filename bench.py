@@ -507,8 +507,19 @@ class Pipeline(Workload):
         self.halo = TUT['r'][1] + TUT['f'][1]
         self.shard = tiles.empty_shard((4, self.k), self.global_ny, self.nx, self.halo, dev,
                                        rank=rank, world=world)
-        synth.wishart_c2_stack(self.k, self.rows, self.nx, looks=a.looks, seed=99 + rank,
-                               change_frac=a.change_frac, out=self.shard.core)
+        if TRAFFIC_MODE:
+            # (under the profiler's counter passes the Wishart synthesis -- thousands of small launches, each
+            #  with its counters read out -- takes longer than the run may stay silent; the filter's traffic does
+            #  not depend on the values: uniform planes, three launches per date)
+            import torch
+            g_ = torch.Generator(device=dev).manual_seed(99 + rank)
+            for t_ in range(self.k):
+                self.shard.core[:, t_] = torch.rand((4, self.rows, self.nx), generator=g_, device=dev) + 0.5
+                self.shard.core[1:3, t_] -= 1.0
+                self.shard.core[1:3, t_] *= 0.3
+        else:
+            synth.wishart_c2_stack(self.k, self.rows, self.nx, looks=a.looks, seed=99 + rank,
+                                   change_frac=a.change_frac, out=self.shard.core)
         if world == 1:
             self.stack = self.shard.core
         # the filter reads and writes every (variable, date, pixel) once: 8 B per px.t.var

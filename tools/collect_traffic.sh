@@ -8,6 +8,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/$1; COMMIT=${2:-unknown}; shift; shift
 KEYS="$@"
 [ -z "$KEYS" ] && KEYS="headline omnibus_a0.01 omnibus_a0.0001 omnibus_a0.2 ml3 ml5 pm_a0.99 pm_a0.01 c3_a0.99 c3_a0.01 boxcar3 boxcar5 gauss1 nlm_pm0 nlm_pm1 pipeline"
 mkdir -p $OUT
+# (a heartbeat: a run that writes nothing for seven minutes is taken to be hung)
+( while true; do sleep 60; date >> $OUT/heartbeat.log; done ) &
+HB=$!
 for K in $KEYS; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/tr_$C
@@ -17,6 +20,7 @@ for K in $KEYS; do
   done
   echo "collected $K"
 done
+kill $HB 2>/dev/null
 python3 $R/tools/summarize_traffic.py $OUT $COMMIT $KEYS > $OUT/traffic.json
 rm -f $OUT/*_FETCH_SIZE.csv $OUT/*_WRITE_SIZE.csv
 cat $OUT/traffic.json | head -c 3000
