@@ -66,7 +66,11 @@ def test_three_dimensional_windows(device, dtype, mode):
     rng = np.random.default_rng(11)
     cases = [((6, 37, 141), (3, 3, 3)), ((9, 40, 130), (5, 3, 5)), ((4, 33, 70), (3, 7, 7)), ((12, 20, 40), (5, 1, 1)),
              ((7, 35, 66), (2, 4, 4)), ((2, 30, 50), (3, 5, 3)), ((3, 3, 8, 150), (1, 3, 3, 3)), ((1, 17, 19), (3, 3, 3)),
-             ((5, 64, 129), (7, 5, 5))]
+             ((5, 64, 129), (7, 5, 5)),
+             # windows along time or y alone, and pairs without x, on arrays large enough that the wrapper
+             # used to transpose them to the back first: filtered where they lie
+             ((6, 128, 256), (3, 1, 1)), ((6, 128, 256), (1, 5, 1)), ((6, 130, 250), (3, 5, 1)),
+             ((5, 128, 256), (3, 1, 5)), ((2, 3, 128, 130), (1, 3, 1, 1))]
     for shape, kshape in cases:
         a = rng.normal(size=shape).astype(dtype)
         for k in (rng.normal(size=kshape), np.ones(kshape) / float(np.prod(kshape))):
