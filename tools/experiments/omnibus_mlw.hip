@@ -1,4 +1,26 @@
-// nd_amd/csrc/omnibus_mlw.hip -- OmnibusTest(ml=w), multilooking fused into pass A: the WAVE form.
+// tools/experiments/omnibus_mlw.hip -- OmnibusTest(ml=w), multilooking fused into pass A: the WAVE form.
+//
+// STATUS (round 5): an experiment, NOT part of the library.  Built, verified (tests/test_omnibus_ml_gpu.py: 15
+// passed with this form selected; 11 485 fuzz cases, 0 failures) and measured SLOWER than the block form of
+// nd_amd/csrc/omnibus_ml.hip: 24 x 4096^2, alpha = 0.99, one box: 2.69 ms (3 x 3) / 4.11 ms (5 x 5) against
+// 2.04 / 3.21 ms; 4 waves x 3 slots 2.30 ms; two waves per SIMD 2.67 ms (profiles/r05_ml_experiments.txt,
+// DESIGN.md section 5 K1m "Round 5").  Kept as the record of what was tried.  To build it again: copy it to
+// nd_amd/csrc/, and restore the three hooks it needs --
+//   omnibus_c2_device.hpp, struct OmniMlPlan:   int w_strips, w_xsegs, w_segw;
+//   omnibus_ml.hip, omni_ml_plan (behind p->seg):
+//       const int W = mlw_waves_per_block();
+//       p->w_strips = (int)ceil_div(ny, (int64_t)(2 * W));
+//       const int64_t tiles32 = ceil_div(nx, 32);
+//       int xs = 1;
+//       while ((int64_t)p->w_strips * W * xs < 4 * 3072 && tiles32 / (xs * 2) >= 8) xs *= 2;
+//       p->w_segw = (int)(ceil_div(tiles32, xs) * 32);
+//       p->w_xsegs = (int)ceil_div(nx, (int64_t)p->w_segw);
+//       const int64_t range = (int64_t)p->w_strips * W * p->w_xsegs * (p->w_segw / 32 + 2);
+//       const uint32_t wseg = (uint32_t)(ceil_div(range, (int64_t)kShards) * 64 + 64);
+//       if (wseg > p->seg) p->seg = wseg;
+//   omnibus_ml.hip, launch_ml_pass_a (behind a.list):   if (a.x4) return launch_mlw_pass_a(g, tab, p, a, ss, stats, stream);
+//   omnibus_ml_common.hpp:   int mlw_waves_per_block();  int launch_mlw_pass_a(const OmniGlobalArgs<float> &, const OmniTab &,
+//       const OmniMlPlan &, const OmniMlArgs &, const StreamScreen<32> *, bool, hipStream_t);
 //
 // Reference: nd/change.py:61-64 (BoxcarFilter(w=ml) in front of nd._change.change_detection, n = ml**2),
 // nd/filters.py:256-267, 294-298 (scipy.ndimage.convolve, ones((w, w)) / w**2, mode 'reflect').  Same
