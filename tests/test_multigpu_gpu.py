@@ -161,6 +161,13 @@ def test_apply_over_two_devices_equals_one(oracle):
     ml1 = OmnibusTest(ml=3, alpha=0.9).apply(host).values
     ml2 = OmnibusTest(ml=3, alpha=0.9, njobs=2).apply(host).values
     np.testing.assert_array_equal(ml1, ml2)
+    # the sparse regime, where OmnibusTest(ml=...) takes the FUSED kernel: its 155 KB of dynamic LDS are opted
+    # into on every launch, i.e. on every device of the in-process pool (a once-per-process opt-in left the
+    # second device without it: ADVICE r04)
+    for mlw in (3, 5):
+        f1 = OmnibusTest(ml=mlw, alpha=0.99).apply(host).values
+        f2 = OmnibusTest(ml=mlw, alpha=0.99, devices=devs).apply(host).values
+        np.testing.assert_array_equal(f1, f2)
     # device-resident dataset on GPU 0: chunks travel peer-to-peer, the result comes back to GPU 0
     dev_ds = xr_lite.Dataset()
     for v in host.data_vars:
