@@ -655,6 +655,7 @@ def _free():
 
 
 EXTRA_KEYS = ('omnibus_a0.01', 'omnibus_a0.0001', 'omnibus_a0.2', 'ml3', 'ml5', 'pm_a0.99', 'pm_a0.01', 'c3_a0.99', 'c3_a0.01',
+              'c3_pm_a0.99',
               'boxcar3', 'boxcar5', 'gauss1', 'nlm_pm0', 'nlm_pm1', 'pipeline')
 
 
@@ -772,7 +773,7 @@ def extras(main, barrier, dev, only=None):
     # -- full-pol C3, config 4's single-GPU share
     class A:
         pass
-    if want('c3_a0.99', 'c3_a0.01'):
+    if want('c3_a0.99', 'c3_a0.01', 'c3_pm_a0.99'):
         a3 = A()
         a3.__dict__.update(a.__dict__)
         a3.k, a3.ny, a3.nx, a3.alpha, a3.scaling = 48, 1024, 8192, 0.99, 'weak'
@@ -792,6 +793,29 @@ def extras(main, barrier, dev, only=None):
                        note=None if alpha > 0.5 else 'search fused into the streaming pass (omnibus_c3_stream_kernel)'),
                   res['bad'] == 0, sample=res)
             del ch
+        # -- the same test on data in the reference's layout: nine (y, x, time) variables, the off-diagonals as
+        #    interleaved complex arrays (what OmnibusTest(pol='full').apply(ds) receives)
+        if want('c3_pm_a0.99'):
+            yxt = [w.stack[c].permute(1, 2, 0).contiguous() for c in range(9)]
+            cplx = [torch.complex(yxt[c], yxt[c + 1]) for c in (3, 5, 7)]
+            pmv = yxt[:3] + [h for z_ in cplx for h in (z_.real, z_.imag)]
+            del yxt
+            fn = lambda: kernels.change_detection_c3_pixel_major(pmv, alpha=0.99, n=a.looks)      # noqa: E731
+            dt, km, ch = timed_extra(fn, 10, 10, barrier)
+            if not quick:
+                a3.alpha = 0.99
+                ref = w.step()
+                same = bool(torch.equal(ch, ref))
+                res = w.check(ch)
+                dom = max(km, key=km.get)
+                entry('c3_pm_a0.99', 'OmnibusTest full-pol C3 48t x 1024 x 8192 f32 in the reference layout (y, x, time), '
+                      'C12 / C13 / C23 complex64, alpha=0.99', dt, 10, w.npix, km,
+                      roof('c3_pm_a0.99', 'omnibus_c3_pm', dom, km, w.alg_bytes,
+                           note='LDS images of the contiguous per-pixel runs folded in place (16 pixels per wave); pass B '
+                                'reads the listed series where they lie'),
+                      res['bad'] == 0 and same, sample=res, equal_to_planar_map=same)
+                del ref
+            del ch, pmv, cplx
         del w
         _free()
 

@@ -166,6 +166,29 @@ int nd_amd_omnibus_c3(const void *const planes[9], int dtype,
                       void *hip_stream);
 
 /* ------------------------------------------------------------------------
+ * nd_amd_omnibus_c3 for data in the reference's own layout, without a
+ * transpose (the full-pol counterpart of nd_amd_omnibus_c2_pixel_major;
+ * nd/change.py:66-67 stacks (y, x, time) variables): plane c holds element
+ * (y, x, t) at  planes[c][((y * nx + x) * k + t) * date_stride[c]].
+ * date_stride = 1 for a real (y, x, time) array; 2, with
+ * planes[c + 1] == planes[c] + 1, for the two halves of an interleaved
+ * complex C12 / C13 / C23.  Accepted: nine real arrays, or three real and
+ * three interleaved complex ones; 16-byte aligned; k a multiple of 4
+ * (float64: of 2) with 9 k elements of 16 pixels within 56 KB; the sparse
+ * regime, alpha >= 0.75.  Everything else returns ND_AMD_EUNSUPPORTED --
+ * transpose and call nd_amd_omnibus_c3.  The series is folded out of LDS
+ * images of the contiguous per-pixel runs, and the search reads a listed
+ * pixel's series where it lies (9 runs of k values instead of 9 k values
+ * gathered from planes).  Workspace as for nd_amd_omnibus_c3.
+ * ---------------------------------------------------------------------- */
+int nd_amd_omnibus_c3_pixel_major(const void *const planes[9], int dtype,
+                                  int64_t ny, int64_t nx, int64_t k,
+                                  const int64_t date_stride[9],
+                                  uint32_t n_looks, double alpha, uint8_t *change,
+                                  void *z_out, void *p_out,
+                                  void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/* ------------------------------------------------------------------------
  * Kernel convolution / boxcar.
  * Replaces  scipy.ndimage.convolve(arr, nd_kernel, output=output, **kwargs)
  *           as called at nd/filters.py:256-267 (scipy is the reference's

@@ -24,7 +24,7 @@ SYMBOLS = ('nd_amd_abi_version', 'nd_amd_last_error',
            'nd_amd_omnibus_c2_workspace_bytes', 'nd_amd_omnibus_c2',
            'nd_amd_omnibus_c2_pixel_major',
            'nd_amd_omnibus_c2_ml_workspace_bytes', 'nd_amd_omnibus_c2_ml',
-           'nd_amd_omnibus_c3_workspace_bytes', 'nd_amd_omnibus_c3',
+           'nd_amd_omnibus_c3_workspace_bytes', 'nd_amd_omnibus_c3', 'nd_amd_omnibus_c3_pixel_major',
            'nd_amd_correlate', 'nd_amd_correlate1d', 'nd_amd_correlate1d_yx', 'nd_amd_nlmeans3d',
            'nd_amd_relayout_planar', 'nd_amd_relayout_planar_complex',
            'nd_amd_relayout_pixel_major', 'nd_amd_split_complex', 'nd_amd_merge_complex',
@@ -74,6 +74,9 @@ def lib():
     L.nd_amd_omnibus_c3.restype = i32
     L.nd_amd_omnibus_c3.argtypes = ([C.POINTER(vp), i32] + [i64] * 6 + [C.c_uint32, dbl]
                                     + [vp, vp, vp, vp, C.c_size_t, vp])
+    L.nd_amd_omnibus_c3_pixel_major.restype = i32
+    L.nd_amd_omnibus_c3_pixel_major.argtypes = ([C.POINTER(vp), i32] + [i64] * 3 + [C.POINTER(i64)]
+                                                + [C.c_uint32, dbl] + [vp, vp, vp, vp, C.c_size_t, vp])
     L.nd_amd_correlate.restype = i32
     L.nd_amd_correlate.argtypes = [vp, vp, i32, C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(i64), i64, C.POINTER(i64),

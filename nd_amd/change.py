@@ -156,6 +156,12 @@ def _omnibus_change_detection(ds, alpha=0.01, ml=None, n=1, njobs=1, device=None
                 res = kernels.change_detection_pixel_major(
                     *[da.transpose('y', 'x', 'time').values for da in vals], alpha=alpha, n=int(n),
                     stats=stats)
+        if full_pol and ml is None and all(v in ds_m.data_vars for v in _VARS3):
+            # the same for the full-pol test: nine (y, x, time) variables read where they lie
+            vals = [ds_m[v] for v in _VARS3]
+            if all(set(da.dims) == {'y', 'x', 'time'} and len(da.dims) == 3 for da in vals):
+                res = kernels.change_detection_c3_pixel_major(
+                    [da.transpose('y', 'x', 'time').values for da in vals], alpha=alpha, n=int(n), stats=stats)
         if res is None:
             names = _VARS3 if full_pol else _VARS
             # (time-first device datasets are planar where they lie -- also in front of the fused

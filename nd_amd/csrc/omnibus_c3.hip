@@ -97,6 +97,8 @@ struct C3Args {
     uint32_t seg;
     OmniTabEntry *tab_dev;
     uint32_t starts_max;      // lists of a shard up to this length are searched one lane per segment start
+    int mult[9];              // element-offset multiplier per plane (pixel-major inputs: 2 for the halves of an
+                              // interleaved complex array, else 1): pass B reads plane c at pl[c][o * mult[c]]
 };
 
 // ---- pass A ---------------------------------------------------------------------------------
@@ -180,6 +182,148 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3A
         for (int i = tid; i < nvec; i += kC3Threads) __builtin_nontemporal_store(zero, vz + i);
         const int tail0 = head + (nvec << 4);
         if (tail0 + tid < nb) ob[tail0 + tid] = 0;
+    }
+}
+
+// ---- pass A for the reference's layout ((y, x, time) per variable), sparse regime ---------------------------
+// The full-pol counterpart of omnibus_c2_pm_long_kernel (omnibus.hip).  In this layout a pixel's series is a
+// contiguous run per variable, so (i) the wave's span of every variable goes into wave-private LDS images by
+// LDS-DMA (all transfers in flight at once, no barrier) and every lane folds its pixel's series out of them,
+// and (ii) pass B reads a listed pixel's 9 k values as 9 (or, with interleaved complex off-diagonals, 6) runs
+// of k -- 27 sectors at 48 dates -- instead of gathering 432 isolated values from planes megabytes apart, which is
+// a third of the planar call at the benchmark's threshold.  PXW pixels per wave (the upper lanes idle): images
+// of about 28 KB, five waves per CU -- 16 pixels at 48 dates (the fold of 16 lanes is what bounds the kernel:
+// 3.2 - 3.4 ms on 48 x 1024 x 8192 against 2.36 ms for the planar pass A -- a wave loads, then folds, and five
+// waves per CU do not hide the one behind the other; four lanes per pixel sharing a date's determinant through
+// quad broadcasts, 33 instead of 70 instructions per date on all 64 lanes, measured the same: 3.3 - 3.55 ms).
+// JOINT: C12, C13, C23 are interleaved complex arrays (re at the even places); otherwise nine real ones.
+template <typename T, int N>
+struct alignas(sizeof(T) * N) C3Pack {
+    T v[N];
+};
+struct C3PmArgs {
+    int img_off[9];           // element offset of each plane's image in the wave's LDS region
+};
+
+template <typename T, int PXW, bool STATS, bool JOINT>
+__global__ void __launch_bounds__(64) omnibus_c3_pm_kernel(const C3Args<T> g, const OmniTab tab, const C3PmArgs pm)
+{
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef __attribute__((address_space(1))) unsigned char glb_u8;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    extern __shared__ __align__(16) unsigned char nd_smem3pm[];
+    T *img = reinterpret_cast<T *>(nd_smem3pm);
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t px0 = b * PXW;
+    const int64_t x0 = px0 + lane;
+    const int k = g.k;
+    const bool in = lane < PXW && x0 < g.nx;
+    const int64_t left = g.nx - px0;
+    const int np = left > PXW ? PXW : (int)left;
+
+    // ---- every transfer of the wave in flight ----
+    auto stage = [&](int c, int mult) {
+        const int wpp = k * mult;                            // elements per pixel in memory
+        const int bytes = np * wpp * (int)sizeof(T);        // multiple of 16 (host checks k)
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(g.pl[c] + px0 * wpp);
+        unsigned char *dst = reinterpret_cast<unsigned char *>(img + pm.img_off[c]);
+        for (int c0 = 0; c0 < bytes; c0 += 1024) {
+            const int eb = c0 + lane * 16;
+            if (eb < bytes) __builtin_amdgcn_global_load_lds((glb_u8 *)(src + eb), (lds_u8 *)(dst + c0), 16, 0, 2);
+        }
+    };
+    stage(0, 1);
+    stage(1, 1);
+    stage(2, 1);
+    if (JOINT) {
+        stage(3, 2);
+        stage(5, 2);
+        stage(7, 2);
+    } else {
+#pragma unroll
+        for (int c = 3; c < 9; ++c) stage(c, 1);
+    }
+    if (g.write_tab && b == 0)
+        for (int j = lane; j <= k; j += 64) g.tab_dev[j] = tab.e[j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    typedef C3Pack<T, VE> PV;
+    Accum3<T> A;
+    A.reset();
+    const int nv = k / VE;
+    {
+    // ---- one lane per pixel: fold this lane's series in time order (idle lanes fold the last pixel of the span) ----
+    const int own = (lane < np) ? lane : np - 1;
+    const PV *im[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+        im[c] = reinterpret_cast<const PV *>(img + pm.img_off[c] + own * k * ((JOINT && c >= 3) ? 2 : 1));
+    for (int u = 0; u < nv; ++u) {
+        PV q[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = im[c][u];
+        if (JOINT) {
+#pragma unroll
+            for (int c = 3; c < 9; c += 2) {
+                const PV q0 = im[c][2 * u], q1 = im[c][2 * u + 1];      // (re, im) pairs of VE dates
+#pragma unroll
+                for (int j = 0; j < VE; ++j) {
+                    q[c].v[j] = (j < VE / 2 ? q0 : q1).v[2 * (j % (VE / 2))];
+                    q[c + 1].v[j] = (j < VE / 2 ? q0 : q1).v[2 * (j % (VE / 2)) + 1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 3; c < 9; ++c) q[c] = im[c][u];
+        }
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            T v[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) v[c] = q[c].v[j];
+            A.step(v);
+        }
+    }
+
+    }
+
+    bool flag;
+    if (STATS) {
+        const T z = z_stat3<T>(A, k, g.nlooks, g.e);
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair<1>(zd, 9 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        flag = in && ((double)P > g.alpha);
+        if (in) {
+            if (g.z_out) g.z_out[x0] = z;
+            if (g.p_out) g.p_out[x0] = P;
+        }
+    } else {
+        flag = in && (z_approx3<T>(A, k, g.nlooks, g.e) >= g.e.zlo_a);
+    }
+    if (__any(flag)) {
+        const unsigned long long m = __ballot(flag);
+        const unsigned shard = (unsigned)(b % kC3Shards);
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(g.flag_count + shard * kC3CounterStride, (unsigned)__popcll(m));
+        base = __shfl(base, 0);
+        if (flag) g.flag_idx[(size_t)shard * g.seg + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)x0;
+    }
+    // zero-fill this wave's slice of the change map
+    {
+        uint8_t *ob = g.change + px0 * (int64_t)k;
+        const int nb = np * k;
+        int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (lane < head) ob[lane] = 0;
+        const int nvec = (nb - head) >> 4;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        u4 *vz = reinterpret_cast<u4 *>(ob + head);
+        const u4 zero = {0u, 0u, 0u, 0u};
+        for (int i = lane; i < nvec; i += 64) __builtin_nontemporal_store(zero, vz + i);
+        const int tail0 = head + (nvec << 4);
+        if (tail0 + lane < nb) ob[tail0 + lane] = 0;
     }
 }
 
@@ -656,7 +800,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
                     if (t0 + u < k) {
                         const int64_t o = off + (int64_t)(t0 + u) * s.st;
 #pragma unroll
-                        for (int c = 0; c < 9; ++c) q[u][c] = s.pl[c][o];
+                        for (int c = 0; c < 9; ++c) q[u][c] = s.pl[c][o * s.mult[c]];
                     }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
@@ -675,7 +819,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
         auto fetch = [&](int t, T (&v)[9]) {
             const int64_t o = off + (int64_t)t * s.st;
 #pragma unroll
-            for (int c = 0; c < 9; ++c) v[c] = s.pl[c][o];
+            for (int c = 0; c < 9; ++c) v[c] = s.pl[c][o * s.mult[c]];
         };
         auto load_step = [&](Accum3<T> &A, int t) {
             T v[9];
@@ -800,7 +944,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_starts_kernel(const C3Ar
         T *mine = ser + grp * (k * 9);
         __syncthreads();                        // (one wave per block: orders the LDS accesses of two rounds)
         if (active)
-            for (int e = l0; e < k * 9; e += nsw) mine[e] = s.pl[e % 9][off + (int64_t)(e / 9) * s.st];
+            for (int e = l0; e < k * 9; e += nsw) mine[e] = s.pl[e % 9][(off + (int64_t)(e / 9) * s.st) * s.mult[e % 9]];
         __syncthreads();
         int nxt_a = -1, nxt_b = -1;             // per sweep: the next segment start, or stop
         for (int sweep = 0; sweep < nsweep; ++sweep) {
@@ -888,7 +1032,7 @@ template <typename T>
 static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, int64_t k,
                            int64_t sy, int64_t sx, int64_t st, uint32_t n_looks, double alpha,
                            uint8_t *change, void *z_out, void *p_out, void *workspace,
-                           size_t workspace_bytes, hipStream_t stream)
+                           size_t workspace_bytes, hipStream_t stream, const int64_t *pm_ids = nullptr)
 {
     const int64_t npix = ny * nx;
     const C3Workspace w = c3_layout(npix, ny, k);
@@ -912,8 +1056,11 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     memcpy(tab.e, htab.data(), htab.size() * sizeof(OmniTabEntry));
 
     C3Args<T> g;
-    for (int c = 0; c < 9; ++c) g.pl[c] = static_cast<const T *>(planes[c]);
-    const bool flat = (sx == 1) && (sy == nx);
+    for (int c = 0; c < 9; ++c) {
+        g.pl[c] = static_cast<const T *>(planes[c]);
+        g.mult[c] = pm_ids ? (int)pm_ids[c] : 1;
+    }
+    const bool flat = ((sx == 1) && (sy == nx)) || pm_ids != nullptr;
     g.nx = flat ? npix : nx;
     g.nrows = flat ? 1 : ny;
     g.nx_orig = nx;
@@ -949,7 +1096,65 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         const char *e = getenv("ND_AMD_C3_FUSED_ALPHA");
         return e ? atof(e) : 0.75;
     }();
-    const bool fused = k >= 2 && k <= kDenseMax && k <= kTabArgs && alpha < fused_alpha && g.off32;
+    const bool fused = pm_ids == nullptr && k >= 2 && k <= kDenseMax && k <= kTabArgs && alpha < fused_alpha && g.off32;
+    if (pm_ids != nullptr) {
+        // the reference's layout: LDS images folded in place, in the sparse regime (omnibus_c3_pm_kernel)
+        constexpr int VE = 16 / (int)sizeof(T);
+        bool all_real = true, joint = pm_ids[0] == 1 && pm_ids[1] == 1 && pm_ids[2] == 1;
+        for (int c = 0; c < 9; ++c) all_real = all_real && pm_ids[c] == 1;
+        for (int c = 3; c < 9; c += 2)
+            joint = joint && pm_ids[c] == 2 && pm_ids[c + 1] == 2 && g.pl[c + 1] == g.pl[c] + 1;
+        bool aligned = true;
+        for (int c = 0; c < 9; ++c)
+            if (!(joint && c >= 3 && ((c - 3) & 1))) aligned = aligned && (((uintptr_t)g.pl[c]) & 15) == 0;
+        const int64_t per_px = 9 * k * (int64_t)sizeof(T);
+        static const int pxw_env = [] {
+            const char *e = getenv("ND_AMD_C3_PM_PXW");          // 64 / 32 / 16: pixels per wave (diagnostic)
+            return e ? atoi(e) : 0;
+        }();
+        // images of ~28 KB (five waves per CU, every SIMD with a wave to fold) where that leaves at least 16
+        // pixels per wave; 16 pixels up to 56 KB.  48 dates: 32 pixels per wave (55 KB, two waves per CU: two
+        // SIMDs idle) 4.56 ms, 16 pixels 3.39 ms
+        int pxw = 64 * per_px <= 32 * 1024 ? 64 : (32 * per_px <= 32 * 1024 ? 32 : (16 * per_px <= 56 * 1024 ? 16 : 0));
+        if ((pxw_env == 32 || pxw_env == 16) && pxw_env < pxw) pxw = pxw_env;
+        if (!(all_real || joint) || !aligned || (k % VE) != 0 || pxw == 0 || !(alpha >= fused_alpha)) {
+            set_error("nd_amd_omnibus_c3_pixel_major: nine real (y, x, time) arrays, or three real and three interleaved "
+                      "complex ones, 16-byte aligned, a multiple of %d dates up to 56 KB per 16 pixels, alpha >= %g "
+                      "(transpose and call nd_amd_omnibus_c3 otherwise)", VE, fused_alpha);
+            return ND_AMD_EUNSUPPORTED;
+        }
+        C3PmArgs pa;
+        int off = 0;
+        for (int c = 0; c < 9; ++c) {
+            if (joint && c >= 3 && ((c - 3) & 1)) {
+                pa.img_off[c] = pa.img_off[c - 1];           // the imaginary half: inside the pair's image
+                continue;
+            }
+            pa.img_off[c] = off;
+            off += pxw * (int)k * ((joint && c >= 3) ? 2 : 1);
+        }
+        const size_t lds_pm = (size_t)off * sizeof(T);
+        const dim3 gridw((unsigned)ceil_div(npix, (int64_t)pxw)), blockw(64);
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+#define ND_C3_PM(PXW_)                                                                                       \
+    do {                                                                                                     \
+        if (stats && joint)                                                                                  \
+            hipLaunchKernelGGL((omnibus_c3_pm_kernel<T, PXW_, true, true>), gridw, blockw, lds_pm, stream, g, tab, pa);   \
+        else if (stats)                                                                                      \
+            hipLaunchKernelGGL((omnibus_c3_pm_kernel<T, PXW_, true, false>), gridw, blockw, lds_pm, stream, g, tab, pa);  \
+        else if (joint)                                                                                      \
+            hipLaunchKernelGGL((omnibus_c3_pm_kernel<T, PXW_, false, true>), gridw, blockw, lds_pm, stream, g, tab, pa);  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((omnibus_c3_pm_kernel<T, PXW_, false, false>), gridw, blockw, lds_pm, stream, g, tab, pa); \
+    } while (0)
+        if (pxw == 64)
+            ND_C3_PM(64);
+        else if (pxw == 32)
+            ND_C3_PM(32);
+        else
+            ND_C3_PM(16);
+#undef ND_C3_PM
+    } else
     if (!fused || stats) {
         // the sparse design -- or, with a fused search, only the z / P rasters of it
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
@@ -1070,6 +1275,51 @@ extern "C" size_t nd_amd_omnibus_c3_workspace_bytes(int64_t ny, int64_t nx, int6
 {
     if (ny < 0 || nx < 0 || k < 0) return 0;
     return c3_layout(ny * nx, ny, k).total;
+}
+
+extern "C" int nd_amd_omnibus_c3_pixel_major(const void *const planes[9], int dtype, int64_t ny, int64_t nx,
+                                             int64_t k, const int64_t date_stride[9], uint32_t n_looks,
+                                             double alpha, uint8_t *change, void *z_out, void *p_out,
+                                             void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    if (dtype != ND_AMD_F32 && dtype != ND_AMD_F64) {
+        set_error("nd_amd_omnibus_c3_pixel_major: dtype must be ND_AMD_F32 or ND_AMD_F64, got %d", dtype);
+        return ND_AMD_EINVAL;
+    }
+    if (ny < 0 || nx < 0 || k < 0 || !date_stride) {
+        set_error("nd_amd_omnibus_c3_pixel_major: bad shape");
+        return ND_AMD_EINVAL;
+    }
+    if (ny == 0 || nx == 0 || k == 0) return ND_AMD_OK;
+    if (!planes || !change) {
+        set_error("nd_amd_omnibus_c3_pixel_major: null data pointer");
+        return ND_AMD_EINVAL;
+    }
+    for (int c = 0; c < 9; ++c) {
+        if (!planes[c]) {
+            set_error("nd_amd_omnibus_c3_pixel_major: plane %d is null", c);
+            return ND_AMD_EINVAL;
+        }
+        if (date_stride[c] != 1 && date_stride[c] != 2) {
+            set_error("nd_amd_omnibus_c3_pixel_major: date strides must be 1 or 2");
+            return ND_AMD_EINVAL;
+        }
+    }
+    if (n_looks == 0) {
+        set_error("nd_amd_omnibus_c3_pixel_major: n_looks must be >= 1");
+        return ND_AMD_EINVAL;
+    }
+    if (ny * nx >= 0xffffffffLL) {
+        set_error("nd_amd_omnibus_c3_pixel_major: raster exceeds the 32-bit pixel index");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    // unit-stride geometry of the layout: (y, x, t) -> (y * nx + x) * k + t
+    if (dtype == ND_AMD_F32)
+        return omnibus_c3_impl<float>(planes, ny, nx, k, nx * k, k, 1, n_looks, alpha, change, z_out, p_out,
+                                      workspace, workspace_bytes, stream, date_stride);
+    return omnibus_c3_impl<double>(planes, ny, nx, k, nx * k, k, 1, n_looks, alpha, change, z_out, p_out,
+                                   workspace, workspace_bytes, stream, date_stride);
 }
 
 extern "C" int nd_amd_omnibus_c3(const void *const planes[9], int dtype, int64_t ny, int64_t nx,

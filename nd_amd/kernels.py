@@ -226,6 +226,45 @@ def change_detection_c3(planes, alpha, n=1, dims=('time', 'y', 'x'), stats=False
     return change
 
 
+def change_detection_c3_pixel_major(planes, alpha, n=1, stats=False):
+    """change_detection_c3 for nine device variables in the reference's own layout, (y, x, time) with time
+    fastest -- [C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im], the off-diagonal pairs either real
+    arrays or the `.real` / `.imag` views of complex tensors (read once).  Returns None where the kernel
+    does not apply (other layouts, series lengths, thresholds below the sparse regime): the caller then
+    transposes and uses change_detection_c3."""
+    planes = list(planes)
+    if len(planes) != 9 or not all(torch.is_tensor(t) and t.is_cuda and t.dim() == 3 for t in planes):
+        return None
+    p0 = planes[0]
+    ny, nx, k = p0.shape
+    dt = p0.dtype
+    if dt not in _DT or ny * nx * k == 0:
+        return None
+    ids = []
+    for t in planes:
+        if t.shape != p0.shape or t.dtype != dt or t.device != p0.device:
+            return None
+        ids.append(_pixel_major_stride(t))
+        if ids[-1] is None:
+            return None
+    dev = p0.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        change = torch.empty((ny, nx, k), dtype=torch.uint8, device=dev)
+        z = torch.empty((ny, nx), dtype=dt, device=dev) if stats else None
+        P = torch.empty((ny, nx), dtype=dt, device=dev) if stats else None
+        nbytes = L.nd_amd_omnibus_c3_workspace_bytes(ny, nx, k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * 9)(*[t.data_ptr() for t in planes])
+        rc = L.nd_amd_omnibus_c3_pixel_major(ptrs, _DT[dt], ny, nx, k, _lib.i64_array(ids), int(n), float(alpha),
+                                             _ptr(change), _ptr(z), _ptr(P), _ptr(ws), nbytes, _stream_ptr(dev))
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        _lib.check(rc)
+        ws.record_stream(torch.cuda.current_stream(dev))
+    return (change, z, P) if stats else change
+
+
 # ---------------------------------------------------------------------------
 # layout change in front of the hot path
 # ---------------------------------------------------------------------------

@@ -38,6 +38,40 @@ def test_c3_against_generic_oracle(oracle, device, dtype, k, alpha):
     assert want.sum() > 0
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('k', [8, 12, 48, 96])
+def test_c3_pixel_major_entry_point(oracle, device, dtype, k):
+    """nd_amd_omnibus_c3_pixel_major: the nine variables in the reference's (y, x, time) layout read where
+    they lie -- nine real arrays, or three real and three interleaved complex ones; ragged rasters; z / P
+    rasters; the sparse regime.  Against the generic-p oracle and the planar entry point."""
+    import torch
+    from nd_amd import kernels
+    if dtype == np.float64 and k == 96:
+        pytest.skip('9 k doubles of 16 pixels exceed the images')
+    for ny, nx in [(1, 5), (7, 70), (12, 131)]:
+        planes = synth.omnibus_stack_c3(seed=k + nx, k=k, ny=ny, nx=nx, dtype=dtype, change_frac=0.2)
+        yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+        dev = [torch.from_numpy(a).to(device) for a in yxt]
+        cplx = [torch.complex(dev[c], dev[c + 1]) for c in (3, 5, 7)]
+        joint = dev[:3] + [h for z_ in cplx for h in (z_.real, z_.imag)]
+        for alpha in (0.8, 0.99):
+            want, z0, P0 = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8, stats=True)
+            got = kernels.change_detection_c3_pixel_major(dev, alpha=alpha, n=9)
+            assert got is not None
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
+            res = kernels.change_detection_c3_pixel_major(joint, alpha=alpha, n=9, stats=True)
+            assert res is not None
+            np.testing.assert_array_equal(res[0].cpu().numpy(), want)
+            np.testing.assert_allclose(res[1].cpu().numpy(), z0, rtol=1e-5, equal_nan=True)
+            np.testing.assert_allclose(res[2].cpu().numpy(), P0, rtol=1e-5, atol=1e-30, equal_nan=True)
+            planar = kernels.change_detection_c3([torch.from_numpy(p).to(device) for p in planes], alpha=alpha, n=9)
+            assert torch.equal(planar, got)
+        # below the sparse regime: declined (the caller transposes)
+        assert kernels.change_detection_c3_pixel_major(dev, alpha=0.01, n=9) is None
+    t = torch.ones((3, 4, 10), device=device)                      # 10 dates: not whole 16-byte vectors
+    assert kernels.change_detection_c3_pixel_major([t] * 9, alpha=0.9) is None
+
+
 def test_c3_layouts_and_tails(oracle, device):
     planes = synth.omnibus_stack_c3(seed=3, k=6, ny=5, nx=131, dtype=np.float32, change_frac=0.3)
     yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/$1; COMMIT=${2:-unknown}; shift; shift
 KEYS="$@"
-[ -z "$KEYS" ] && KEYS="headline omnibus_a0.01 omnibus_a0.0001 omnibus_a0.2 ml3 ml5 pm_a0.99 pm_a0.01 c3_a0.99 c3_a0.01 boxcar3 boxcar5 gauss1 nlm_pm0 nlm_pm1 pipeline"
+[ -z "$KEYS" ] && KEYS="headline omnibus_a0.01 omnibus_a0.0001 omnibus_a0.2 ml3 ml5 pm_a0.99 pm_a0.01 c3_a0.99 c3_a0.01 c3_pm_a0.99 boxcar3 boxcar5 gauss1 nlm_pm0 nlm_pm1 pipeline"
 mkdir -p $OUT
 # (a heartbeat: a run that writes nothing for seven minutes is taken to be hung)
 ( while true; do sleep 60; date >> $OUT/heartbeat.log; done ) &
