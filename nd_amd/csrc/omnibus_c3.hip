@@ -97,6 +97,8 @@ struct C3Args {
     uint32_t seg;
     OmniTabEntry *tab_dev;
     uint32_t starts_max;      // lists of a shard up to this length are searched one lane per segment start
+    int pm_vec;               // pixel-major inputs (st = 1, whole 16-byte vectors of dates, aligned runs): pass B
+                              // reads the series of a listed pixel with 16-byte loads
     int mult[9];              // element-offset multiplier per plane (pixel-major inputs: 2 for the halves of an
                               // interleaved complex array, else 1): pass B reads plane c at pl[c][o * mult[c]]
 };
@@ -791,7 +793,58 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
         const int64_t pix = active ? (int64_t)list[idx] : 0;
         const int64_t row = pix / s.nx_orig, col = pix - row * s.nx_orig;
         const int64_t off = row * s.sy + col * s.sx;
-        if (USE_LDS && mylane) {
+        if (USE_LDS && mylane && s.pm_vec) {
+            // Pixel-major inputs: a listed pixel's series is a contiguous run per plane (or per interleaved pair).
+            // 16-byte loads, the whole series of a lane in flight group by group: 108 (real planes) or 72 + 36
+            // loads of 16 bytes instead of 432 of 4 -- the sectors are the same, the requests a quarter.
+            constexpr int VE = 16 / (int)sizeof(T);
+            typedef C3Pack<T, VE> PV;
+            const bool joint = s.mult[3] == 2;
+            for (int t0 = 0; t0 < k; t0 += 2 * VE) {
+                PV q[9][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (t0 + h * VE < k) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            q[c][h] = *reinterpret_cast<const PV *>(s.pl[c] + off + t0 + h * VE);
+                        if (joint) {
+                            // VE dates of (re, im): two vectors of the interleaved array
+#pragma unroll
+                            for (int c = 3; c < 9; c += 2) {
+                                const T *p = s.pl[c] + 2 * (off + t0 + h * VE);
+                                q[c][h] = *reinterpret_cast<const PV *>(p);
+                                q[c + 1][h] = *reinterpret_cast<const PV *>(p + VE);
+                            }
+                        } else {
+#pragma unroll
+                            for (int c = 3; c < 9; ++c)
+                                q[c][h] = *reinterpret_cast<const PV *>(s.pl[c] + off + t0 + h * VE);
+                        }
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (t0 + h * VE < k) {
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) {
+                            const int t = t0 + h * VE + j;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) lds[(t * 9 + c) * LANES + lane] = q[c][h].v[j];
+                            if (joint) {
+#pragma unroll
+                                for (int c = 3; c < 9; c += 2) {
+                                    const PV &w0 = j < VE / 2 ? q[c][h] : q[c + 1][h];
+                                    lds[(t * 9 + c) * LANES + lane] = w0.v[2 * (j % (VE / 2))];
+                                    lds[(t * 9 + c + 1) * LANES + lane] = w0.v[2 * (j % (VE / 2)) + 1];
+                                }
+                            } else {
+#pragma unroll
+                                for (int c = 3; c < 9; ++c) lds[(t * 9 + c) * LANES + lane] = q[c][h].v[j];
+                            }
+                        }
+                    }
+            }
+        } else if (USE_LDS && mylane) {
             // eight dates (72 independent loads per lane) in flight at a time
             for (int t0 = 0; t0 < k; t0 += 8) {
                 T q[8][9];
@@ -1060,6 +1113,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         g.pl[c] = static_cast<const T *>(planes[c]);
         g.mult[c] = pm_ids ? (int)pm_ids[c] : 1;
     }
+    g.pm_vec = 0;
     const bool flat = ((sx == 1) && (sy == nx)) || pm_ids != nullptr;
     g.nx = flat ? npix : nx;
     g.nrows = flat ? 1 : ny;
@@ -1123,6 +1177,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
                       "(transpose and call nd_amd_omnibus_c3 otherwise)", VE, fused_alpha);
             return ND_AMD_EUNSUPPORTED;
         }
+        g.pm_vec = 1;                        // (the checks above are what the 16-byte loads of pass B need as well)
         C3PmArgs pa;
         int off = 0;
         for (int c = 0; c < 9; ++c) {
