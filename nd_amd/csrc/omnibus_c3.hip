@@ -101,6 +101,12 @@ struct C3Args {
                               // reads the series of a listed pixel with 16-byte loads
     int mult[9];              // element-offset multiplier per plane (pixel-major inputs: 2 for the halves of an
                               // interleaved complex array, else 1): pass B reads plane c at pl[c][o * mult[c]]
+    // Series of the listed pixels, written by the time-split pass A (omnibus_c3_retain_kernel) from its
+    // registers: entry i of shard s's list has its series at dump[(s * dump_cap + i) * dump_stride + t * 9 + c]
+    // while i < dump_cap; later entries are gathered from the planes as before.  nullptr: no dump.
+    T *dump;
+    uint32_t dump_cap, dump_stride;
+    float retain_rel;         // 3 (21 k + 40) 2^-24: rounding band of the re-associated sums (see the kernel)
 };
 
 // ---- pass A ---------------------------------------------------------------------------------
@@ -184,6 +190,201 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3A
         for (int i = tid; i < nvec; i += kC3Threads) __builtin_nontemporal_store(zero, vz + i);
         const int tail0 = head + (nvec << 4);
         if (tail0 + tid < nb) ob[tail0 + tid] = 0;
+    }
+}
+
+// ---- pass A, time-split and retaining (round 6) ----------------------------------------------------
+// The gather of pass B was a third of the full-pol call at the benchmark's threshold: 432 isolated 4-byte
+// reads per listed pixel, one 64-byte sector each -- 7.1 GB of sector traffic for 1.9 % of the pixels
+// (profiles/r05_traffic.json), all of it data pass A had just read.  One thread cannot retain 432 values;
+// FOUR WAVES SHARING A PIXEL'S TIME AXIS can: block = PG groups of 64 pixels x 4 waves, wave w of a group
+// loads the KQ dates [w KQ, (w + 1) KQ) of its 64 pixels (9 KQ registers, all loads in flight at once) and
+// folds its slice into nine partial sums and a partial product of determinants.  The partials meet in LDS;
+// the group's first wave screens the combined value, lists the candidates, and every wave then stores its
+// slice of a candidate's series from registers into the dump (16-byte stores, the series of a pixel as one
+// contiguous run [t][9]) where pass B reads it with 16-byte loads instead of gathering from the planes.
+//
+// Pass A is only a screen -- exactness lives in pass B, which folds in the reference's order
+// (nd/_change.pyx:64-69) -- but it must not lose a pixel that fires.  What differs from the reference's
+// forward fold, and how the screen pays for it:
+//   * the nine sums are re-associated ((s0 + s1) + s2) + s3.  With every date positive semi-definite
+//     (positive diagonal, non-negative 2 x 2 minors: checked per date, anything else is listed) both
+//     summation orders are within (k - 1) u of the exact sums on the diagonal and within
+//     (k - 1) u sqrt(s_ii s_jj) on each off-diagonal part, and for D = det3 the bound of the streaming
+//     search applies to each: |D' - D| <= (21 k + 40) u abc (evaluation in `floating` included).  The two
+//     determinants therefore differ by at most 2 (21 k + 40) u abc; the screen adds
+//     |m2rho| n k * 1.02 * rel,  rel = 3 (21 k + 40) u abc / D'  (u = 2^-24), to z_approx and lists the
+//     pixel when rel >= 0.01 or the sums leave [2^-26, 2^26] (no underflow inside det3 then).
+//   * the product of determinants is p0 p1 p2 p3 of the slices' double products: (k + 3) roundings of 2^-53
+//     instead of k -- inside the 10x margin zlo_a already carries -- PROVIDED no prefix product the
+//     reference forms leaves the normal range.  Every wave tracks the binary exponents its running product
+//     passes through; a pixel whose prefix exponents (slice offsets added) leave +-1000 is listed.
+//   * a date whose determinant is NaN or exactly 0 makes the whole-series statistic NaN or infinite: no
+//     change anywhere (omnibus_c3_stream_kernel, `dead`) -- not listed, as the plain screen does not.
+constexpr int kC3Slices = 4;
+
+template <int KQ, int PG, int OCC>
+__global__ void __launch_bounds__(64 * kC3Slices * PG, OCC) omnibus_c3_retain_kernel(const C3Args<float> g, const OmniTab tab)
+{
+    typedef float T;
+    constexpr int NW = kC3Slices;
+    __shared__ float part_s[PG][NW][9][64];
+    __shared__ double part_p[PG][NW][64];
+    __shared__ int part_e[PG][NW][3][64];          // lowest / highest exponent the slice's product passes, flags
+    __shared__ unsigned long long flag_mask[PG];
+    __shared__ unsigned list_base[PG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv % NW, pg = wv / NW;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t gpx0 = bx * (int64_t)(64 * PG) + pg * 64;       // first pixel of this group
+    const int64_t x0 = gpx0 + lane;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+    const int64_t xc = in ? x0 : g.nx - 1;
+    const int64_t off0 = row * g.sy + xc * g.sx;
+    const int t_lo = w * KQ;
+
+    if (g.write_tab && b == 0)
+        for (int j = tid; j <= k; j += 64 * NW * PG) g.tab_dev[j] = tab.e[j];
+
+    // every load of the slice in flight (a plane's extent fits 32 bits of byte offset: g.off32)
+    T v[KQ][9];
+#pragma unroll
+    for (int tt = 0; tt < KQ; ++tt) {
+        const int t = t_lo + tt < k ? t_lo + tt : k - 1;           // (behind the series: the last date again)
+        const unsigned o = (unsigned)(off0 + (int64_t)t * g.st) * (unsigned)sizeof(T);
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            v[tt][c] = __builtin_nontemporal_load(
+                reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.pl[c]) + o));
+    }
+
+    // zero-fill a quarter of the group's slice of the change map (issued early, never waited on)
+    if (gpx0 < g.nx) {
+        const int64_t left = g.nx - gpx0;
+        const int npx = left > 64 ? 64 : (int)left;
+        uint8_t *ob = g.change + (row * g.nx + gpx0) * (int64_t)k;
+        const int nb = npx * k;
+        int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (w == 0 && lane < head) ob[lane] = 0;
+        const int nvec = (nb - head) >> 4;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        u4 *vz = reinterpret_cast<u4 *>(ob + head);
+        const u4 zero = {0u, 0u, 0u, 0u};
+        for (int i = w * 64 + lane; i < nvec; i += 64 * NW) __builtin_nontemporal_store(zero, vz + i);
+        const int tail0 = head + (nvec << 4);
+        if (w == 0 && tail0 + lane < nb) ob[tail0 + lane] = 0;
+    }
+
+    // fold the slice in time order
+    T s[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s[c] = (T)0;
+    double prod = 1.0;
+    int emin = 1, emax = 1;                        // frexp exponent of 1.0
+    bool bad = false, dead = false;
+#pragma unroll
+    for (int tt = 0; tt < KQ; ++tt) {
+        if (t_lo + tt < k) {                       // wave-uniform
+            const T(&q)[9] = v[tt];
+            const T det = det3<T>(q);
+            const T mn12 = (q[0] * q[1]) - ((q[3] * q[3]) + (q[4] * q[4]));
+            const T mn13 = (q[0] * q[2]) - ((q[5] * q[5]) + (q[6] * q[6]));
+            const T mn23 = (q[1] * q[2]) - ((q[7] * q[7]) + (q[8] * q[8]));
+            const T dmin = fminf(fminf(q[0], q[1]), q[2]);
+            const T mmin = fminf(fminf(mn12, mn13), mn23);
+            bad = bad | !((dmin > (T)0) & (mmin >= (T)0) & (det > (T)0));
+            dead = dead | !((det > (T)0) | (det < (T)0));
+            prod = prod * (double)det;
+            const int e = __builtin_amdgcn_frexp_exp(prod);
+            emin = e < emin ? e : emin;
+            emax = e > emax ? e : emax;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) s[c] = s[c] + q[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) part_s[pg][w][c][lane] = s[c];
+    part_p[pg][w][lane] = prod;
+    part_e[pg][w][0][lane] = emin;
+    part_e[pg][w][1][lane] = emax;
+    part_e[pg][w][2][lane] = (bad ? 1 : 0) | (dead ? 2 : 0);
+    __syncthreads();
+
+    const unsigned shard = (unsigned)(b % kC3Shards);
+    if (w == 0) {
+        // the combined screen, by the group's first wave
+        T S[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) S[c] = part_s[pg][0][c][lane];
+        double PP = part_p[pg][0][lane];
+        int fl = part_e[pg][0][2][lane];
+        int eoff = 0;
+        bool range_ok = true;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            if (u * KQ < k) {
+                const double pu = part_p[pg][u][lane];
+                const int lo = part_e[pg][u][0][lane], hi = part_e[pg][u][1][lane];
+                range_ok = range_ok & (lo > -1000) & (hi < 1000) & (eoff + lo > -1000) & (eoff + hi < 1000) &
+                           (pu > 0.0) & (pu < INFINITY);
+                eoff += __builtin_amdgcn_frexp_exp(pu);
+                if (u > 0) {
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) S[c] = S[c] + part_s[pg][u][c][lane];
+                    PP = PP * pu;
+                    fl |= part_e[pg][u][2][lane];
+                }
+            }
+        }
+        const bool isdead = (fl & 2) != 0;
+        bool isbad = ((fl & 1) != 0) | !range_ok;
+        const T det_of_sum = det3<T>(S);
+        const T abc = (S[0] * S[1]) * S[2];
+        const T smin = fminf(fminf(S[0], S[1]), S[2]), smax = fmaxf(fmaxf(S[0], S[1]), S[2]);
+        isbad = isbad | !((smin > 1.4901161e-08f) & (smax < 67108864.f));            // 2^-26, 2^26
+        const float rel = g.retain_rel * (abc * __builtin_amdgcn_rcpf(det_of_sum));
+        isbad = isbad | !((det_of_sum > (T)0) & (rel < 0.01f));
+        const double logQ = g.nlooks * ((g.e.pklogk + approx_ln(PP)) - ((double)k * approx_ln((double)det_of_sum)));
+        const double za = g.e.m2rho * logQ;
+        const double mz = (fabs(g.e.m2rho) * g.nlooks * (double)k * 1.02) * (double)rel;
+        const bool flag = in && !isdead && (isbad || (za + mz >= g.e.zlo_a));
+        const unsigned long long m = __ballot(flag);
+        unsigned base = 0;
+        if (m != 0ull) {
+            if (lane == 0) base = atomicAdd(g.flag_count + shard * kC3CounterStride, (unsigned)__popcll(m));
+            base = __shfl(base, 0);
+            if (flag)
+                g.flag_idx[(size_t)shard * g.seg + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] =
+                    (uint32_t)(row * g.nx + x0);
+        }
+        if (lane == 0) {
+            flag_mask[pg] = m;
+            list_base[pg] = base;
+        }
+    }
+    __syncthreads();
+    // a candidate's slice leaves the registers: 9 KQ values as 16-byte pieces, the series of a pixel one run
+    const unsigned long long m = flag_mask[pg];
+    if (m != 0ull && t_lo < k) {
+        const unsigned pos = list_base[pg] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (((m >> lane) & 1ull) && pos < g.dump_cap) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 *dst = reinterpret_cast<f4 *>(g.dump + ((size_t)shard * g.dump_cap + pos) * g.dump_stride + t_lo * 9);
+#pragma unroll
+            for (int i = 0; i < (KQ * 9) / 4; ++i) {
+                f4 q;
+                q.x = v[(4 * i) / 9][(4 * i) % 9];
+                q.y = v[(4 * i + 1) / 9][(4 * i + 1) % 9];
+                q.z = v[(4 * i + 2) / 9][(4 * i + 2) % 9];
+                q.w = v[(4 * i + 3) / 9][(4 * i + 3) % 9];
+                dst[i] = q;
+            }
+        }
     }
 }
 
@@ -771,7 +972,9 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
     const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
     const uint32_t n = s.flag_count[shard * kC3CounterStride];
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
-    if (lblock * (unsigned)LANES >= n) return;            // nothing for this block
+    // (entries whose series pass A dumped from its registers are omnibus_c3_search_dump_kernel's)
+    const unsigned first = s.dump != nullptr ? s.dump_cap : 0u;
+    if (first >= n || lblock * (unsigned)LANES >= n - first) return;   // nothing for this block
     if (n <= s.starts_max) return;                        // a short list: omnibus_c3_search_starts_kernel's
     // per-j constants of the screen as four LDS arrays behind the series image (omnibus.hip): every
     // lane looks up its own j in every iteration
@@ -786,7 +989,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
     }
     __syncthreads();
 
-    for (uint32_t base = lblock * (unsigned)LANES; base < n; base += nlblock * (unsigned)LANES) {
+    for (uint32_t base = first + lblock * (unsigned)LANES; base < n; base += nlblock * (unsigned)LANES) {
         const bool mylane = lane < LANES;                   // (LANES = 32: the upper half idles)
         const uint32_t idx = base + lane;
         const bool active = mylane && idx < n;
@@ -950,6 +1153,127 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
 }
 
 
+// ---- pass B on the dump of the time-split pass A (round 6) ------------------------------------------
+// A listed pixel's series lies in the dump as one contiguous run [t][9] (omnibus_c3_retain_kernel), so the
+// search needs neither the gather nor the LDS image that held it: ONE LANE PER PIXEL ON ALL 64 LANES, the
+// series read where it lies in chunks of four dates (nine 16-byte loads per lane: 27 sectors per pixel and
+// sweep instead of 432 isolated values, and a second sweep of the same pixel finds them in the L2), no LDS but
+// the per-j constants, so that the occupancy is what the registers allow.  (The image form ran 16 pixels
+// per wave to fit five waves on a CU: three quarters of every vector instruction idle, 0.84 ms on config
+// 4's share with the dump as its source.)  The search itself is omnibus_c3_search_kernel's, step for step:
+// one sweep per segment (nd/_change.pyx:235-257), the hardware-log2 screen, the exact evaluation behind a
+// wave-uniform branch.
+template <typename T>
+__global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args<T> s)
+{
+    constexpr int VE = 16 / (int)sizeof(T);              // values per 16-byte piece
+    constexpr int CD = 4;                                // dates per chunk
+    constexpr int NV = CD * 9 / VE;                      // pieces per chunk
+    typedef C3Pack<T, VE> PV;
+    extern __shared__ __align__(16) unsigned char nd_smem3d[];
+    double *scr = reinterpret_cast<double *>(nd_smem3d);
+    const int lane = threadIdx.x;
+    const int k = s.k;
+    const unsigned shard = blockIdx.x % kC3Shards;
+    const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
+    const uint32_t nall = s.flag_count[shard * kC3CounterStride];
+    const uint32_t n = nall < s.dump_cap ? nall : s.dump_cap;
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+    if (lblock * 64u >= n) return;
+    const int kp = k + 1;
+    for (int j = lane; j <= k; j += 64) {
+        const OmniTabEntry e = s.tab_dev[j];
+        scr[j] = e.m2rho;
+        scr[kp + j] = e.pklogk;
+        scr[2 * kp + j] = e.zlo_a;
+        scr[3 * kp + j] = e.zhi_a;
+    }
+    __syncthreads();
+
+    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < n;
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+        const PV *src = reinterpret_cast<const PV *>(s.dump + ((size_t)shard * s.dump_cap + (active ? idx : base)) *
+                                                                  s.dump_stride);
+        Accum3<T> A;
+        A.reset();
+        int l = 0, t = 0, fire_at = -1;
+        bool done = !active;
+        uint8_t *res = s.change + pix * (int64_t)k;
+        while (__any(!done)) {
+            const int ci = t / CD;                          // this lane's chunk (lanes restart at different dates)
+            PV q[NV];
+            if (!done) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) q[u] = src[ci * NV + u];
+            }
+#pragma unroll 1
+            for (int tt = 0; tt < CD; ++tt) {
+                const bool on = !done && (t == ci * CD + tt);
+                if (!__any(on)) continue;
+                T v[9];
+                // (tt is wave-uniform: a scalar switch over static positions, no indexed register access)
+                switch (tt) {
+#define ND_C3_PICK(TT)                                                                 \
+    case TT:                                                                           \
+        _Pragma("unroll") for (int c = 0; c < 9; ++c) v[c] = q[(TT * 9 + c) / VE].v[(TT * 9 + c) % VE]; \
+        break;
+                    ND_C3_PICK(0)
+                    ND_C3_PICK(1)
+                    ND_C3_PICK(2)
+                default:
+                    ND_C3_PICK(3)
+#undef ND_C3_PICK
+                }
+                if (on) {
+                    A.step(v);
+                    const int jj = t - l + 1;
+                    const bool last = (t == k - 1);
+                    const bool need = (jj >= 2) && (fire_at < 0 || last);
+                    bool fires = false, inband = false;
+                    if (need) {
+                        const double za = z_approx3<T>(A, jj, s.nlooks, scr[jj], scr[kp + jj]);
+                        fires = (za > scr[3 * kp + jj]) && (za < INFINITY);
+                        inband = (za >= scr[2 * kp + jj]) && !fires;
+                    }
+                    if (__any(inband)) {
+                        if (inband) {
+                            const OmniTabEntry e = s.tab_dev[jj];
+                            const T zp = z_stat3<T>(A, jj, s.nlooks, e);
+                            const double zd = (double)zp;
+                            int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                            if (verdict == 2) {
+                                double zv[1] = {zd}, P1[1], P2[1];
+                                chisq_pair<1>(zv, 9 * (jj - 1), e.lgam, P1, P2);
+                                const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                                verdict = ((double)P > s.alpha) ? 1 : 0;
+                            }
+                            fires = (verdict == 1);
+                        }
+                    }
+                    if (fires && fire_at < 0) fire_at = t;
+                    if (!last) {
+                        t = t + 1;
+                    } else if (fires && jj >= 2) {
+                        res[fire_at] = 1;
+                        l = fire_at;
+                        if (l >= k - 1) {
+                            done = true;
+                        } else {
+                            A.reset();
+                            t = l;                          // (an earlier date: met again behind the next chunk load)
+                            fire_at = -1;
+                        }
+                    } else {
+                        done = true;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- pass B, one lane per SEGMENT START (short lists behind the streaming search) ------------------
 // The full-pol counterpart of omnibus_c2_search_starts_kernel (omnibus.hip).  What the streaming search
 // hands over are a few thousand pixels of 8 M (2 070 at alpha = 0.01 on config 4's share), nearly every
@@ -1065,20 +1389,98 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_starts_kernel(const C3Ar
 
 // ---- host -----------------------------------------------------------------------------------
 struct C3Workspace {
-    size_t off_count, off_tab, off_idx, total;
+    size_t off_count, off_tab, off_idx, off_dump, total;
     uint32_t seg;
+    uint32_t dump_cap, dump_stride;      // slots per shard, elements per slot (0: no dump at this length)
+    int kq;                              // dates per slice of the time-split pass A
 };
+
+// Dump of the time-split pass A (float32, up to 64 dates): room for one pixel in 16 per shard -- three times
+// the candidates of the benchmark's threshold; what does not fit is gathered from the planes as before.
+constexpr int kC3RetainMaxK = 64;
+constexpr int64_t kC3DumpShare = 16;
 
 static C3Workspace c3_layout(int64_t npix, int64_t ny, int64_t k)
 {
     C3Workspace w;
+    // (lists: blocks of 64 pixels per row at the finest, i.e. at most ceil(npix / 64) + ny blocks of <= 64 entries)
     const int64_t nb256 = ceil_div(npix, kC3Threads) + ny;
     w.seg = (uint32_t)((ceil_div(nb256, kC3Shards) + 1) * kC3Threads);
     w.off_count = 0;
     w.off_tab = align256(kC3CounterBytes);
     w.off_idx = w.off_tab + align256((size_t)(k + 1) * sizeof(OmniTabEntry));
-    w.total = w.off_idx + align256((size_t)w.seg * kC3Shards * sizeof(uint32_t));
+    w.off_dump = w.off_idx + align256((size_t)w.seg * kC3Shards * sizeof(uint32_t));
+    w.kq = (int)(ceil_div(ceil_div(k, kC3Slices), 4) * 4);
+    if (k >= 2 && k <= kC3RetainMaxK) {
+        w.dump_cap = (uint32_t)ceil_div(ceil_div(npix, kC3DumpShare), kC3Shards);
+        w.dump_stride = (uint32_t)(kC3Slices * w.kq * 9);
+    } else {
+        w.dump_cap = w.dump_stride = 0;
+    }
+    w.total = w.off_dump + align256((size_t)w.dump_cap * kC3Shards * w.dump_stride * sizeof(float));
     return w;
+}
+
+// ND_AMD_C3_RETAIN: 0 = never the time-split pass A, 1 (default) = where it applies; ND_AMD_C3_RETAIN_MIN_K: the
+// shortest series it takes (default 2); ND_AMD_C3_RETAIN_PG: pixel groups per block (1 or 2)
+template <typename T>
+static bool c3_retain_ok(const C3Workspace &w, const C3Args<T> &g)
+{
+    static const int on = [] {
+        const char *e = getenv("ND_AMD_C3_RETAIN");
+        return e ? atoi(e) : 1;
+    }();
+    static const int min_k = [] {
+        const char *e = getenv("ND_AMD_C3_RETAIN_MIN_K");
+        return e ? atoi(e) : 2;
+    }();
+    return sizeof(T) == 4 && on != 0 && w.dump_cap > 0 && g.k >= min_k && g.k <= kC3RetainMaxK && g.off32 != 0;
+}
+
+static int c3_launch_retain(const C3Workspace &w, C3Args<double> &, const OmniTab &, unsigned char *, hipStream_t)
+{
+    return ND_AMD_EUNSUPPORTED;          // (float32 only: c3_retain_ok)
+}
+
+static int c3_launch_retain(const C3Workspace &w, C3Args<float> &g, const OmniTab &tab, unsigned char *ws,
+                            hipStream_t stream)
+{
+    static const int pg_env = [] {
+        const char *e = getenv("ND_AMD_C3_RETAIN_PG");
+        return e ? atoi(e) : 1;
+    }();
+    const int pg = pg_env == 2 ? 2 : 1;
+    g.dump = reinterpret_cast<float *>(ws + w.off_dump);
+    g.dump_cap = w.dump_cap;
+    g.dump_stride = w.dump_stride;
+    g.blocks_per_row = ceil_div(g.nx, (int64_t)64 * pg);
+    const int64_t nblocks = g.blocks_per_row * g.nrows;
+    if (nblocks > 0x7fffffffLL) {
+        set_error("nd_amd_omnibus_c3: raster too large for one launch");
+        return ND_AMD_EUNSUPPORTED;
+    }
+    const dim3 grid((unsigned)nblocks), block((unsigned)(64 * kC3Slices * pg));
+    static const int occ_env = [] {
+        const char *e = getenv("ND_AMD_C3_RETAIN_OCC");      // 4: at most 128 registers (a few spilled); 0: as compiled
+        return e ? atoi(e) : 0;
+    }();
+#define ND_C3_RETAIN(KQ_, OCC_)                                                                            \
+    do {                                                                                                   \
+        if (pg == 2)                                                                                       \
+            hipLaunchKernelGGL((omnibus_c3_retain_kernel<KQ_, 2, 2>), grid, block, 0, stream, g, tab);     \
+        else if (occ_env == 4)                                                                             \
+            hipLaunchKernelGGL((omnibus_c3_retain_kernel<KQ_, 1, 4>), grid, block, 0, stream, g, tab);     \
+        else                                                                                               \
+            hipLaunchKernelGGL((omnibus_c3_retain_kernel<KQ_, 1, OCC_>), grid, block, 0, stream, g, tab);  \
+    } while (0)
+    switch (w.kq) {
+    case 4: ND_C3_RETAIN(4, 4); break;
+    case 8: ND_C3_RETAIN(8, 4); break;
+    case 12: ND_C3_RETAIN(12, 3); break;
+    default: ND_C3_RETAIN(16, 2); break;
+    }
+#undef ND_C3_RETAIN
+    return ND_AMD_OK;
 }
 
 template <typename T>
@@ -1137,6 +1539,9 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     g.flag_idx = reinterpret_cast<uint32_t *>(ws + w.off_idx);
     g.seg = w.seg;
     g.starts_max = 0;
+    g.dump = nullptr;
+    g.dump_cap = g.dump_stride = 0;
+    g.retain_rel = 3.f * (21.f * (float)k + 40.f) * 5.9604645e-08f;
     const int64_t nblocks = g.blocks_per_row * g.nrows;
     if (nblocks > 0x7fffffffLL) {
         set_error("nd_amd_omnibus_c3: raster too large for one launch");
@@ -1209,6 +1614,11 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         else
             ND_C3_PM(16);
 #undef ND_C3_PM
+    } else
+    if (!fused && !stats && c3_retain_ok<T>(w, g)) {
+        // the sparse design with the candidates' series handed over from registers (omnibus_c3_retain_kernel)
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+        if (int rc = c3_launch_retain(w, g, tab, ws, stream)) return rc;
     } else
     if (!fused || stats) {
         // the sparse design -- or, with a fused search, only the z / P rasters of it
@@ -1291,8 +1701,18 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
                              ? c3_lanes_env
                              : (lds_bytes <= 33 * 1024 ? 64 : (lds_bytes <= 66 * 1024 ? 32 : 16));
     const bool halves = use_lds && c3_lanes != 64;
+    if (g.dump != nullptr) {
+        // the candidates whose series pass A dumped: one lane per pixel, read where they lie
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
+        int64_t per_shard_d = ceil_div((int64_t)g.dump_cap, 64);
+        if (per_shard_d > 64) per_shard_d = 64;
+        if (per_shard_d < 1) per_shard_d = 1;
+        hipLaunchKernelGGL((omnibus_c3_search_dump_kernel<T>), dim3((unsigned)(per_shard_d * kC3Shards)), dim3(64),
+                           scr_bytes, stream, g);
+        ND_HIP_CHECK(hipGetLastError());
+    }
     {
-        KernelTimer timer(g.starts_max ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
+        KernelTimer timer((g.starts_max || g.dump != nullptr) ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
         if (halves) {
             const int lanes = c3_lanes == 16 ? 16 : 32;
             const size_t lds_part = (size_t)k * 9 * lanes * sizeof(T) + scr_bytes;
