@@ -1163,7 +1163,25 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_kernel(const C3Args<T> s
 // 4's share with the dump as its source.)  The search itself is omnibus_c3_search_kernel's, step for step:
 // one sweep per segment (nd/_change.pyx:235-257), the hardware-log2 screen, the exact evaluation behind a
 // wave-uniform branch.
-template <typename T>
+// MODE 0: the dump.  MODE 1 / 2 (round 6 as well): pixel-major inputs (nd_amd_omnibus_c3_pixel_major), where
+// a listed pixel's series is a contiguous run per variable in the caller's arrays -- nine real arrays (1) or
+// three real and three interleaved complex ones (2): the same chunks of four dates, one or two 16-byte
+// pieces per variable, no LDS image (the image form: 0.79 ms on config 4's share).
+// (vector, element) of value c of date tt of a chunk, per mode
+template <int MODE, int VE, int CD>
+__device__ __forceinline__ constexpr int c3_chunk_vec(const int tt, const int c)
+{
+    return MODE == 0 ? (tt * 9 + c) / VE
+           : (MODE == 1 || c < 3) ? c * (CD / VE) + tt / VE
+                                  : 3 * (CD / VE) + ((c - 3) / 2) * (2 * CD / VE) + (2 * tt + ((c - 3) & 1)) / VE;
+}
+template <int MODE, int VE, int CD>
+__device__ __forceinline__ constexpr int c3_chunk_elem(const int tt, const int c)
+{
+    return MODE == 0 ? (tt * 9 + c) % VE : (MODE == 1 || c < 3) ? tt % VE : (2 * tt + ((c - 3) & 1)) % VE;
+}
+
+template <typename T, int MODE>
 __global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args<T> s)
 {
     constexpr int VE = 16 / (int)sizeof(T);              // values per 16-byte piece
@@ -1177,7 +1195,7 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args
     const unsigned shard = blockIdx.x % kC3Shards;
     const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
     const uint32_t nall = s.flag_count[shard * kC3CounterStride];
-    const uint32_t n = nall < s.dump_cap ? nall : s.dump_cap;
+    const uint32_t n = (MODE != 0 || nall < s.dump_cap) ? nall : s.dump_cap;
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
     if (lblock * 64u >= n) return;
     const int kp = k + 1;
@@ -1194,8 +1212,11 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args
         const uint32_t idx = base + lane;
         const bool active = idx < n;
         const int64_t pix = active ? (int64_t)list[idx] : 0;
-        const PV *src = reinterpret_cast<const PV *>(s.dump + ((size_t)shard * s.dump_cap + (active ? idx : base)) *
-                                                                  s.dump_stride);
+        const PV *src = nullptr;
+        if (MODE == 0)
+            src = reinterpret_cast<const PV *>(s.dump + ((size_t)shard * s.dump_cap + (active ? idx : base)) *
+                                                            s.dump_stride);
+        const int64_t off = pix * (int64_t)k;              // (MODE 1 / 2: the pixel's run in every variable)
         Accum3<T> A;
         A.reset();
         int l = 0, t = 0, fire_at = -1;
@@ -1205,8 +1226,23 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args
             const int ci = t / CD;                          // this lane's chunk (lanes restart at different dates)
             PV q[NV];
             if (!done) {
+                if (MODE == 0) {
 #pragma unroll
-                for (int u = 0; u < NV; ++u) q[u] = src[ci * NV + u];
+                    for (int u = 0; u < NV; ++u) q[u] = src[ci * NV + u];
+                } else {
+                    // (whole 16-byte pieces of dates: a piece behind the series is not read)
+                    constexpr int PR = CD / VE;             // pieces of a real variable per chunk
+#pragma unroll
+                    for (int u = 0; u < NV; ++u) {
+                        const bool real = MODE == 1 || u < 3 * PR;
+                        const int c = real ? u / PR : 3 + 2 * ((u - 3 * PR) / (2 * PR));
+                        const int wv = real ? u % PR : (u - 3 * PR) % (2 * PR);
+                        const int t_first = ci * CD + (real ? wv * VE : (wv * VE) / 2);
+                        if (t_first < k)
+                            q[u] = real ? reinterpret_cast<const PV *>(s.pl[c] + off + ci * CD)[wv]
+                                        : reinterpret_cast<const PV *>(s.pl[c] + 2 * (off + ci * CD))[wv];
+                    }
+                }
             }
 #pragma unroll 1
             for (int tt = 0; tt < CD; ++tt) {
@@ -1217,7 +1253,8 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args
                 switch (tt) {
 #define ND_C3_PICK(TT)                                                                 \
     case TT:                                                                           \
-        _Pragma("unroll") for (int c = 0; c < 9; ++c) v[c] = q[(TT * 9 + c) / VE].v[(TT * 9 + c) % VE]; \
+        _Pragma("unroll") for (int c = 0; c < 9; ++c)                                 \
+            v[c] = q[c3_chunk_vec<MODE, VE, CD>(TT, c)].v[c3_chunk_elem<MODE, VE, CD>(TT, c)]; \
         break;
                     ND_C3_PICK(0)
                     ND_C3_PICK(1)
@@ -1707,10 +1744,28 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         int64_t per_shard_d = ceil_div((int64_t)g.dump_cap, 64);
         if (per_shard_d > 64) per_shard_d = 64;
         if (per_shard_d < 1) per_shard_d = 1;
-        hipLaunchKernelGGL((omnibus_c3_search_dump_kernel<T>), dim3((unsigned)(per_shard_d * kC3Shards)), dim3(64),
+        hipLaunchKernelGGL((omnibus_c3_search_dump_kernel<T, 0>), dim3((unsigned)(per_shard_d * kC3Shards)), dim3(64),
                            scr_bytes, stream, g);
         ND_HIP_CHECK(hipGetLastError());
     }
+    // ND_AMD_C3_PM_SEARCH=image: the LDS-image search on pixel-major inputs, as before round 6 (A/B)
+    static const bool pm_image = [] {
+        const char *e = getenv("ND_AMD_C3_PM_SEARCH");
+        return e != nullptr && strcmp(e, "image") == 0;
+    }();
+    if (g.pm_vec && !pm_image) {
+        // pixel-major inputs: every listed pixel read where it lies in the caller's arrays
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
+        int64_t per_shard_d = ceil_div(ceil_div(npix, kC3Shards), 64);
+        if (per_shard_d > 64) per_shard_d = 64;
+        if (per_shard_d < 1) per_shard_d = 1;
+        const dim3 gridd((unsigned)(per_shard_d * kC3Shards));
+        if (g.mult[3] == 2)
+            hipLaunchKernelGGL((omnibus_c3_search_dump_kernel<T, 2>), gridd, dim3(64), scr_bytes, stream, g);
+        else
+            hipLaunchKernelGGL((omnibus_c3_search_dump_kernel<T, 1>), gridd, dim3(64), scr_bytes, stream, g);
+        ND_HIP_CHECK(hipGetLastError());
+    } else
     {
         KernelTimer timer((g.starts_max || g.dump != nullptr) ? ND_AMD_KERNEL_OMNIBUS_EXACT : ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
         if (halves) {

@@ -1,10 +1,9 @@
 """Timing / traffic variants of single translation units, built HERE (no GPU) as _variants/lib_<name>.so
 (other objects come from nd_amd/csrc/_build) and selected on the GPU box with ND_AMD_LIB.
 
-    python tools/variants_r5.py build [names...]
+    python tools/variants.py build [names...]
 
-A variant = (file, [(old text, new text), ...], [extra compiler flags]).  Round 5's experiments; the ones that won are in the
-sources, the table stays as the record of what was tried."""
+A variant = (file, [(old text, new text), ...], [extra compiler flags]).  """
 import os
 import shutil
 import subprocess
@@ -15,23 +14,18 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, '_variants')
 
 VARIANTS = {
-    # pixel-major dense form: C11 / C22 pieces with plain (temporal) loads instead of non-temporal ones
-    # pm_temporal (C11 / C22 pieces with plain instead of non-temporal loads): adopted in round 5,
-    # 1.86 -> 1.49 ms, 8.19 -> 6.44 GB of traffic (gpurun_out/r5_exp1)
-    # pm_direct_c12 (C12 straight into registers as well, no LDS image; -DND_PM_DIRECT_C12, code since removed):
-    # 1.49 against 1.45 ms -- no gain (gpurun_out/r5_exp2)
-    # mlw_* (the wave-private form of the fused multilooking kernel, tools/experiments/omnibus_mlw.hip, as
-    # omnibus_mlw.hip in csrc at the time): 6 waves x 2 slots 2.69 ms, 4 waves x 3 slots 2.30 ms, two waves
-    # per SIMD 2.67 ms, against 2.04 ms for the block form on the same box (gpurun_out/r5_ml)
-    # the block form: L2 prefetch by the idle waves, steps ahead of the transfers
-    # non-local means as of round 4 (A/B of the stream3 kernel's skipped edge planes on one box)
-    'nlm_r04': ('nlmeans.hip', 'git:d879eb2', []),
-    'ml_trace': ('omnibus_ml.hip', [], ['-DND_ML_TRACE']),
-    'ml_pf0': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=0']),
-    'ml_pf1': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=1']),
-    'ml_pf2': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=2']),
-    'ml_pf5': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=5']),
-    'ml_pf8': ('omnibus_ml.hip', [], ['-DND_ML_PREFETCH=8']),
+    # ---- round 5 (the ones that won are in the sources; the table stays as the record of what was tried) ----
+    # pm_temporal (C11 / C22 pieces with plain instead of non-temporal loads): adopted, 1.86 -> 1.49 ms
+    # pm_direct_c12 (C12 straight into registers, no LDS image): 1.49 against 1.45 ms -- no gain, code removed
+    # mlw_* (wave-private form of the fused multilooking kernel): 2.30 - 2.69 ms against 2.04 ms -- lost, code removed
+    # ml_pf* (L2 prefetch by the idle waves, -DND_ML_PREFETCH=n): 2.14 / 3.27 ms against 2.03 / 3.13 -- lost
+    # ---- round 6: the time-split pass A of the full-pol test (omnibus_c3_retain_kernel) ----
+    # timing only, NOT a correct screen: no per-date PSD check, no exponent tracking -- what the checks cost
+    'c3_nocheck': ('omnibus_c3.hip', [
+        ("            bad = bad | !((dmin > (T)0) & (mmin >= (T)0) & (det > (T)0));\n", ""),
+        ("            const int e = __builtin_amdgcn_frexp_exp(prod);\n            emin = e < emin ? e : emin;\n"
+         "            emax = e > emax ? e : emax;\n", ""),
+    ], []),
 }
 
 
