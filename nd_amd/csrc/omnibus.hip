@@ -339,6 +339,201 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 }
 
 // -----------------------------------------------------------------------------------------
+// pass A, TIME-SPLIT register-retaining form (round 6; float32, 49 .. 192 dates, sparse regime).
+// Beyond 48 dates one thread cannot hold a pixel's series, the plain pass A did not dump, and pass B
+// gathered every listed pixel again from the planes: 4 k isolated 4-byte reads, one 64-byte sector each
+// (96 dates x 2048 x 4096 at alpha = 0.99: 1.3 ms of a 3.45 ms call, for data pass A had just read).
+// Here NS waves share the time axis of 64 pixels: wave w loads the KQ dates [w KQ, (w + 1) KQ) of its 64
+// pixels (4 KQ registers, every load in flight at once), folds its slice into four partial sums and a
+// partial product of determinants; the partials meet in LDS, the group's first wave screens the combined
+// value and lists the candidates, and every wave stores its slice of a candidate's series from its
+// registers into the dump ([slot][date][4], 16-byte stores) that pass B reads.
+//
+// Pass A only screens; exactness lives in pass B, which folds in the reference's order
+// (nd/_change.pyx:64-69).  What differs from the forward fold and how the screen pays for it (the
+// full-pol twin, omnibus_c3_retain_kernel, has the long form):
+//   * the sums are re-associated (((s0 + s1) + s2) + ...).  Every date positive semi-definite (c11 > 0,
+//     det > 0: checked, anything else is listed) bounds both orders' errors: |D' - D_ref| <=
+//     2 (5 k + 4) u s11 s22 (the streaming search's bound, once per order).  The screen adds
+//     |m2rho| n k 1.02 rel, rel = 3 (5 k + 8) u s11 s22 / D', to z_approx; rel >= 0.01 or sums
+//     outside [2^-40, 2^40]: listed.
+//   * the product of determinants is the product of the slices' double products -- NS - 1 more roundings
+//     of 2^-53, inside the tenfold margin of zlo_a -- provided no prefix product the reference forms
+//     leaves the normal range: the waves track the exponents their running products pass through, and a
+//     pixel whose prefix exponents (slice offsets added) leave +-1000 is listed.
+//   * a determinant that is NaN or exactly 0 makes the whole-series statistic NaN or infinite: no change
+//     anywhere, not listed (as the plain screen does not list it).
+// -----------------------------------------------------------------------------------------
+template <int KQ, int NS>
+__global__ void __launch_bounds__(64 * NS)
+omnibus_c2_split_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const float retain_rel)
+{
+    typedef float T;
+    __shared__ float part_s[NS][4][64];
+    __shared__ double part_p[NS][64];
+    __shared__ int part_e[NS][3][64];              // lowest / highest exponent of the slice's running product, flags
+    __shared__ unsigned long long flag_mask;
+    __shared__ unsigned list_base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t gpx0 = bx * 64;
+    const int64_t x0 = gpx0 + lane;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+    const int t_lo = w * KQ;
+
+    if (g.write_tab && b == 0)
+        for (int j = tid; j <= k; j += 64 * NS) g.tab_dev[j] = tab.e[j];
+
+    // every load of the slice in flight: a uniform 64-bit base per plane and date (scalar arithmetic) plus
+    // a 32-bit lane offset -- `global_load_dword v, v_off, s[base]`, no per-lane 64-bit addresses, and no
+    // limit on the extent of a plane stack (a buffer descriptor's offsets end at 2 GB)
+    T v[KQ][4];
+    {
+        const int64_t ub = row * g.sy + gpx0;
+        const unsigned lx = in ? (unsigned)lane : (unsigned)(g.nx - 1 - gpx0);   // idle lanes re-read the last pixel
+        const unsigned voff = lx * (unsigned)sizeof(T);
+#pragma unroll
+        for (int tt = 0; tt < KQ; ++tt) {
+            const int t = t_lo + tt < k ? t_lo + tt : k - 1;               // (behind the series: the last date again)
+            const int64_t uo = ub + (int64_t)t * g.st;
+            v[tt][0] = __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.c11 + uo) + voff));
+            v[tt][1] = __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.c12r + uo) + voff));
+            v[tt][2] = __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.c12i + uo) + voff));
+            v[tt][3] = __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.c22 + uo) + voff));
+        }
+    }
+
+    // zero-fill this wave's share of the group's slice of the change map (np.zeros, nd/_change.pyx:275)
+    {
+        const int64_t left = g.nx - gpx0;
+        const int npx = left > 64 ? 64 : (int)left;
+        uint8_t *ob = g.change + (row * g.nx + gpx0) * (int64_t)k;
+        const int nb = npx * k;
+        int head = (int)((16 - ((uintptr_t)ob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (w == 0 && lane < head) ob[lane] = 0;
+        const int nvec = (nb - head) >> 4;
+        uint4 *vz = reinterpret_cast<uint4 *>(ob + head);
+        for (int i = w * 64 + lane; i < nvec; i += 64 * NS) store_zero16_nt(vz + i);
+        const int tail0 = head + (nvec << 4);
+        if (w == 0 && tail0 + lane < nb) ob[tail0 + lane] = 0;
+    }
+
+    // fold the slice in time order
+    T s11 = 0, s12r = 0, s12i = 0, s22 = 0;
+    double prod = 1.0;
+    int emin = 1, emax = 1;                        // frexp exponent of 1.0
+    bool bad = false, dead = false;
+#pragma unroll
+    for (int tt = 0; tt < KQ; ++tt) {
+        if (t_lo + tt < k) {                       // wave-uniform
+            const T a = v[tt][0], br = v[tt][1], bi = v[tt][2], d = v[tt][3];
+            const T det = (a * d) - ((br * br) + (bi * bi));
+            bad = bad | !((a > (T)0) & (det > (T)0));
+            dead = dead | !((det > (T)0) | (det < (T)0));
+            prod = prod * (double)det;
+            const int e = __builtin_amdgcn_frexp_exp(prod);
+            emin = e < emin ? e : emin;
+            emax = e > emax ? e : emax;
+            s11 = s11 + a;
+            s12r = s12r + br;
+            s12i = s12i + bi;
+            s22 = s22 + d;
+        }
+    }
+    part_s[w][0][lane] = s11;
+    part_s[w][1][lane] = s12r;
+    part_s[w][2][lane] = s12i;
+    part_s[w][3][lane] = s22;
+    part_p[w][lane] = prod;
+    part_e[w][0][lane] = emin;
+    part_e[w][1][lane] = emax;
+    part_e[w][2][lane] = (bad ? 1 : 0) | (dead ? 2 : 0);
+    __syncthreads();
+
+    const unsigned shard = (unsigned)(b % kShards);
+    if (w == 0) {
+        T S11 = 0, S12r = 0, S12i = 0, S22 = 0;
+        double PP = 1.0;
+        int fl = 0, eoff = 0;
+        bool range_ok = true;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (u * KQ < k) {
+                const double pu = part_p[u][lane];
+                const int lo = part_e[u][0][lane], hi = part_e[u][1][lane];
+                range_ok = range_ok & (lo > -1000) & (hi < 1000) & (eoff + lo > -1000) & (eoff + hi < 1000) &
+                           (pu > 0.0) & (pu < INFINITY);
+                eoff += __builtin_amdgcn_frexp_exp(pu);
+                if (u == 0) {
+                    S11 = part_s[0][0][lane];
+                    S12r = part_s[0][1][lane];
+                    S12i = part_s[0][2][lane];
+                    S22 = part_s[0][3][lane];
+                    PP = pu;
+                } else {
+                    S11 = S11 + part_s[u][0][lane];
+                    S12r = S12r + part_s[u][1][lane];
+                    S12i = S12i + part_s[u][2][lane];
+                    S22 = S22 + part_s[u][3][lane];
+                    PP = PP * pu;
+                }
+                fl |= part_e[u][2][lane];
+            }
+        }
+        const bool isdead = (fl & 2) != 0;
+        bool isbad = ((fl & 1) != 0) | !range_ok;
+        const T dd = S11 * S22;
+        const T det_of_sum = dd - ((S12r * S12r) + (S12i * S12i));
+        const T smin = fminf(S11, S22), smax = fmaxf(S11, S22);
+        isbad = isbad | !((smin > 9.094947e-13f) & (smax < 1.0995116e12f));          // 2^-40, 2^40
+        const float rel = retain_rel * (dd * __builtin_amdgcn_rcpf(det_of_sum));
+        isbad = isbad | !((det_of_sum > (T)0) & (rel < 0.01f));
+        const double logQ = g.nlooks * ((g.e.pklogk + approx_ln(PP)) - ((double)k * approx_ln((double)det_of_sum)));
+        const double za = g.e.m2rho * logQ;
+        const double mz = (fabs(g.e.m2rho) * g.nlooks * (double)k * 1.02) * (double)rel;
+        const bool flag = in && !isdead && (isbad || (za + mz >= g.e.zlo_a));
+        const unsigned long long m = __ballot(flag);
+        unsigned base = 0;
+        if (m != 0ull) {
+            if (lane == 0) base = atomicAdd(g.flag_count + shard * kCounterStride, (unsigned)__popcll(m));
+            base = __shfl(base, 0);
+            if (flag)
+                g.flag_idx[(size_t)shard * g.seg + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] =
+                    (uint32_t)(row * g.nx + x0);
+        }
+        if (lane == 0) {
+            flag_mask = m;
+            list_base = base;
+        }
+    }
+    __syncthreads();
+    // a candidate's slice leaves the registers: one 16-byte store per date
+    const unsigned long long m = flag_mask;
+    if (m != 0ull && t_lo < k) {
+        const unsigned slot = list_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (((m >> lane) & 1ull) && slot < g.dump_cap) {
+            T *dptr = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k) + 4 * t_lo;
+#pragma unroll
+            for (int tt = 0; tt < KQ; ++tt) {
+                if (t_lo + tt < k) {
+                    Pack<T, 4> q;
+                    q.v[0] = v[tt][0];
+                    q.v[1] = v[tt][1];
+                    q.v[2] = v[tt][2];
+                    q.v[3] = v[tt][3];
+                    *reinterpret_cast<Pack<T, 4> *>(dptr + 4 * tt) = q;
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------
 // How dense is the raster?  A few hundred pixel blocks spread over it, one pixel per thread,
 // streaming fold of the whole series and the same global screen as pass A; the number of
 // candidates goes to *gate_out.  ~1 % of the data: microseconds.
@@ -2201,8 +2396,20 @@ struct OmniSearchArgs {
 // PXW: pixels per wave (64, or 32 / 16 with the upper lanes idle: the LDS image of PXW series of a long
 // stack is what limits the waves per CU -- 98 KB for 64 series of 96 dates, one wave; the sweep costs a wave
 // the same whatever its number of live lanes, so narrower waves, more of them per CU, finish the list sooner)
-template <typename T, int MODE, int PXW = 64>
-__global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchArgs<T> s)
+// FS (round 6): the screen of a test is the float32 one of dense_chain's second pass (omnibus_c2_device.hpp) --
+// x = log2(prod det) - j log2(det of sum) relative to the decision point, from the exponents and the hardware
+// log2 of the mantissas of the reference's own running values, against the per-j band of make_dense_entry --
+// instead of z_approx in double: ~30 float32 instructions per date where the double form takes ~25 double
+// ones on top (the sweep of a long series is bound by them: 96 dates x 164 000 pixels 0.41 -> 0.2 ms).
+// Whatever it cannot decide (band, non-positive or non-finite determinants, a product outside the normal
+// doubles) takes the exact evaluation, as before.  The table covers tests over up to 192 dates.
+constexpr int kScreenLong = 192;
+struct DenseScreenLong {
+    DenseScreenEntry e[kScreenLong + 1];
+};
+
+template <typename T, int MODE, int PXW = 64, bool FS = false>
+__global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchArgs<T> s, const DenseScreenLong fscr)
 {
     constexpr bool USE_LDS = (MODE == 0);
     extern __shared__ __align__(16) unsigned char nd_smem[];
@@ -2214,8 +2421,13 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     // consecutive banks (as 64-byte records all j of one parity would share a bank).
     const OmniTabEntry *tabp = s.tab;          // full records, read only on the rare exact path
     const int kp = k + 1;
-    double *scr = reinterpret_cast<double *>(nd_smem + (size_t)k * 4 * PXW * sizeof(T));
-    if (USE_LDS) {
+    // (MODE 1 keeps no series image: the constants alone, 32 (k + 1) bytes)
+    double *scr = reinterpret_cast<double *>(nd_smem + (USE_LDS ? (size_t)k * 4 * PXW * sizeof(T) : 0));
+    DenseScreenEntry *scr_f = reinterpret_cast<DenseScreenEntry *>(scr);      // FS: one 16-byte record per j
+    if (FS) {
+        for (int j = lane; j <= k; j += 64) scr_f[j] = fscr.e[j];
+        __syncthreads();
+    } else {
         for (int j = lane; j <= k; j += 64) {
             const OmniTabEntry e = s.tab[j];
             scr[j] = e.m2rho;
@@ -2225,12 +2437,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
         }
         __syncthreads();
     }
-    // MODE 1 (series too long for LDS): the same four constants straight from the records
-    auto screen = [&](int f, int j) -> double {
-        if (USE_LDS) return scr[f * kp + j];
-        const OmniTabEntry &e = s.tab[j];
-        return f == 0 ? e.m2rho : (f == 1 ? e.pklogk : (f == 2 ? e.zlo_a : e.zhi_a));
-    };
+    auto screen = [&](int f, int j) -> double { return scr[f * kp + j]; };
     // blocks shard, shard + kShards, ... work through the list of one shard
     const unsigned shard = blockIdx.x % kShards;
     const unsigned lblock = blockIdx.x / kShards;
@@ -2358,7 +2565,21 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                 // Screen: z from the hardware log2 against the widened bounds.  fires = above the
                 // band for certain; inband = the screen cannot tell.  (NaN compares false twice.)
                 bool fires = false, inband = false;
-                if (need) {
+                if (need && FS) {
+                    const T dets = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
+                    // (the product a positive normal double: its logarithm below is then meaningful, and the
+                    //  reference's own log() of it finite)
+                    const bool ok = (dets > (T)0) & (dets < (T)INFINITY) & __builtin_amdgcn_class(A.prod, 0x100);
+                    const DenseScreenEntry c = scr_f[jj];
+                    int es, eP;
+                    float ms, mP;
+                    log2_parts(ok ? dets : (T)1, es, ms);
+                    log2_parts(ok ? A.prod : 1.0, eP, mP);
+                    const int E = (eP - c.re) - __mul24(jj, es);
+                    const float x = (float)E + __builtin_fmaf(-(float)jj, ms, mP - c.rf);
+                    fires = ok & (x < c.a);
+                    inband = !(fires | (ok & (x > c.b)));
+                } else if (need) {
                     const double za = z_approx<T>(A, jj, s.nlooks, screen(0, jj), screen(1, jj));
                     fires = (za > screen(3, jj)) && (za < INFINITY);
                     inband = (za >= screen(2, jj)) && !fires;
@@ -2963,6 +3184,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // z / P rasters asked for on top: they come from one launch of the plain pass A (which
     // evaluates the whole-series test of every pixel anyway), the map from the streaming search
     const bool stats_split = stream_long && stats;
+    // (round 6) the sparse regime beyond the register-retaining lengths: the time-split pass A hands the
+    // candidates' series to pass B from its registers (omnibus_c2_split_kernel).  ND_AMD_C2_SPLIT=0: the
+    // plain pass A and the gather, as before.
+    static const bool split_env = [] {
+        const char *e = getenv("ND_AMD_C2_SPLIT");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool split_ok = split_env && sizeof(T) == 4 && !retain && !stream_long && !stats && k <= 192 &&
+                          pm_ids == nullptr && mlp == nullptr && sx == 1;
     // The threshold only says that dense waves are LIKELY; whether they are is a property of the
     // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
     // is therefore made on the device from a sample (omnibus_c2_sample_kernel): both variants are
@@ -2978,7 +3208,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const size_t per = (size_t)k * 4 * sizeof(T);
         // (the streaming searches of longer series write the few pixels they hand over as well: pass B
         // would otherwise gather 4 x k isolated values per pixel from planes megabytes apart)
-        size_t cap = (retain || stream_long) ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
+        size_t cap = (retain || stream_long || split_ok) ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
         g.seg = w.seg;
         if (cap > g.seg) cap = g.seg;
         g.dump = reinterpret_cast<T *>(ws + w.off_dump);
@@ -3114,10 +3344,33 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // the LDS image of 64 series may take up to 150 KB of the CU's 160 KB: for long series that is
         // one or two waves per CU, still well ahead of a dependent plane access per date and lane
         const bool use_lds = lds_bytes <= 150 * 1024;
+        // the float32 screen of the sweep (FS): its per-j band, for tests over up to 192 dates
+        static const bool fs_env = [] {
+            const char *e = getenv("ND_AMD_SEARCH_FS");          // 0: z_approx in double, as before round 6
+            return e ? atoi(e) != 0 : true;
+        }();
+        const bool fs = fs_env && k <= kScreenLong;
+        DenseScreenLong fscr;
+        memset(&fscr, 0, sizeof(fscr));
+        for (int j = 0; j <= kScreenLong; ++j) {
+            fscr.e[j].a = -INFINITY;
+            fscr.e[j].b = INFINITY;
+            if (fs && j >= 1 && j <= (int)k) fscr.e[j] = make_dense_entry<T>(htab[(size_t)j], j, n_looks);
+        }
         if (use_lds && lds_bytes > 64 * 1024) {
-            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0>),
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0, 64, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0, 64, true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         }
+// the sweep kernel with or without the float32 screen
+#define ND_LAUNCH_SWEEP(MODE_, PXW_, GRID_, LDS_)                                                                  \
+    do {                                                                                                          \
+        if (fs)                                                                                                   \
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, MODE_, PXW_, true>), GRID_, dim3(64), LDS_, sq, s, fscr);  \
+        else                                                                                                      \
+            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, MODE_, PXW_, false>), GRID_, dim3(64), LDS_, sq, s, fscr); \
+    } while (0)
         // kShards x (blocks per shard); a shard's blocks stride through its list
         int64_t per_shard = ceil_div(ceil_div(npix_listed, kShards), 64);
         if (per_shard > 64) per_shard = 64;
@@ -3184,7 +3437,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         // (behind the register form there is usually nothing left: the from-memory form, whose
         // blocks reserve no LDS, and a quarter of the blocks)
         const bool behind = chain_form;
-        const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !behind) ? 0 : 1);
+        // (behind the time-split pass A every listed series of a long stack lies in the dump, one run per
+        //  pixel: read there date by date, the next date in flight, on all 64 lanes -- the image form runs 16
+        //  pixels per wave at these lengths: 96 dates x 8.4 Mpx at alpha = 0.99 0.86 ms against 0.41.  Two
+        //  other forms were built, verified and measured slower -- eight dates per lane at a time: 0.56 ms; a
+        //  ring of LDS-DMA transfers twelve dates ahead: 0.44 - 0.47 ms -- the sweep is bound by the rate at
+        //  which the CU looks up 64 different lines per wave instruction, not by latency or arithmetic:
+        //  DESIGN-EXPERIMENTS.md, round 6)
+        const bool from_dump = split_ok && dump_cap > 0;
+        const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !behind && !from_dump) ? 0 : 1);
         const int64_t xblocks = behind ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
         // images beyond 48 KB (three waves per CU or fewer at 64 series per wave): 16 series per wave
         // (96 dates x 8.4 Mpx at alpha = 0.99: pass B 1.84 ms with 64, 1.35 with 32, 1.30 with 16)
@@ -3201,10 +3462,13 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             const dim3 gn((unsigned)(ps * kShards));
 #define ND_LAUNCH_PXW(P)                                                                                   \
     do {                                                                                                  \
-        if (lds_n > 64 * 1024)                                                                            \
-            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0, P>), \
+        if (lds_n > 64 * 1024) {                                                                          \
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0, P, false>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));    \
-        hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0, P>), gn, dim3(64), lds_n, sq, s);              \
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&omnibus_c2_search_kernel<T, 0, P, true>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_n));    \
+        }                                                                                                 \
+        ND_LAUNCH_SWEEP(0, P, gn, lds_n);                                                                 \
     } while (0)
             if (pxw == 32)
                 ND_LAUNCH_PXW(32);
@@ -3213,12 +3477,12 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
 #undef ND_LAUNCH_PXW
             return ND_AMD_OK;
         }
+        const dim3 gx((unsigned)xblocks);
         if (mode == 0 && use_lds)
-            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 0>), dim3((unsigned)xblocks), dim3(64),
-                               lds_bytes, sq, s);
+            ND_LAUNCH_SWEEP(0, 64, gx, lds_bytes);
         else
-            hipLaunchKernelGGL((omnibus_c2_search_kernel<T, 1>), dim3((unsigned)xblocks), dim3(64),
-                               0, sq, s);
+            ND_LAUNCH_SWEEP(1, 64, gx, scr_bytes);
+#undef ND_LAUNCH_SWEEP
         return ND_AMD_OK;
     };
 
@@ -3608,6 +3872,33 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             launch_retain<T>(g, tab, nblocks, stats && !stats_split, stream);
         }
         g.gate_mode = 0;
+    } else if (split_ok) {
+        if constexpr (std::is_same<T, float>::value) {
+            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+            g.blocks_per_row = ceil_div(g.nx, (int64_t)64);
+            const int64_t nbs = g.blocks_per_row * g.nrows;
+            if (nbs > 0x7fffffffLL) {
+                set_error("nd_amd_omnibus_c2: raster too large for one launch (%lld blocks)", (long long)nbs);
+                return ND_AMD_EUNSUPPORTED;
+            }
+            const float rel = 3.f * (5.f * (float)k + 8.f) * 5.9604645e-08f;
+            const int ns = k <= 96 ? 4 : 8;
+            const int kqc = (int)ceil_div(k, ns);
+            const int kq = kqc <= 16 ? 16 : (kqc <= 20 ? 20 : 24);
+            const dim3 grid((unsigned)nbs);
+#define ND_LAUNCH_SPLIT(KQ_, NS_) \
+    hipLaunchKernelGGL((omnibus_c2_split_kernel<KQ_, NS_>), grid, dim3(64 * NS_), 0, stream, g, tab, rel)
+            if (ns == 4) {
+                if (kq <= 16) ND_LAUNCH_SPLIT(16, 4);
+                else if (kq == 20) ND_LAUNCH_SPLIT(20, 4);
+                else ND_LAUNCH_SPLIT(24, 4);
+            } else {
+                if (kq == 16) ND_LAUNCH_SPLIT(16, 8);
+                else if (kq == 20) ND_LAUNCH_SPLIT(20, 8);
+                else ND_LAUNCH_SPLIT(24, 8);
+            }
+#undef ND_LAUNCH_SPLIT
+        }
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (retain)

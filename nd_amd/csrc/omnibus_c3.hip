@@ -89,6 +89,7 @@ struct C3Args {
     int64_t nx_orig;          // pixels per row of the raster (list entries are y * nx_orig + x)
     int k, write_tab;
     int off32;                // every element offset of a plane, in bytes, fits 32 bits
+    int lane32;               // the byte offsets within a row (x * sx) fit 32 bits, sx >= 0
     double nlooks, alpha;
     OmniTabEntry e;
     uint8_t *change;
@@ -223,43 +224,48 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_global_kernel(const C3A
 //     change anywhere (omnibus_c3_stream_kernel, `dead`) -- not listed, as the plain screen does not.
 constexpr int kC3Slices = 4;
 
-template <int KQ, int PG, int OCC>
-__global__ void __launch_bounds__(64 * kC3Slices * PG, OCC) omnibus_c3_retain_kernel(const C3Args<float> g, const OmniTab tab)
+// (Measured and not kept: two pixel groups per block -- 2.96 against 2.57 ms; the kernel held to 128 registers
+//  for four waves per SIMD, eight values spilled -- 2.83 ms; plain instead of non-temporal loads -- 2.89 ms;
+//  blocks renumbered so that an XCD walks a contiguous eighth of the raster -- 2.72 ms; the per-date checks
+//  removed -- 2.556 against 2.562 ms: they are free.  DESIGN-EXPERIMENTS.md, round 6.)
+template <int KQ>
+__global__ void __launch_bounds__(64 * kC3Slices) omnibus_c3_retain_kernel(const C3Args<float> g, const OmniTab tab)
 {
     typedef float T;
     constexpr int NW = kC3Slices;
-    __shared__ float part_s[PG][NW][9][64];
-    __shared__ double part_p[PG][NW][64];
-    __shared__ int part_e[PG][NW][3][64];          // lowest / highest exponent the slice's product passes, flags
-    __shared__ unsigned long long flag_mask[PG];
-    __shared__ unsigned list_base[PG];
+    __shared__ float part_s[NW][9][64];
+    __shared__ double part_p[NW][64];
+    __shared__ int part_e[NW][3][64];          // lowest / highest exponent the slice's product passes, flags
+    __shared__ unsigned long long flag_mask;
+    __shared__ unsigned list_base;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv % NW, pg = wv / NW;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b = blockIdx.x;
     const int64_t row = b / g.blocks_per_row;
     const int64_t bx = b - row * g.blocks_per_row;
-    const int64_t gpx0 = bx * (int64_t)(64 * PG) + pg * 64;       // first pixel of this group
+    const int64_t gpx0 = bx * 64;                                   // first pixel of this group
     const int64_t x0 = gpx0 + lane;
     const int k = g.k;
     const bool in = x0 < g.nx;
     const int64_t xc = in ? x0 : g.nx - 1;
-    const int64_t off0 = row * g.sy + xc * g.sx;
     const int t_lo = w * KQ;
 
     if (g.write_tab && b == 0)
-        for (int j = tid; j <= k; j += 64 * NW * PG) g.tab_dev[j] = tab.e[j];
+        for (int j = tid; j <= k; j += 64 * NW) g.tab_dev[j] = tab.e[j];
 
-    // every load of the slice in flight (a plane's extent fits 32 bits of byte offset: g.off32)
+    // every load of the slice in flight: a uniform 64-bit base per plane and date (row and date are
+    // wave-uniform: scalar arithmetic) plus a 32-bit lane offset (a row's extent fits 32 bits of byte
+    // offset: g.lane32) -- `global_load_dword v, v_off, s[base]`, whatever the extent of the stack
     T v[KQ][9];
+    const unsigned lo = (unsigned)(xc * g.sx) * (unsigned)sizeof(T);
 #pragma unroll
     for (int tt = 0; tt < KQ; ++tt) {
         const int t = t_lo + tt < k ? t_lo + tt : k - 1;           // (behind the series: the last date again)
-        const unsigned o = (unsigned)(off0 + (int64_t)t * g.st) * (unsigned)sizeof(T);
+        const int64_t uo = row * g.sy + (int64_t)t * g.st;
 #pragma unroll
         for (int c = 0; c < 9; ++c)
             v[tt][c] = __builtin_nontemporal_load(
-                reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.pl[c]) + o));
+                reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.pl[c] + uo) + lo));
     }
 
     // zero-fill a quarter of the group's slice of the change map (issued early, never waited on)
@@ -308,11 +314,11 @@ __global__ void __launch_bounds__(64 * kC3Slices * PG, OCC) omnibus_c3_retain_ke
         }
     }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) part_s[pg][w][c][lane] = s[c];
-    part_p[pg][w][lane] = prod;
-    part_e[pg][w][0][lane] = emin;
-    part_e[pg][w][1][lane] = emax;
-    part_e[pg][w][2][lane] = (bad ? 1 : 0) | (dead ? 2 : 0);
+    for (int c = 0; c < 9; ++c) part_s[w][c][lane] = s[c];
+    part_p[w][lane] = prod;
+    part_e[w][0][lane] = emin;
+    part_e[w][1][lane] = emax;
+    part_e[w][2][lane] = (bad ? 1 : 0) | (dead ? 2 : 0);
     __syncthreads();
 
     const unsigned shard = (unsigned)(b % kC3Shards);
@@ -320,24 +326,24 @@ __global__ void __launch_bounds__(64 * kC3Slices * PG, OCC) omnibus_c3_retain_ke
         // the combined screen, by the group's first wave
         T S[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) S[c] = part_s[pg][0][c][lane];
-        double PP = part_p[pg][0][lane];
-        int fl = part_e[pg][0][2][lane];
+        for (int c = 0; c < 9; ++c) S[c] = part_s[0][c][lane];
+        double PP = part_p[0][lane];
+        int fl = part_e[0][2][lane];
         int eoff = 0;
         bool range_ok = true;
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
             if (u * KQ < k) {
-                const double pu = part_p[pg][u][lane];
-                const int lo = part_e[pg][u][0][lane], hi = part_e[pg][u][1][lane];
+                const double pu = part_p[u][lane];
+                const int lo = part_e[u][0][lane], hi = part_e[u][1][lane];
                 range_ok = range_ok & (lo > -1000) & (hi < 1000) & (eoff + lo > -1000) & (eoff + hi < 1000) &
                            (pu > 0.0) & (pu < INFINITY);
                 eoff += __builtin_amdgcn_frexp_exp(pu);
                 if (u > 0) {
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) S[c] = S[c] + part_s[pg][u][c][lane];
+                    for (int c = 0; c < 9; ++c) S[c] = S[c] + part_s[u][c][lane];
                     PP = PP * pu;
-                    fl |= part_e[pg][u][2][lane];
+                    fl |= part_e[u][2][lane];
                 }
             }
         }
@@ -363,15 +369,15 @@ __global__ void __launch_bounds__(64 * kC3Slices * PG, OCC) omnibus_c3_retain_ke
                     (uint32_t)(row * g.nx + x0);
         }
         if (lane == 0) {
-            flag_mask[pg] = m;
-            list_base[pg] = base;
+            flag_mask = m;
+            list_base = base;
         }
     }
     __syncthreads();
     // a candidate's slice leaves the registers: 9 KQ values as 16-byte pieces, the series of a pixel one run
-    const unsigned long long m = flag_mask[pg];
+    const unsigned long long m = flag_mask;
     if (m != 0ull && t_lo < k) {
-        const unsigned pos = list_base[pg] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned pos = list_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         if (((m >> lane) & 1ull) && pos < g.dump_cap) {
             typedef float f4 __attribute__((ext_vector_type(4)));
             f4 *dst = reinterpret_cast<f4 *>(g.dump + ((size_t)shard * g.dump_cap + pos) * g.dump_stride + t_lo * 9);
@@ -1222,28 +1228,32 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args
         int l = 0, t = 0, fire_at = -1;
         bool done = !active;
         uint8_t *res = s.change + pix * (int64_t)k;
+        // chunk `ci` of this lane's series into q (MODE 1 / 2: whole 16-byte pieces of dates, a piece behind
+        // the series is not read)
+        auto load_chunk = [&](const int ci, PV (&q)[NV]) {
+            if (MODE == 0) {
+#pragma unroll
+                for (int u = 0; u < NV; ++u) q[u] = src[ci * NV + u];
+            } else {
+                constexpr int PR = CD / VE;                 // pieces of a real variable per chunk
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const bool real = MODE == 1 || u < 3 * PR;
+                    const int c = real ? u / PR : 3 + 2 * ((u - 3 * PR) / (2 * PR));
+                    const int wv = real ? u % PR : (u - 3 * PR) % (2 * PR);
+                    const int t_first = ci * CD + (real ? wv * VE : (wv * VE) / 2);
+                    if (t_first < k)
+                        q[u] = real ? reinterpret_cast<const PV *>(s.pl[c] + off + ci * CD)[wv]
+                                    : reinterpret_cast<const PV *>(s.pl[c] + 2 * (off + ci * CD))[wv];
+                }
+            }
+        };
+        // (reading the next chunk ahead into a second set of registers was built and measured slower:
+        //  0.335 against 0.235 ms on config 4's share)
         while (__any(!done)) {
             const int ci = t / CD;                          // this lane's chunk (lanes restart at different dates)
             PV q[NV];
-            if (!done) {
-                if (MODE == 0) {
-#pragma unroll
-                    for (int u = 0; u < NV; ++u) q[u] = src[ci * NV + u];
-                } else {
-                    // (whole 16-byte pieces of dates: a piece behind the series is not read)
-                    constexpr int PR = CD / VE;             // pieces of a real variable per chunk
-#pragma unroll
-                    for (int u = 0; u < NV; ++u) {
-                        const bool real = MODE == 1 || u < 3 * PR;
-                        const int c = real ? u / PR : 3 + 2 * ((u - 3 * PR) / (2 * PR));
-                        const int wv = real ? u % PR : (u - 3 * PR) % (2 * PR);
-                        const int t_first = ci * CD + (real ? wv * VE : (wv * VE) / 2);
-                        if (t_first < k)
-                            q[u] = real ? reinterpret_cast<const PV *>(s.pl[c] + off + ci * CD)[wv]
-                                        : reinterpret_cast<const PV *>(s.pl[c] + 2 * (off + ci * CD))[wv];
-                    }
-                }
-            }
+            if (!done) load_chunk(ci, q);
 #pragma unroll 1
             for (int tt = 0; tt < CD; ++tt) {
                 const bool on = !done && (t == ci * CD + tt);
@@ -1459,7 +1469,7 @@ static C3Workspace c3_layout(int64_t npix, int64_t ny, int64_t k)
 }
 
 // ND_AMD_C3_RETAIN: 0 = never the time-split pass A, 1 (default) = where it applies; ND_AMD_C3_RETAIN_MIN_K: the
-// shortest series it takes (default 2); ND_AMD_C3_RETAIN_PG: pixel groups per block (1 or 2)
+// shortest series it takes (default 2)
 template <typename T>
 static bool c3_retain_ok(const C3Workspace &w, const C3Args<T> &g)
 {
@@ -1471,10 +1481,10 @@ static bool c3_retain_ok(const C3Workspace &w, const C3Args<T> &g)
         const char *e = getenv("ND_AMD_C3_RETAIN_MIN_K");
         return e ? atoi(e) : 2;
     }();
-    return sizeof(T) == 4 && on != 0 && w.dump_cap > 0 && g.k >= min_k && g.k <= kC3RetainMaxK && g.off32 != 0;
+    return sizeof(T) == 4 && on != 0 && w.dump_cap > 0 && g.k >= min_k && g.k <= kC3RetainMaxK && g.lane32 != 0;
 }
 
-static int c3_launch_retain(const C3Workspace &w, C3Args<double> &, const OmniTab &, unsigned char *, hipStream_t)
+static int c3_launch_retain(const C3Workspace &, C3Args<double> &, const OmniTab &, unsigned char *, hipStream_t)
 {
     return ND_AMD_EUNSUPPORTED;          // (float32 only: c3_retain_ok)
 }
@@ -1482,41 +1492,22 @@ static int c3_launch_retain(const C3Workspace &w, C3Args<double> &, const OmniTa
 static int c3_launch_retain(const C3Workspace &w, C3Args<float> &g, const OmniTab &tab, unsigned char *ws,
                             hipStream_t stream)
 {
-    static const int pg_env = [] {
-        const char *e = getenv("ND_AMD_C3_RETAIN_PG");
-        return e ? atoi(e) : 1;
-    }();
-    const int pg = pg_env == 2 ? 2 : 1;
     g.dump = reinterpret_cast<float *>(ws + w.off_dump);
     g.dump_cap = w.dump_cap;
     g.dump_stride = w.dump_stride;
-    g.blocks_per_row = ceil_div(g.nx, (int64_t)64 * pg);
+    g.blocks_per_row = ceil_div(g.nx, (int64_t)64);
     const int64_t nblocks = g.blocks_per_row * g.nrows;
     if (nblocks > 0x7fffffffLL) {
         set_error("nd_amd_omnibus_c3: raster too large for one launch");
         return ND_AMD_EUNSUPPORTED;
     }
-    const dim3 grid((unsigned)nblocks), block((unsigned)(64 * kC3Slices * pg));
-    static const int occ_env = [] {
-        const char *e = getenv("ND_AMD_C3_RETAIN_OCC");      // 4: at most 128 registers (a few spilled); 0: as compiled
-        return e ? atoi(e) : 0;
-    }();
-#define ND_C3_RETAIN(KQ_, OCC_)                                                                            \
-    do {                                                                                                   \
-        if (pg == 2)                                                                                       \
-            hipLaunchKernelGGL((omnibus_c3_retain_kernel<KQ_, 2, 2>), grid, block, 0, stream, g, tab);     \
-        else if (occ_env == 4)                                                                             \
-            hipLaunchKernelGGL((omnibus_c3_retain_kernel<KQ_, 1, 4>), grid, block, 0, stream, g, tab);     \
-        else                                                                                               \
-            hipLaunchKernelGGL((omnibus_c3_retain_kernel<KQ_, 1, OCC_>), grid, block, 0, stream, g, tab);  \
-    } while (0)
+    const dim3 grid((unsigned)nblocks), block((unsigned)(64 * kC3Slices));
     switch (w.kq) {
-    case 4: ND_C3_RETAIN(4, 4); break;
-    case 8: ND_C3_RETAIN(8, 4); break;
-    case 12: ND_C3_RETAIN(12, 3); break;
-    default: ND_C3_RETAIN(16, 2); break;
+    case 4: hipLaunchKernelGGL((omnibus_c3_retain_kernel<4>), grid, block, 0, stream, g, tab); break;
+    case 8: hipLaunchKernelGGL((omnibus_c3_retain_kernel<8>), grid, block, 0, stream, g, tab); break;
+    case 12: hipLaunchKernelGGL((omnibus_c3_retain_kernel<12>), grid, block, 0, stream, g, tab); break;
+    default: hipLaunchKernelGGL((omnibus_c3_retain_kernel<16>), grid, block, 0, stream, g, tab); break;
     }
-#undef ND_C3_RETAIN
     return ND_AMD_OK;
 }
 
@@ -1565,6 +1556,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     g.write_tab = 1;
     g.off32 = (sx >= 0 && sy >= 0 && st >= 0 &&
                ((nx - 1) * sx + (ny - 1) * sy + (k - 1) * st + 1) * (int64_t)sizeof(T) < 0xffffffffLL) ? 1 : 0;
+    g.lane32 = (sx >= 0 && (g.nx - 1) * sx * (int64_t)sizeof(T) < 0xffffffffLL) ? 1 : 0;
     g.nlooks = (double)n_looks;
     g.alpha = alpha;
     g.e = htab[(size_t)k];

@@ -210,3 +210,39 @@ def test_c3_pass_b_pixels_per_wave(lanes):
     out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, ND_AMD_C3_LANES=lanes),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize('k', [5, 16, 33, 48, 64])
+def test_c3_sparse_regime_degenerate_values(oracle, device, k):
+    """The time-split pass A of the sparse regime (omnibus_c3_retain_kernel: four waves share a pixel's
+    time axis, candidates dumped from registers, the dump searched one lane per pixel) on values its
+    re-associated screen cannot vouch for: non-positive-definite dates, under- and overflowing products
+    of determinants, prefix products far from the suffix's, nodata -- all must reach the exact pass or
+    be provably silent; more candidates than the dump holds; ragged rows."""
+    rng = np.random.default_rng(k)
+    planes = [p.copy() for p in synth.omnibus_stack_c3(seed=900 + k, k=k, ny=6, nx=333, dtype=np.float32,
+                                                       change_frac=0.3)]
+    planes[3][:, 0, 10:40] *= 5.0                      # |C12|^2 > C11 C22
+    planes[0][:, 1, 5:25] *= -1.0
+    for p in planes:
+        p[:, 2, 0:60] *= 1e-8                          # determinants ~1e-24: the product underflows for long series
+        p[:, 2, 60:120] *= 3e6
+        p[k // 2:, 3, 0:50] *= 1e-6
+        p[:, 3, 100:130] = 0.0
+        p[:, 3, 130:160] = np.nan
+    planes[2][k - 1, 4, 0:30] = np.inf
+    planes[5][0, 4, 30:60] = np.nan
+    for val in (0.0, -1.0):
+        m = rng.random(planes[0].shape) < 0.002
+        planes[int(rng.integers(0, 9))][m] = val
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    import torch
+    from nd_amd import kernels
+    dev = [torch.from_numpy(p).to(device) for p in planes]
+    for alpha in (0.8, 0.99):
+        with np.errstate(all='ignore'):
+            want = oracle.change_detection_pol(yxt, 3, alpha, 9, njobs=8)
+        got = kernels.change_detection_c3(dev, alpha=alpha, n=9)
+        torch.cuda.synchronize()
+        assert int((got.cpu().numpy() != want).sum()) == 0, (k, alpha)
+        assert want.sum() > 0

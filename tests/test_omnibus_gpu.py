@@ -255,3 +255,40 @@ def test_nodata_margins_at_low_thresholds(oracle, device, dtype, k):
         assert int((got != want).sum()) == 0, (k, alpha)
         assert not got[:, 0:215].any()             # nodata never changes
         assert got[:, 215:].any()
+
+
+@pytest.mark.parametrize('k', [49, 57, 64, 80, 96, 97, 130, 192])
+def test_long_series_sparse_regime(oracle, device, k):
+    """49 .. 192 float32 dates in the sparse regime (alpha >= 0.75): the time-split pass A
+    (omnibus_c2_split_kernel: four or eight waves share a pixel's time axis, candidates dumped from
+    registers) and the LDS-DMA ring search behind it; with the minimal workspace (no dump: every
+    candidate gathered from the planes) and with degenerate values -- whatever the re-associated screen
+    cannot vouch for must reach the exact pass -- the map equals the oracle's byte for byte."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(k)
+    planes = [p.copy() for p in synth.omnibus_stack(seed=700 + k, k=k, ny=5, nx=333, dtype=np.float32,
+                                                    change_frac=0.25)]
+    planes[1][:, 0, 10:40] *= 6.0                      # |C12|^2 > C11 C22: not positive semi-definite
+    planes[0][:, 1, 5:25] *= -1.0
+    for p in planes:
+        p[:, 2, 0:60] *= 1e-12                         # the product of determinants underflows
+        p[:, 2, 60:120] *= 1e10                        # ... overflows
+        p[k // 2:, 3, 0:50] *= 1e-9                    # prefix product in range, suffix far below
+        p[:, 3, 100:130] = 0.0                         # nodata
+        p[:, 3, 130:160] = np.nan
+    planes[3][k - 1, 4, 0:30] = np.inf
+    planes[2][0, 4, 30:60] = np.nan
+    for val in (0.0, -1.0):
+        m = rng.random(planes[0].shape) < 0.002
+        planes[int(rng.integers(0, 4))][m] = val
+    yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
+    dev = [torch.from_numpy(p).to(device) for p in planes]
+    for alpha in (0.8, 0.99):
+        with np.errstate(all='ignore'):
+            want = oracle.change_detection_planes(yxt, alpha, 9, njobs=8)
+        for ws in ('recommended', 'minimal'):
+            got = kernels.change_detection(*dev, alpha=alpha, n=9, dims=('time', 'y', 'x'), workspace=ws)
+            torch.cuda.synchronize()
+            assert int((got.cpu().numpy() != want).sum()) == 0, (k, alpha, ws)
+        assert want.sum() > 0

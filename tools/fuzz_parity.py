@@ -30,7 +30,7 @@ def wishart(rng, k, ny, nx, looks, dtype, pol=2):
 
 
 def case_omnibus(rng):
-    k = int(rng.choice([2, 3, 5, 8, 9, 12, 16, 17, 24, 25, 31, 32, 33, 40, 48, 49, 60, 63, 64, 65]))
+    k = int(rng.choice([2, 3, 5, 8, 9, 12, 16, 17, 24, 25, 31, 32, 33, 40, 48, 49, 60, 63, 64, 65, 80, 96, 97, 128, 130, 160, 192]))
     ny, nx = int(rng.integers(1, 40)), int(rng.integers(1, 300))
     looks = int(rng.choice([1, 2, 4, 9, 20]))
     dtype = rng.choice([np.float32, np.float64])

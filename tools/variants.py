@@ -26,6 +26,17 @@ VARIANTS = {
         ("            const int e = __builtin_amdgcn_frexp_exp(prod);\n            emin = e < emin ? e : emin;\n"
          "            emax = e > emax ? e : emax;\n", ""),
     ], []),
+    # plain instead of non-temporal loads in the time-split pass A
+    'c3_plain_loads': ('omnibus_c3.hip', [
+        ("            v[tt][c] = __builtin_nontemporal_load(\n                reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.pl[c] + uo) + lo));\n",
+         "            v[tt][c] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.pl[c] + uo) + lo);\n"),
+    ], []),
+    # XCD-aware order: the blocks one XCD receives (every eighth) walk a contiguous eighth of the raster
+    'c3_xcd': ('omnibus_c3.hip', [
+        ("    const int w = wv % NW, pg = wv / NW;\n    const int64_t b = blockIdx.x;\n",
+         "    const int w = wv % NW, pg = wv / NW;\n    const int64_t nb8 = (int64_t)gridDim.x / 8;\n"
+         "    const int64_t b = (int64_t)blockIdx.x < 8 * nb8 ? ((int64_t)blockIdx.x % 8) * nb8 + (int64_t)blockIdx.x / 8 : (int64_t)blockIdx.x;\n"),
+    ], []),
 }
 
 
