@@ -115,6 +115,9 @@ def parse():
                          'device clocks and transfer rates; they go to bench_extras.json / '
                          'bench_detail.json, never into the line')
     ap.add_argument('--no-extra', action='store_true', help='(accepted, ignored: extras are opt-in now)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='N = 1, default workload: skip the `secondary` block of the line (BASELINE configs 3 - 5 '
+                         'at one GPU\'s share: a few steps and a sampled oracle check each, ~30 s of wall)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch of the dominant kernel from a separate '
                          'rocprofv3 --pmc pass, copied into roofline.traffic')
@@ -582,10 +585,18 @@ class Pipeline(Workload):
                    'halo rows exchanged with the neighbour ranks over RCCL every step'
                    if self.world > 1 else 'single rank: no exchange'))
 
-    def check(self, out, nsample=0):
+    def check(self, out, nsample=0, light=False):
         from nd_amd import kernels
         from oracle import checks
         kernels.raise_if_no_solution(self.status_any)
+        if light:
+            # the `secondary` block: the corner crops of the two edge bands and one interior crop
+            res = checks.nlmeans_crops(self.stack, self.filtered, TUT['r'], TUT['f'], TUT['sigma'],
+                                       TUT['h'], TUT['n_eff'], self.a.patch_mode,
+                                       [(0, 0), (self.rows, 0), (self.rows // 2, self.nx // 3)],
+                                       size=(8, 256), then_omnibus=(self.a.alpha, TUT['n']), change=out)
+            res['bands'] = 'three 8 x 256 crops: the first and last rows at column 0, one in the interior'
+            return res
         # the two edge bands of the tile whole (rows 0 .. 7 and the last 8, every column: with neighbour
         # ranks these are the rows the separate edge launches compute) and a crop from the interior
         res = checks.nlmeans_crops(self.stack, self.filtered, TUT['r'], TUT['f'], TUT['sigma'],
@@ -659,8 +670,9 @@ EXTRA_KEYS = ('omnibus_a0.01', 'omnibus_a0.0001', 'omnibus_a0.2', 'ml3', 'ml5', 
               'boxcar3', 'boxcar5', 'gauss1', 'nlm_pm0', 'nlm_pm1', 'pipeline')
 
 
-def extras(main, barrier, dev, only=None):
-    """The other kernels of the path.  only = one of EXTRA_KEYS: just that workload (--traffic-run)."""
+def extras(main, barrier, dev, only=None, light=False):
+    """The other kernels of the path.  only = one of EXTRA_KEYS: just that workload (--traffic-run).
+    light: the `secondary` block of the default run -- fewer steps, no CPU baselines, smaller oracle samples."""
     import numpy as np
     import torch
     from nd_amd import kernels
@@ -671,7 +683,9 @@ def extras(main, barrier, dev, only=None):
     quick = TRAFFIC_MODE
 
     def want(*keys):
-        return only is None or only in keys
+        if only is None or isinstance(only, str):
+            return only is None or only in keys
+        return any(k_ in only for k_ in keys)
 
     def roof(key, hint, dom, km, alg_bytes, note=None):
         traffic, source = profiled_traffic(key, hint)
@@ -783,15 +797,16 @@ def extras(main, barrier, dev, only=None):
             if not want(key):
                 continue
             a3.alpha = alpha
-            dt, km, ch = timed_extra(w.step, 10, 10, barrier)
+            nst = 5 if light else 10
+            dt, km, ch = timed_extra(w.step, nst, 3 if light else 10, barrier)
             if quick:
                 continue
-            res = w.check(ch)
+            res = w.check(ch, nsample=5000 if light else 20000)
             dom = w.dom if (alpha > 0.5 and w.dom in km) else max(km, key=km.get)
-            entry(key, w.describe(), dt, 10, w.npix, km,
+            entry(key, w.describe(), dt, nst, w.npix, km,
                   roof(key, 'omnibus_c3_global' if alpha > 0.5 else 'omnibus_c3_stream', dom, km, w.alg_bytes,
                        note=None if alpha > 0.5 else 'search fused into the streaming pass (omnibus_c3_stream_kernel)'),
-                  res['bad'] == 0, sample=res)
+                  res['bad'] == 0, sample=res, alg_bytes=w.alg_bytes)
             del ch
         # -- the same test on data in the reference's layout: nine (y, x, time) variables, the off-diagonals as
         #    interleaved complex arrays (what OmnibusTest(pol='full').apply(ds) receives)
@@ -894,7 +909,7 @@ def extras(main, barrier, dev, only=None):
             key = 'nlm_pm%d' % pm
             if not want(key):
                 continue
-            steps = 5 if pm == 0 else 2
+            steps = (3 if pm == 0 else 1) if light else (5 if pm == 0 else 2)
             fn = lambda: kernels.pixelwise_nlmeans_3d(x.permute(2, 3, 1, 0), y.permute(2, 3, 1, 0),    # noqa: E731
                                                       (10, 10, 0), (3, 3, 0), 0.5, 0.5, -1, patch_mode=pm)
             dt, km, _ = timed(fn, steps, 1, barrier)
@@ -905,7 +920,7 @@ def extras(main, barrier, dev, only=None):
             nq = 21 * 21 - 1
             flop = x.numel() * nq * (49 * 3 + 8) if pm else x.numel() * nq * 2
             e = dict(sample=res, TFLOPs_naive_formula=flop / (dt / steps) / 1e12)
-            if pm == 1:
+            if pm == 1 and not light:
                 crop = np.ascontiguousarray(x[:, :1, :640, :640].permute(2, 3, 1, 0).cpu().numpy())
                 o = np.empty_like(crop)
                 t0 = time.perf_counter()
@@ -941,7 +956,7 @@ def extras(main, barrier, dev, only=None):
         # allocation of each costs tens of milliseconds of hipMalloc
         dt, km, ch = timed(w.step, 3, 2, barrier)
         if not quick:
-            res = w.check(ch)
+            res = w.check(ch, light=light)
             nq_t = 3 * 7 * 7 - 1                              # neighbours of the tutorial's window
             entry('pipeline', w.describe(), dt, 3, w.npix, km,
                   valu_roofline(roof('pipeline', 'nlmeans', w.dom, km, w.alg_bytes),
@@ -954,7 +969,38 @@ def extras(main, barrier, dev, only=None):
     return out
 
 
+SECONDARY = (('nlm_cc_pm0', 'nlm_pm0'), ('nlm_cc_pm1', 'nlm_pm1'), ('c3_share_a0.99', 'c3_a0.99'),
+             ('pipeline_share', 'pipeline'))
+
+
+def secondary(main, barrier, dev):
+    """The other BASELINE configs in the driver-run line, compactly: config 3 (non-local
+    means 7 x 7 / 21 x 21 on 12t x 4096 x 4096, the reference-compatible and the signed patch distances), one
+    GPU's share of config 4 (full-pol C3 48t x 1024 x 8192 at alpha = 0.99) and of config 5 (the tutorial
+    pipeline on 24t x 2048 x 16384 x 4).  -> ({key: [ms_per_step, frac, 'hbm' | 'valu', matches_oracle_on_sample]},
+    the long entries for bench_detail.json).  frac is of the WHOLE step: algorithmic bytes per step against the
+    HBM peak, or the algorithm's dependent float32 additions per step against the packed-add rate."""
+    block, long_form = {}, []
+    t0 = time.perf_counter()
+    es = {e['key']: e for e in extras(main, barrier, dev, only=tuple(ek for _, ek in SECONDARY), light=True)}
+    wall = time.perf_counter() - t0
+    for key, ekey in SECONDARY:
+        e = es[ekey]
+        r = e['roofline']
+        step_s = e['ms'] * 1e-3
+        if r['bound'] == 'valu':
+            frac = r['algorithmic_additions_per_launch'] / step_s / 1e12 / VALU_PK_F32_TADD
+        else:
+            frac = e.get('alg_bytes', r['algorithmic_bytes_per_launch']) / step_s / 1e9 / HBM_PEAK_GBS
+        block[key] = [float('%.4g' % e['ms']), float('%.3g' % frac), r['bound'], bool(e['matches_oracle_on_sample'])]
+        long_form.append(e)
+    long_form.append({'wall_s_of_the_block': wall})
+    return block, long_form
+
+
 LINE_LIMIT = 4096           # bytes; the driver keeps only the tail of stdout and parses its last line
+SECONDARY_LIMIT = 500       # bytes of the `secondary` block
+LINE_LIMIT_WITH_SECONDARY = 1900    # the driver keeps a 2 000-character tail
 
 
 def _r(x, nd=4):
@@ -994,6 +1040,8 @@ def headline(m):
         line['comm'] = m['comm']
     if m.get('matches_oracle_on_sample') is not None:
         line['matches_oracle_on_sample'] = m['matches_oracle_on_sample']
+    if m.get('secondary') is not None:
+        line['secondary'] = m['secondary']
     for k in ('detail_file', 'extras_file'):
         if m.get(k):
             line[k] = m[k]
@@ -1004,8 +1052,14 @@ def emit(line):
     """strict JSON, one line, under LINE_LIMIT bytes -- or no line at all (a line the driver cannot
     parse leaves the round unmeasured: better to fail here, loudly)"""
     text = json.dumps(line, allow_nan=False, separators=(',', ':'))
-    if '\n' in text or len(text.encode()) >= LINE_LIMIT:
-        raise RuntimeError('bench line is %d bytes (limit %d)' % (len(text.encode()), LINE_LIMIT))
+    limit = LINE_LIMIT
+    if line.get('secondary') is not None:
+        limit = LINE_LIMIT_WITH_SECONDARY
+        sec = json.dumps(line['secondary'], allow_nan=False, separators=(',', ':'))
+        if len(sec.encode()) >= SECONDARY_LIMIT:
+            raise RuntimeError('the secondary block is %d bytes (limit %d)' % (len(sec.encode()), SECONDARY_LIMIT))
+    if '\n' in text or len(text.encode()) >= limit:
+        raise RuntimeError('bench line is %d bytes (limit %d)' % (len(text.encode()), limit))
     return text
 
 
@@ -1289,6 +1343,9 @@ def main():
             chk = w.check(out)
             detail['check'] = chk
             m['matches_oracle_on_sample'] = bool(chk.get('bad', 1) == 0 and chk.get('change_bad', 0) == 0)
+        if world == 1 and is_default and not args.no_secondary and not args.extras:
+            # configs 3 - 5 in the driver-run line (behind every timed region of the headline)
+            m['secondary'], detail['secondary'] = secondary(w, barrier, dev)
         if args.extras and world == 1 and w.name == 'omnibus':
             # the secondary workloads: their own invocation (`bench.py --extras`), their own file
             detail['device_state'] = {'before_timed_region': state_before, 'after_timed_region': state_after}

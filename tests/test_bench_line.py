@@ -52,6 +52,26 @@ def _stub(world):
     return m
 
 
+def test_secondary_block_fits_the_drivers_tail():
+    """The default N = 1 run adds `secondary` (BASELINE configs 3 - 5 at one GPU's share): at most 500 bytes,
+    the whole line under 1 900 so that the driver's 2 000-character tail keeps it whole; strict JSON."""
+    import bench
+    m = _stub(1)
+    m['secondary'] = {'nlm_cc_pm0': [2.112345, 0.4412345, 'valu', True], 'nlm_cc_pm1': [41.81234, 0.404123, 'valu', True],
+                      'c3_share_a0.99': [2.851234, 0.661234, 'hbm', True], 'pipeline_share': [14.85912, 0.494123, 'valu', True]}
+    text = bench.emit(bench.headline(m))
+    assert len(text.encode()) < 1900, len(text)
+    line = json.loads(text)
+    assert set(line['secondary']) == {k for k, _ in bench.SECONDARY}
+    assert len(json.dumps(line['secondary'], separators=(',', ':'))) < 500
+    for ms, frac, bound, ok in line['secondary'].values():
+        assert ms > 0 and 0 < frac < 1 and bound in ('hbm', 'valu') and ok is True
+    m['secondary']['x' * 300] = [1.0, 0.5, 'hbm', True]
+    m['secondary']['y' * 300] = [1.0, 0.5, 'hbm', True]
+    with pytest.raises(RuntimeError, match='secondary'):
+        bench.emit(bench.headline(m))
+
+
 @pytest.mark.parametrize('world', [1, 2, 8])
 def test_line_is_the_headline_object_only_and_short(world):
     import bench
