@@ -46,19 +46,34 @@ PER_FILE = {'nlmeans.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_NLM_F
 # (the N newest operations it leaves outstanding then include the scratch access, never an OLDER
 # transfer), i.e. cost time, not correctness -- but time is what this kernel is about, and a compiler
 # or flag change that pushes the step loop into scratch should not pass unnoticed.  The build reads the
-# compiler's own resource report (-Rpass-analysis=kernel-resource-usage) and fails if an instantiation
-# exceeds its budget: none for the sparse form (pass A of the benchmark regime), what the fused-search
+# compiler's own resource report (-Rpass-analysis=kernel-resource-usage) and warns (fails under
+# ND_AMD_STRICT_SCRATCH=1) if an instantiation exceeds its budget: none for the sparse form (pass A of the benchmark regime), what the fused-search
 # and statistics forms are known to spill in their tails (bytes per lane) otherwise.
 NO_SCRATCH = {'omnibus_ml.hip': 'omnibus_c2_ml_kernel'}
-# template arguments <K, KMAX, STATS, CHAIN> as they appear in the mangled name
-SCRATCH_BUDGET = {'Lb0ELb0E': 0, 'Lb0ELb1E': 96, 'Lb1ELb0E': 256}
+# bytes per lane by the kernel's template arguments <K, KMAX, STATS, CHAIN>, keyed (STATS, CHAIN)
+SCRATCH_BUDGET = {(False, False): 0, (False, True): 96, (True, False): 256}
 
 
-def check_no_scratch(remarks_path, symbol):
-    """-> [(function, bytes per lane)] of the kernels whose mangled name contains `symbol`; raises if
-    any of them exceeds its scratch budget, or if the report holds none of them (a renamed kernel must
-    not pass)."""
+def _template_bools(mangled, symbol):
+    """(STATS, CHAIN) of an omnibus_c2_ml_kernel instantiation from its mangled name
+    (...omnibus_c2_ml_kernelILi3ELi24ELb0ELb1EEEv...), or None if the name does not parse."""
     import re
+    m = re.search(re.escape(symbol) + r'I((?:L[ib]\d+E)+)E', mangled)
+    if not m:
+        return None
+    flags = re.findall(r'Lb(\d)E', m.group(1))
+    return (flags[0] == '1', flags[1] == '1') if len(flags) == 2 else None
+
+
+def check_no_scratch(remarks_path, symbol, obj_path=None):
+    """-> [(function, bytes per lane)] of the kernels whose mangled name contains `symbol`.  An instantiation
+    over its budget is a SPEED regression (the counted waits only get stricter), so it is reported as a
+    warning; ND_AMD_STRICT_SCRATCH=1 (CI) turns it into an error.  A report that is missing or older than
+    the object it describes says nothing and is skipped."""
+    import re
+    if not os.path.exists(remarks_path) or (obj_path and os.path.exists(obj_path)
+                                            and os.path.getmtime(remarks_path) + 1.0 < os.path.getmtime(obj_path)):
+        return []
     found, cur = [], None
     for ln in open(remarks_path, errors='replace'):
         m = re.search(r'Function Name: (\S+)', ln)
@@ -68,16 +83,25 @@ def check_no_scratch(remarks_path, symbol):
         m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', ln)
         if m and cur is not None and symbol in cur:
             found.append((cur, int(m.group(1))))
+    strict = os.environ.get('ND_AMD_STRICT_SCRATCH', '') == '1'
     if not found:
-        raise RuntimeError('%s: no resource report for %s (is -Rpass-analysis=kernel-resource-usage on?)'
-                           % (remarks_path, symbol))
+        msg = ('%s: no resource report for %s (is -Rpass-analysis=kernel-resource-usage on?)'
+               % (remarks_path, symbol))
+        if strict:
+            raise RuntimeError(msg)
+        sys.stderr.write('nd_amd.build: warning: ' + msg + '\n')
+        return found
     bad = []
     for f, n in found:
-        budget = next((b for key, b in SCRATCH_BUDGET.items() if key + 'EEvNS' in f), 0)
+        key = _template_bools(f, symbol)
+        budget = SCRATCH_BUDGET.get(key, 0) if key is not None else 0
         if n > budget:
             bad.append((f, n, budget))
-    if bad and os.environ.get('ND_AMD_ALLOW_SCRATCH', '') != '1':
-        raise RuntimeError('scratch use (bytes per lane) over budget: %s' % bad)
+    if bad:
+        msg = 'scratch use (bytes per lane) over budget: %s' % bad
+        if strict:
+            raise RuntimeError(msg)
+        sys.stderr.write('nd_amd.build: warning: ' + msg + ' (speed only; ND_AMD_STRICT_SCRATCH=1 makes this an error)\n')
     return found
 
 
@@ -136,7 +160,8 @@ def _build(force, verbose, extra_flags, LIB, OBJ):
     for src in sources():
         sym = NO_SCRATCH.get(os.path.basename(src))
         if sym:
-            check_no_scratch(os.path.join(OBJ, os.path.basename(src)[:-4] + '.o.remarks'), sym)
+            objp = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+            check_no_scratch(objp + '.remarks', sym, objp)
     linked = False
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs

@@ -247,6 +247,13 @@ def change_detection_c3_pixel_major(planes, alpha, n=1, stats=False):
         ids.append(_pixel_major_stride(t))
         if ids[-1] is None:
             return None
+    # the entry point's documented conditions (include/nd_amd.h), checked before anything is allocated: with the
+    # reference's default alpha = 0.01 every full-pol (y, x, time) call would otherwise allocate the map and the
+    # workspace only to learn that it is declined
+    ve = 16 // p0.element_size()
+    if (not (alpha >= 0.75) or k % ve != 0 or 16 * 9 * k * p0.element_size() > 56 * 1024
+            or any(t.data_ptr() % 16 != 0 for t, i in zip(planes, ids) if i == 1)):
+        return None
     dev = p0.device
     L = _lib.lib()
     with torch.cuda.device(dev):
@@ -521,8 +528,10 @@ def convolve(inp, kernel, out=None, mode='reflect', cval=0.0, origin=0):
     # back first (a 3 x 1 x 1 window on 8 x 2048^2: 0.95 ms of transposes around 0.08 ms of filtering).  The
     # reference's (y, x, time) layout with a (y, x) window keeps its transpose kernels: its last axis is the
     # short one.
+    # (only where the LAST axis is long -- it is the tiles' x axis; on time-fastest data, (y, x, time)
+    # or (var, y, x, time) with a window over y and / or x, wide tiles would idle over a short time axis)
     in_place = (inp.stride(-1) == 1 and out.stride(-1) == 1 and all(d >= nd - 3 for d in span)
-                and not (nd == 3 and span == [0, 1]))
+                and not (nd == 3 and span == [0, 1]) and inp.shape[-1] >= 64)
     if (0 < len(span) <= 2 and nd <= 4 and not in_place
             and (span != tail or inp.stride(-1) != 1 or out.stride(-1) != 1)
             and inp.numel() >= (1 << 16)):

@@ -213,9 +213,35 @@ _FORMS_LONG = [{}, {'ND_AMD_FUSED_FORM': '0', 'ND_AMD_SEARCH_STARTS': '0'}, {'ND
                {'ND_AMD_SEARCH_PXW': '64'}, {'ND_AMD_SEARCH_PXW': '32', 'ND_AMD_FUSED_ALPHA': '0'}]
 
 
-@pytest.mark.parametrize('k,env', [(24, e) for e in _FORMS_24] + [(12, e) for e in _FORMS_12] +
-                         [(48, e) for e in _FORMS_LONG] + [(96, e) for e in _FORMS_LONG])
-def test_every_kernel_form_gives_the_same_map(k, env):
+def _bench_dense_many(jobs, workers=4):
+    """jobs: [(label, argv of tools/bench_dense.py, environment additions, number of result lines expected)].
+    Every form is forced through the environment, which the library reads once per process: one fresh process
+    per job, `workers` of them at a time (the GPU box allows six processes on its card; this one counts).
+    -> {label: result lines}; asserts exit codes and line counts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def one(job):
+        label, argv, env, nlines = job
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py')] + argv, env=e,
+                             capture_output=True, text=True, timeout=600, stdin=subprocess.DEVNULL)
+        assert out.returncode == 0, (label, out.stderr[-2000:])
+        lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == nlines, (label, out.stdout[-2000:])
+        return label, lines
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return dict(pool.map(one, jobs))
+
+
+@pytest.mark.parametrize('k,forms', [(24, _FORMS_24), (12, _FORMS_12), (48, _FORMS_LONG), (96, _FORMS_LONG)])
+def test_every_kernel_form_gives_the_same_map(k, forms):
     """The library picks among several forms of the search by alpha, series length and a sample of the
     data (streaming fused, chain fused in registers or in two streaming passes, separate dense kernel,
     gate on / off; LDS-DMA or register-staged pixel-major pass A; pixel-major streaming search from
@@ -223,54 +249,45 @@ def test_every_kernel_form_gives_the_same_map(k, env):
     segment start).  The choice is about speed only: force each form in a fresh process, at 12, 24, 48
     and 96 dates, and compare with the oracle -- also with every pixel of a low-threshold run going
     through pass B (ND_AMD_FUSED_ALPHA=0).  (Round 4 deleted the forms that lost everywhere: the
-    register triangle ND_AMD_FUSED_FORM=1 and the round-based pass B ND_AMD_SEARCH_MODE=2.)"""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ)
-    e.update(env)
+    register triangle ND_AMD_FUSED_FORM=1 and the round-based pass B ND_AMD_SEARCH_MODE=2.  Round 6: the
+    forms of one series length run four processes at a time -- 32 processes one after the other were
+    250 s of the suite.)"""
     long_ = k > 24
     layouts = 'planar' if long_ else 'planar,pm'
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py'), '--k', str(k), '--ny',
-                          '256' if long_ else '512', '--nx', '2048', '--alphas', '1e-4,0.01,0.2,0.6,0.99',
-                          '--steps', '1', '--cpu-rows', '256' if long_ else '512', '--layouts', layouts],
-                         env=e, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == (5 if long_ else 10), out.stdout[-2000:]
-    for r in lines:
-        assert r['bytes_differing'] == 0, r
+    argv = ['--k', str(k), '--ny', '256' if long_ else '512', '--nx', '2048', '--alphas', '1e-4,0.01,0.2,0.6,0.99',
+            '--steps', '1', '--cpu-rows', '256' if long_ else '512', '--layouts', layouts]
+    jobs = [(repr(sorted(env.items())), argv, env, 5 if long_ else 10) for env in forms]
+    if long_:
+        # (round 6) the sparse regime of 96 dates: the time-split pass A off / pass B from its LDS image /
+        # the double-precision screen of the sweep
+        jobs += [(repr(sorted(env.items())), argv, env, 5) for env in
+                 ({'ND_AMD_C2_SPLIT': '0'}, {'ND_AMD_SEARCH_FS': '0'}, {'ND_AMD_C2_SPLIT': '1', 'ND_AMD_SEARCH_MODE': '0'})]
+    for label, lines in _bench_dense_many(jobs).items():
+        for r in lines:
+            assert r['bytes_differing'] == 0, (label, r)
 
 
-@pytest.mark.parametrize('k,dtype,env', [(20, 'f64', {}), (24, 'f64', {}), (33, 'f32', {}), (32, 'f32', {}), (12, 'f64', {}),
-                                         (40, 'f32', {}), (63, 'f32', {}), (96, 'f32', {}), (128, 'f32', {}), (40, 'f64', {}),
-                                         (96, 'f32', {'ND_AMD_FUSED_FORM': '3', 'ND_AMD_SEARCH_STARTS': '0'})])
-def test_chain_form_series_lengths(k, dtype, env):
+_CHAIN_LENGTHS = [(20, 'f64', {}), (24, 'f64', {}), (33, 'f32', {}), (32, 'f32', {}), (12, 'f64', {}),
+                  (40, 'f32', {}), (63, 'f32', {}), (96, 'f32', {}), (128, 'f32', {}), (40, 'f64', {}),
+                  (96, 'f32', {'ND_AMD_FUSED_FORM': '3', 'ND_AMD_SEARCH_STARTS': '0'})]
+
+
+def test_chain_form_series_lengths():
     """dense_chain beyond the 24 float32 dates of the benchmark: 32 float32 / 16 float64 dates (two
     waves per SIMD), the 64-bit-mask instantiation for 17 .. 24 float64 dates (default between the
     streaming search's thresholds and the sparse regime), and beyond the registers the chain search in
     two streaming passes (33 .. 128 dates: 64- and 128-bit masks, pending global tests, the per-start
     pass B with two starts per lane), each against the oracle.  (The 33 .. 48-date float32 register
     instantiation was deleted in round 4: it spilled and never was the default.)"""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ)
-    e.update(env)
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_dense.py'), '--k', str(k), '--dtype', dtype,
-                          '--ny', '256' if k > 64 else '512', '--nx', '2048', '--alphas', '0.05,0.3,0.6', '--steps', '1',
-                          '--cpu-rows', '256', '--layouts', 'planar'],
-                         env=e, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 3, out.stdout[-2000:]
-    for r in lines:
-        assert r['bytes_differing'] == 0, r
-        assert 'omnibus_c2_fused' in r['kernels_ms'], r
+    jobs = []
+    for k, dtype, env in _CHAIN_LENGTHS:
+        argv = ['--k', str(k), '--dtype', dtype, '--ny', '256' if k > 64 else '512', '--nx', '2048',
+                '--alphas', '0.05,0.3,0.6', '--steps', '1', '--cpu-rows', '256', '--layouts', 'planar']
+        jobs.append(('%d %s %r' % (k, dtype, env), argv, env, 3))
+    for label, lines in _bench_dense_many(jobs).items():
+        for r in lines:
+            assert r['bytes_differing'] == 0, (label, r)
+            assert 'omnibus_c2_fused' in r['kernels_ms'], (label, r)
 
 
 @pytest.mark.parametrize('dtype,k', [('float32', 40), ('float64', 24), ('float32', 80)])

@@ -29,7 +29,13 @@ import sys
 GATHER_KERNELS = ('omnibus_c3_search_kernel', 'omnibus_c3_search_starts_kernel')
 
 
-def fetch_factor(kernel_name):
+def fetch_factor(kernel_name, workload=''):
+    """ by kernel AND workload: on pixel-major inputs (c3_pm_*) omnibus_c3_search_kernel's image
+    form reads contiguous per-pixel runs with 16-byte loads -- factor 2 like every coalesced form; since round 6
+    the sparse-regime searches (omnibus_c3_search_dump_kernel) read 16-byte pieces of contiguous runs
+    everywhere and are not in the gather list."""
+    if workload.startswith('c3_pm'):
+        return 2.0
     return 1.0 if any(g in kernel_name for g in GATHER_KERNELS) else 2.0
 
 
@@ -66,7 +72,7 @@ def main():
             f = sum(v) / len(v) * 1024.0
             w = wr.get(name, [0.0])
             w = sum(w) / len(w) * 1024.0
-            ff = fetch_factor(name)
+            ff = fetch_factor(name, k)
             rows.append({'kernel': name, 'launches': len(v), 'fetch_size_bytes': f, 'fetch_factor': ff,
                          'fetch_bytes': ff * f, 'write_bytes': w, 'traffic_bytes': ff * f + w})
         out['workloads'][k] = sorted(rows, key=lambda r: -r['traffic_bytes'])
