@@ -962,6 +962,269 @@ __global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_kernel(const C3A
     }
 }
 
+// ---- the chain search in two streaming passes (round 6) --------------------------------------------
+// The full-pol counterpart of omnibus_c2_stream_chain_kernel (omnibus.hip), for the thresholds between the
+// streaming search's and the sparse regime's (0.02 < alpha < 0.75): there a marginal test over four and more
+// dates is the rule, and the streaming search above re-reads the dates of every such segment from memory
+// (48 x 512 x 4096 at alpha = 0.5: 3.3 ms against 0.97 ms at 0.01).  single_pixel_change_detection consumes
+// every date ONCE (nd/_change.pyx:246-256: the marginal tests of a segment extend one running sum, and the
+// next segment starts at the date that fired); only the global test of ts[l:] looks ahead.  So:
+//   pass 1, dates last to first: the global test of EVERY segment start from suffix sums in double, with
+//           the rounding band of the reference's forward sums (omnibus_c3_stream_kernel's bound), two mask
+//           bits per date;
+//   pass 2, dates first to last (date index wave-uniform, every lane busy at every date): each lane carries
+//           the reference's own running state of its CURRENT segment -- nine sums in `floating`, the double
+//           product of the determinants -- and decides the marginal test over its j dates (bit-identical
+//           determinants, the tight band; the constants of the lane's own j from an LDS table).  A global
+//           test pass 1 could not decide is carried as ONE pending test per pixel and decided exactly at the
+//           end from the reference's own sums of that segment; a second one hands the pixel to pass B.
+// Twice the traffic of the one-pass form, the same cost at every threshold.
+template <typename T, int MW>
+__global__ void __launch_bounds__(kC3Threads) omnibus_c3_stream_chain_kernel(const C3Args<T> g, const OmniTab tab,
+                                                                             const StreamScreen<c3_stream_nj(MW)> ss,
+                                                                             const int dense_min)
+{
+    constexpr int PF = 3;
+    typedef typename std::conditional<MW == 2, Bits128, unsigned long long>::type MT;
+    constexpr int kMaxDates = MW == 2 ? 128 : 64;
+    __shared__ StreamEntry tab_lds[kMaxDates + 1];
+    __shared__ __align__(16) uint32_t out_img[(kC3Threads / 64) * 16 * kMaxDates];   // store_change_rows_wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t b = blockIdx.x;
+    const int64_t row = b / g.blocks_per_row;
+    const int64_t bx = b - row * g.blocks_per_row;
+    const int64_t bpx0 = bx * (int64_t)kC3Threads;
+    const int64_t x0 = bpx0 + tid;
+    const int k = g.k;
+    const bool in = x0 < g.nx;
+    const int64_t xc = in ? x0 : g.nx - 1;                  // idle lanes re-read the last pixel
+    const int64_t off0 = row * g.sy + xc * g.sx;
+    auto load = [&](const int t, T (&v)[9]) {               // (g.off32: 32-bit byte offsets, see the streaming search)
+        const unsigned o = (unsigned)(off0 + (int64_t)t * g.st) * (unsigned)sizeof(T);
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            v[c] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(g.pl[c]) + o);
+    };
+    for (int j = tid; j <= kMaxDates; j += kC3Threads) tab_lds[j] = ss.e[j];
+    if (g.write_tab && b == 0)
+        for (int j = tid; j <= k; j += kC3Threads) g.tab_dev[j] = tab.e[j];
+    __syncthreads();
+
+    // ---- pass 1: the global test of every segment start, dates last to first ----
+    MT gF = mask_zero<MT>(), gC = mask_zero<MT>();
+    bool bad = false, dead = false;
+    const T dlo = (T)ss.dlo, dhi = (T)ss.dhi;
+    {
+        T ring[PF][9];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load(k - 1 - u > 0 ? k - 1 - u : 0, ring[u]);
+        double S[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) S[c] = 0.0;
+        double PP = 1.0;
+        int emin = 1, emax = 1;
+        auto back = [&](const T (&q)[9], const int t, const StreamEntry &e) {
+            const T det = det3<T>(q);
+            const T mn12 = (q[0] * q[1]) - ((q[3] * q[3]) + (q[4] * q[4]));
+            const T mn13 = (q[0] * q[2]) - ((q[5] * q[5]) + (q[6] * q[6]));
+            const T mn23 = (q[1] * q[2]) - ((q[7] * q[7]) + (q[8] * q[8]));
+            const T dmin = fmin(fmin(q[0], q[1]), q[2]);
+            const T mmin = fmin(fmin(mn12, mn13), mn23);
+            // positive semi-definite dates, determinants inside (dlo, dhi): what the rounding bound of the
+            // suffix sums and the range of the products in pass 2 rest on
+            bad = bad | !((dmin > (T)0) & (mmin >= (T)0) & (det > dlo) & (det < dhi));
+            dead = dead | !((det > (T)0) | (det < (T)0));
+            PP = PP * (double)det;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) S[c] += (double)q[c];
+            const int jj = k - t;
+            const double dets = det3<double>(S);
+            const float df = (float)dets;
+            bool okd;
+            int es, eP;
+            float ms, mP;
+            if (sizeof(T) == 4) {
+                okd = df > 7.888609052210118e-31f;
+                log2_parts(df, es, ms);
+            } else {
+                okd = (dets > 0.0) & (dets < (double)INFINITY);
+                log2_parts(dets, es, ms);
+            }
+            log2_parts(PP, eP, mP);
+            emin = eP < emin ? eP : emin;
+            emax = eP > emax ? eP : emax;
+            const int E = (eP - e.re) - __mul24(jj, es);
+            const float x = (float)E + __builtin_fmaf(-e.jf, ms, mP - e.rf);
+            const float qq = (float)((S[0] * S[1]) * S[2]) * __builtin_amdgcn_rcpf(df);
+            const float rel = e.cj * qq;                    // 1.46 (21 n + 20) u abc / D
+            const float m2 = e.mj * rel;
+            bad = bad | !(okd & (rel < 0.01f));
+            mask_push(gF, x + m2 < e.a);
+            mask_push(gC, x - m2 > e.b);
+        };
+        int tb = k - 1;
+        for (; tb >= PF - 1; tb -= PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = tb - u;
+                back(ring[u], t, ss.e[k - t]);
+                load(t >= PF ? t - PF : 0, ring[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb - u;
+            if (t >= 0) back(ring[u], t, ss.e[k - t]);
+        }
+        bad = bad | (emax - emin > 900);
+    }
+    MT gI = mask_undecided(gF, gC);
+    mask_keep_low(gF, k - 1);
+    mask_keep_low(gI, k - 1);
+    if (dead) {                                  // a NaN or zero determinant: no change anywhere, no exact pass
+        bad = false;
+        gF = mask_zero<MT>();
+        gI = mask_zero<MT>();
+    }
+    const unsigned shard = (unsigned)(b % kC3Shards);
+    const int64_t wpx0 = bpx0 + (tid & ~63);
+    const int64_t wleft = g.nx - wpx0;
+    const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
+    uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
+    const bool cand = in && (bad || mask_bit(gF, 0) || mask_bit(gI, 0));
+    const bool dense = __popcll(__ballot(cand)) >= dense_min;
+    bool listed = cand;                          // a sparse wave lists its candidates
+    if (dense) {
+        // ---- pass 2: marginal tests and restarts, dates first to last ----
+        bool handoff = in && bad;
+        bool done = !in || bad || !(mask_bit(gF, 0) || mask_bit(gI, 0));
+        bool pend = !done && mask_bit(gI, 0);
+        int lp = 0;
+        T ps[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ps[c] = (T)0;
+        double PQ = 1.0;
+        MT mask = mask_zero<MT>();
+        T ring[PF][9];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load(u < k ? u : k - 1, ring[u]);
+        T s[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) s[c] = (T)0;
+        double PP = 1.0;
+        int j = 0;
+        auto fwd = [&](const T (&q)[9], const int t) {
+            const bool last = (t == k - 1);
+            const T det = det3<T>(q);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) s[c] = s[c] + q[c];
+            PP = PP * (double)det;
+            j = j + 1;
+            const T dets = det3<T>(s);
+            const bool oks = (dets > (T)0) & (dets < (T)INFINITY);
+            const StreamEntry *ep = tab_lds + j;                 // the lane's own j
+            const int re = ep->re;
+            const float rf = ep->rf, ca = ep->a, cb = ep->b;
+            int es, eP;
+            float ms, mP;
+            log2_parts(dets, es, ms);
+            log2_parts(PP, eP, mP);
+            const int E = (eP - re) - __mul24(j, es);
+            const float x = (float)E + __builtin_fmaf(-(float)j, ms, mP - rf);
+            const bool tested = t > 0;                           // (the first date only starts the state)
+            const bool fires = tested & (last | (oks & (x < ca)));
+            const bool cant = !tested | (!last & oks & (x > cb));
+            const bool act = !done;
+            const bool und = act & !(fires | cant);
+            const bool f = act & fires;
+            handoff = handoff | und;
+            mask_set(mask, t, f);                                // nd/_change.pyx:252
+            const bool gi = mask_bit(gI, t), gf = mask_bit(gF, t);
+            const bool newp = f & !last & gi;                    // an undecided global test starts here
+            handoff = handoff | (newp & pend);
+            done = done | und | (newp & pend) | (f & (last | !(gf | gi)));   // :256, :241-242
+            PQ = PQ * (double)det;
+            const bool startp = newp & !pend;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                ps[c] = ps[c] + q[c];
+                ps[c] = startp ? q[c] : ps[c];
+                s[c] = f ? q[c] : s[c];
+            }
+            PQ = startp ? (double)det : PQ;
+            lp = startp ? t : lp;
+            pend = pend | startp;
+            PP = f ? (double)det : PP;
+            j = f ? 1 : j;
+        };
+        int tb = 0;
+        for (; tb + PF <= k; tb += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = tb + u;
+                fwd(ring[u], t);
+                load(t + PF < k ? t + PF : k - 1, ring[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = tb + u;
+            if (t < k) fwd(ring[u], t);
+        }
+        if (__any(pend)) {
+            // the pending global test over ts[lp:], from the reference's own sums
+            const int jp = k - lp;
+            const T dets = det3<T>(ps);
+            const bool oks = (dets > (T)0) & (dets < (T)INFINITY);
+            const StreamEntry *ep = tab_lds + jp;
+            int es, eP;
+            float ms, mP;
+            log2_parts(dets, es, ms);
+            log2_parts(PQ, eP, mP);
+            const int E = (eP - ep->re) - __mul24(jp, es);
+            const float x = (float)E + __builtin_fmaf(-(float)jp, ms, mP - ep->rf);
+            const bool fires = oks & (x < ep->a);
+            const bool cant = oks & (x > ep->b);
+            if (pend) {
+                if (!(fires | cant)) handoff = true;
+                if (cant) mask_keep_low(mask, lp + 1);       // the search ended at lp (:241-242)
+            }
+        }
+        if (handoff) mask = mask_zero<MT>();                  // pass B writes that pixel's changes
+        if (change_rows_wave_ok(wob, k, wnp)) {
+            store_change_rows_wave(wob, out_img + (tid >> 6) * (16 * kMaxDates), k, mask, lane);
+        } else if (in) {
+            uint8_t *res = wob + (int64_t)lane * k;
+            for (int t = 0; t < k; ++t) res[t] = (uint8_t)(mask_bit(mask, t) ? 1 : 0);
+        }
+        listed = handoff;
+    }
+    if (__any(listed)) {
+        const unsigned long long lm_ = __ballot(listed);
+        unsigned base = 0;
+        if (lane == 0)
+            base = atomicAdd(g.flag_count + shard * kC3CounterStride, (unsigned)__popcll(lm_));
+        base = __shfl(base, 0);
+        if (listed)
+            g.flag_idx[(size_t)shard * g.seg + base + (unsigned)__popcll(lm_ & ((1ull << lane) - 1ull))] =
+                (uint32_t)(row * g.nx + x0);
+    }
+    // a sparse wave zero-fills its own slice of the change map (np.zeros, nd/_change.pyx:275)
+    if (!dense && wnp > 0) {
+        const int nb = wnp * k;
+        int head = (int)((16 - ((uintptr_t)wob & 15)) & 15);
+        if (head > nb) head = nb;
+        if (lane < head) wob[lane] = 0;
+        const int nvec = (nb - head) >> 4;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        u4 *vz = reinterpret_cast<u4 *>(wob + head);
+        const u4 zero = {0u, 0u, 0u, 0u};
+        for (int i = lane; i < nvec; i += 64) vz[i] = zero;
+        const int tail0 = head + (nvec << 4);
+        if (tail0 + lane < nb) wob[tail0 + lane] = 0;
+    }
+}
+
 // ---- pass B ---------------------------------------------------------------------------------
 // LANES: listed pixels per wave.  The LDS image of 64 series of 48 dates is 110 KB: one wave per
 // CU, whose gather (1.13 ms of config 4's share, sector-traffic bound) and search (0.42 ms, latency
@@ -1670,16 +1933,32 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
         // rounding band of the suffix-sum global tests, 3 x 3: 1.46 j (21 n + 20) u abc / D (the kernel's header)
         const float cu3 = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 1.46f;
+        // ND_AMD_C3_FUSED_FORM: 0 the streaming search at every low threshold, 3 the chain search in two
+        // streaming passes at every one; unset: the chain search above alpha = 0.02 (where marginal tests over
+        // four and more dates stop being rare), speed only
+        static const int form_env = [] {
+            const char *e = getenv("ND_AMD_C3_FUSED_FORM");
+            return e ? atoi(e) : -1;
+        }();
+        const bool chain = k >= 3 && (form_env == 3 || (form_env < 0 && alpha > 0.02));
         if (k <= 64) {
             StreamScreen<64> ss = make_stream_screen<T, 64>(htab, scr, (int)k, n_looks);
             for (int j = 0; j <= 64; ++j) ss.e[j].cj = cu3 * (21.f * (float)j + 20.f);
-            hipLaunchKernelGGL((omnibus_c3_stream_kernel<T, 1>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
-                               stream, g, tab, scr, ss, dense_min);
+            if (chain)
+                hipLaunchKernelGGL((omnibus_c3_stream_chain_kernel<T, 1>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
+                                   stream, g, tab, ss, dense_min);
+            else
+                hipLaunchKernelGGL((omnibus_c3_stream_kernel<T, 1>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
+                                   stream, g, tab, scr, ss, dense_min);
         } else {
             StreamScreen<kDenseMax> ss = make_stream_screen<T, kDenseMax>(htab, scr, (int)k, n_looks);
             for (int j = 0; j <= kDenseMax; ++j) ss.e[j].cj = cu3 * (21.f * (float)j + 20.f);
-            hipLaunchKernelGGL((omnibus_c3_stream_kernel<T, 2>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
-                               stream, g, tab, scr, ss, dense_min);
+            if (chain)
+                hipLaunchKernelGGL((omnibus_c3_stream_chain_kernel<T, 2>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
+                                   stream, g, tab, ss, dense_min);
+            else
+                hipLaunchKernelGGL((omnibus_c3_stream_kernel<T, 2>), dim3((unsigned)nblocks), dim3(kC3Threads), 0,
+                                   stream, g, tab, scr, ss, dense_min);
         }
         ND_HIP_CHECK(hipGetLastError());
     }

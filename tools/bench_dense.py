@@ -11,6 +11,9 @@ ap.add_argument('--k', type=int, default=24); ap.add_argument('--ny', type=int, 
 ap.add_argument('--alphas', default='1e-4,0.01,0.5,0.9,0.99'); ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--cpu-rows', type=int, default=4096); ap.add_argument('--dtype', default='f32')
 ap.add_argument('--layouts', default='planar', help="planar and/or pm (the reference's (y, x, time) layout, C12 complex)")
+ap.add_argument('--want-dir', default=None,
+                help='directory of oracle maps shared by several runs on the same stack (the synthesis is seeded): '
+                     'want_<dtype>_<k>_<ny>_<nx>_<rows>_<alpha>.npy is read if present, computed and written otherwise')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 dt_ = torch.float32 if a.dtype == 'f32' else torch.float64
@@ -46,7 +49,16 @@ for layout, alpha in [(l, float(x)) for l in a.layouts.split(',') for x in a.alp
             host = st[:, :, :rows].cpu().numpy()
         planes = [np.moveaxis(host[v], 0, -1) for v in range(4)]
         t0 = time.perf_counter()
-        want = O.change_detection_planes(planes, alpha, 9, njobs=len(os.sched_getaffinity(0)))
+        wf = (os.path.join(a.want_dir, 'want_%s_%d_%d_%d_%d_%r.npy' % (a.dtype, a.k, a.ny, a.nx, rows, alpha))
+              if a.want_dir else None)
+        if wf and os.path.exists(wf):
+            want = np.load(wf)
+        else:
+            want = O.change_detection_planes(planes, alpha, 9, njobs=len(os.sched_getaffinity(0)))
+            if wf:
+                tmp = '%s.%d.tmp.npy' % (wf, os.getpid())
+                np.save(tmp, want)
+                os.replace(tmp, wf)            # (several runs may compute the same map at once: last one wins, all equal)
         res['cpu_s'] = time.perf_counter() - t0
         res['bytes_differing'] = int((out[:rows].cpu().numpy() != want).sum())
         res['compared_px'] = rows * a.nx
