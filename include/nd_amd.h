@@ -154,6 +154,11 @@ int nd_amd_omnibus_c2_ml(const void *c11, const void *c12re, const void *c12im,
  * config "OmnibusTest full-pol C3").  planes[9], all with the same element
  * strides: C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im.
  * Everything else as nd_amd_omnibus_c2; k <= 96.
+ * Workspace: candidate lists plus, for series of up to 64 dates, room for
+ * the series of one pixel in 16 (float32: the sparse regime's pass A hands
+ * the candidates' series to the search from its registers; what does not
+ * fit is gathered from the planes, slower, never wrong): ~ 6.5 % of the
+ * size of a float32 stack.
  * ---------------------------------------------------------------------- */
 size_t nd_amd_omnibus_c3_workspace_bytes(int64_t ny, int64_t nx, int64_t k);
 

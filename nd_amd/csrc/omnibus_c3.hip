@@ -10,11 +10,15 @@
 //
 // Planes (all sharing one set of element strides):
 //   [C11, C22, C33, C12re, C12im, C13re, C13im, C23re, C23im]
-// 1728 B per pixel at k = 48 float32: no register retention; pass A streams the planes in chunks
-// of dates (4-byte non-temporal loads, one pixel per thread, coalesced along x), screens
-// z_approx against the host bound and lists the pixels that can fire; pass B gathers a listed
-// pixel's series (LDS-staged when it fits) and runs the same one-sweep-per-segment search as the
-// dual-pol kernel.  f = 9 (j-1) is odd for even j, so a = f/2 can be a half-integer: the
+// 1728 B per pixel at k = 48 float32: no thread retains that.  Sparse regime (alpha >= 0.75), float32 up
+// to 64 dates (round 6): FOUR WAVES SHARE A PIXEL'S TIME AXIS (omnibus_c3_retain_kernel), screen the
+// re-associated whole-series statistic and dump the candidates' series from their registers; pass B
+// (omnibus_c3_search_dump_kernel) reads the dump one lane per pixel and runs the one-sweep-per-segment
+// search of the dual-pol kernel.  Elsewhere in the sparse regime pass A streams the planes in chunks of
+// dates without retention (omnibus_c3_global_kernel) and pass B gathers a listed pixel's series from the
+// planes (LDS-staged when it fits).  Low thresholds: the search fused into a streaming pass
+// (omnibus_c3_stream_kernel), between 0.02 and the sparse regime the chain search in two streaming passes
+// (omnibus_c3_stream_chain_kernel).  f = 9 (j-1) is odd for even j, so a = f/2 can be a half-integer: the
 // chi-square pair handles both (omnibus_common.hpp).
 #include <type_traits>
 
