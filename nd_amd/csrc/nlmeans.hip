@@ -1571,6 +1571,353 @@ static bool launch_patch_v(const NlmTiledArgs &a, int64_t nslices, size_t lds, h
 }
 
 // Try a tiled form; 1 = launched, 0 = not applicable.
+// ---- patch_mode 1 with a window along the third axis (round 6) ---------------------------------
+// The signed patch distances of a search with an extent along time -- NLMeansFilter(dims=('time', 'y',
+// 'x'), r=(1, 3, 3), f=1), the tutorial's filter (examples/tutorial_s1.ipynb cell 11), in the mode the
+// source text intends (nd/_filters.pyx:363-403) -- ran only in the per-pixel kernel: 146 neighbours x
+// 108 squared differences per pixel, every operand fetched from memory (4 variables, 6 x 1024 x 2048:
+// 152 ms).  Here a block owns a 16-row x (64 - 2 F)-column tile of ONE plane z of the (z, y, x) array:
+//   * the 2 (rz + FZ) + 1 planes around z are staged into LDS for every variable, whole-sample
+//     reflection applied in GLOBAL coordinates on all three axes;
+//   * a thread owns one column and TYW = 4 rows (+ 2 F rows of patch halo) and keeps ITS OWN values of
+//     the 2 FZ + 1 patch planes in registers for the whole search ((TYW + 2 F) (2 FZ + 1) V values);
+//   * per search offset (dz, dy, dx), visited in the reference's order (z outermost): for every row the
+//     squared difference summed over the patch planes and the variables (one LDS read, one subtraction,
+//     one multiply-add per value), the 2 F + 1-wide row sum across lanes (wave shifts, no LDS), the
+//     2 F + 1 row sums of a pixel's patch added down the column: O((2 FZ + 1) V) work per pixel and
+//     offset instead of (2 FZ + 1) (2 F + 1)^2 V;
+//   * weights and weighted sums as in nlmeans_patch_kernel (float32 weight from a float32 distance:
+//     <= ~1e-6 relative, inside the 1e-5 budget of this mode; the weighted sums keep the reference's
+//     order and per-step rounding to float32); pixels with a non-finite value within reach, with all
+//     float32 weights vanishing, or with an ill-conditioned n_eff equation are recomputed one by one in
+//     double, in the reference's order, from the staged planes.
+template <int F, int FZ, int V>
+__device__ __forceinline__ bool nlm_own_patch_nan3(const float *lds, int pz0, int pstride, int vstride, int cols,
+                                                   int py, int px)
+{
+    bool nan = false;
+    for (int z = 0; z < 2 * FZ + 1; ++z)
+        for (int i = -F; i <= F; ++i)
+            for (int j = -F; j <= F; ++j)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float c = lds[(pz0 + z) * pstride + v * vstride + (py + i) * cols + px + j];
+                    nan = nan || (c != c);
+                }
+    return nan;
+}
+
+template <int F>
+__device__ __forceinline__ float nlm_row_sum_lanes(const float e)
+{
+    if (F == 0) return e;
+    float acc = e, up = e, dn = e;
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+        up = dpp_from_prev(up);
+        dn = dpp_from_next(dn);
+        acc = (acc + up) + dn;
+    }
+    return acc;
+}
+
+constexpr int kPatch3TYW = 4, kPatch3TY = 4 * kPatch3TYW;
+constexpr float kPatch3Redo = 1e-2f;      // a pixel whose largest float32 weight is below this: the wave searches again in double
+
+// RMAX: the search radius along rows and columns the tile is laid out for (r0, r1 <= RMAX): the pitches of
+// the staged planes are compile-time constants then, and the (2 FZ + 1) V (TYW + 2 F) reads of a search
+// offset are immediate offsets of three address registers instead of one address computation each.
+template <int F, int FZ, int V, bool NEFF, int RMAX>
+__global__ void __launch_bounds__(256) nlmeans_patch3_kernel(const NlmTiledArgs a)
+{
+    extern __shared__ __align__(16) unsigned char nd_smem_p3[];
+    constexpr int TYW = kPatch3TYW, TY = kPatch3TY, TXO = 64 - 2 * F, NPP = 2 * FZ + 1, NS = TYW + 2 * F;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r0 = a.r0, r1 = a.r1, rz = a.rz;
+    constexpr int cols = 64 + 2 * RMAX, rows = TY + 2 * (RMAX + F);
+    const int np = 2 * (rz + FZ) + 1;                       // staged planes
+    constexpr int vstride = rows * cols, pstride = V * vstride;
+    float *lds = reinterpret_cast<float *>(nd_smem_p3);              // [plane][V][rows][cols]
+    int *ymap = reinterpret_cast<int *>(lds + np * pstride);
+    int *xmap = ymap + rows;
+
+    int64_t b = blockIdx.x;
+    const int tx = (int)(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int ty = (int)(b % a.tiles_y);
+    const int64_t i2 = a.clo2 + b / a.tiles_y;
+    const int64_t y0 = a.clo0 + (int64_t)ty * TY, x0 = a.clo1 + (int64_t)tx * TXO;
+
+    bool nonfinite_here = false;
+    for (int pz = 0; pz < np; ++pz) {
+        int zi = nlm_reflect_i(a.offz + i2 - (rz + FZ) + pz, a.Gz) - (int)a.offz;
+        zi = zi < 0 ? 0 : (zi >= (int)a.N2 ? (int)a.N2 - 1 : zi);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            __syncthreads();
+            nlm_stage(a, lds + pz * pstride + v * vstride, ymap, xmap, rows, cols, a.off0 + y0 - (RMAX + F),
+                      a.off1 + x0 - F - RMAX, zi, v, tid, &nonfinite_here);
+        }
+    }
+    // (any non-finite value in the block's planes: every pixel takes the exact path -- rare, and it spares
+    //  the fast path the bookkeeping of which row sums a NaN or an infinity has entered)
+    const bool block_nonfinite = __syncthreads_or(nonfinite_here ? 1 : 0) != 0;
+
+    // this thread: LDS column `cx`, tile rows wave * TYW - F .. wave * TYW + TYW - 1 + F
+    const int cx = RMAX + lane;
+    const int cy0 = RMAX + F + wave * TYW;           // LDS row of the thread's first OUTPUT row
+    const int pzc = rz + FZ;                         // LDS plane of z itself
+    float P[NS][NPP][V];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+        for (int z = 0; z < NPP; ++z)
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                P[s_][z][v] = lds[(pzc - FZ + z) * pstride + v * vstride + (cy0 - F + s_) * cols + cx];
+
+    double tw[TYW], tsq[NEFF ? TYW : 1];
+    float wmax[TYW];
+    float ws[TYW][V];
+#pragma unroll
+    for (int p_ = 0; p_ < TYW; ++p_) {
+        tw[p_] = 0.0;
+        if (NEFF) tsq[p_] = 0.0;
+        wmax[p_] = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) ws[p_][v] = 0.f;
+    }
+    const float inv_norm = (float)(1.0 / (double)a.dsq_norm);
+    const float neg_inv_h2 = (float)(-1.0 / a.h2);
+    const float two_sigma2 = (float)a.two_sigma2;
+
+    // The search, in two precisions.  DACC = false: the squared differences summed in float32 (a tree of depth
+    // ~16: <= ~1e-6 relative on the distance, i.e. E x 1e-6 on a weight e^-E -- plus the float32 exponent of
+    // __expf -- fine while a pixel's LARGEST weight is not small).  DACC = true: the reference's float32 squares
+    // accumulated in double and the weight's exponent formed in double (split into integer and fraction for the
+    // hardware exp2): ~1e-7 on every weight whatever its size.  A wave in which some pixel's largest float32
+    // weight is below kPatch3Redo searches again in the second form (wave-uniform; about the cost of ONE per-pixel
+    // evaluation in double): pixels next to a x4 step have weights of e^-20 and less, and at E = 69 the float32
+    // form was off by 6e-5 (config 5's share, 5 values of 196 608).
+    auto search = [&](auto dacc_c) {
+        constexpr bool DACC = decltype(dacc_c)::value;
+        const double inv_norm_d = 1.0 / (double)a.dsq_norm;
+        const double neg_inv_h2_log2e = (-1.0 / a.h2) * 1.4426950408889634;
+        for (int dz = -rz; dz <= rz; ++dz)
+            for (int dy = -r0; dy <= r0; ++dy) {
+                const float *qrow = lds + (pzc - FZ + dz) * pstride + (cy0 - F + dy) * cols + cx;
+                for (int dx = -r1; dx <= r1; ++dx) {
+                    if (dz == 0 && dy == 0 && dx == 0) continue;
+                    typename std::conditional<DACC, double, float>::type rs[NS];
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; ++s_) {
+                        if (DACC) {
+                            double e = 0.0;
+#pragma unroll
+                            for (int z = 0; z < NPP; ++z)
+#pragma unroll
+                                for (int v = 0; v < V; ++v) {
+                                    const float df = P[s_][z][v] - qrow[z * pstride + v * vstride + s_ * cols + dx];
+                                    const float sq = df * df;
+                                    e = e + (double)sq;
+                                }
+                            // the row sum across lanes, the two words of the double shifted separately
+                            double acc = e, up = e, dn = e;
+#pragma unroll
+                            for (int j = 0; j < F; ++j) {
+                                const unsigned long long ub = __builtin_bit_cast(unsigned long long, up);
+                                const unsigned long long db = __builtin_bit_cast(unsigned long long, dn);
+                                const unsigned ulo = __builtin_bit_cast(unsigned, dpp_from_prev(__builtin_bit_cast(float, (unsigned)ub)));
+                                const unsigned uhi = __builtin_bit_cast(unsigned, dpp_from_prev(__builtin_bit_cast(float, (unsigned)(ub >> 32))));
+                                const unsigned dlo = __builtin_bit_cast(unsigned, dpp_from_next(__builtin_bit_cast(float, (unsigned)db)));
+                                const unsigned dhi = __builtin_bit_cast(unsigned, dpp_from_next(__builtin_bit_cast(float, (unsigned)(db >> 32))));
+                                up = __builtin_bit_cast(double, ((unsigned long long)uhi << 32) | ulo);
+                                dn = __builtin_bit_cast(double, ((unsigned long long)dhi << 32) | dlo);
+                                acc = (acc + up) + dn;
+                            }
+                            rs[s_] = acc;
+                        } else {
+                            float e = 0.f;
+#pragma unroll
+                            for (int z = 0; z < NPP; ++z)
+#pragma unroll
+                                for (int v = 0; v < V; ++v) {
+                                    const float df = P[s_][z][v] - qrow[z * pstride + v * vstride + s_ * cols + dx];
+                                    e = e + df * df;
+                                }
+                            rs[s_] = nlm_row_sum_lanes<F>(e);
+                        }
+                    }
+#pragma unroll
+                    for (int p_ = 0; p_ < TYW; ++p_) {
+                        auto D = rs[p_];
+#pragma unroll
+                        for (int j = 1; j <= 2 * F; ++j) D = D + rs[p_ + j];
+                        float w;
+                        if (DACC) {
+                            const double t = (D * inv_norm_d) - a.two_sigma2;
+                            const double m = (0.0 > t) ? 0.0 : t;
+                            const double xe = m * neg_inv_h2_log2e;               // log2 of the weight, <= 0
+                            const double xn = rint(xe);
+                            const float fr = (float)(xe - xn);                    // in [-0.5, 0.5], exact enough
+                            const float wn = __builtin_amdgcn_exp2f(fr);
+                            w = xn < -200.0 ? 0.f : ldexpf(wn, (int)xn);
+                        } else {
+                            const float d2 = D * inv_norm;
+                            const float t = d2 - two_sigma2;
+                            const float m = (0.f > t) ? 0.f : t;
+                            w = __expf(m * neg_inv_h2);
+                        }
+                        tw[p_] = tw[p_] + (double)w;
+                        if (NEFF) tsq[p_] = tsq[p_] + (double)w * (double)w;
+                        wmax[p_] = w > wmax[p_] ? w : wmax[p_];
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            // (float)((double)ws + (double)w * (double)a): the product of two floats is exact
+                            // in double, so the single-rounding fused multiply-add gives the same value
+                            const float av = qrow[FZ * pstride + v * vstride + (F + p_) * cols + dx];
+                            ws[p_][v] = __fmaf_rn(w, av, ws[p_][v]);
+                        }
+                    }
+                }
+            }
+    };
+    if (!block_nonfinite) {
+        search(std::integral_constant<bool, false>());
+        bool small = false;
+#pragma unroll
+        for (int p_ = 0; p_ < TYW; ++p_) small = small || (wmax[p_] < kPatch3Redo);
+        if (__any(small)) {
+#pragma unroll
+            for (int p_ = 0; p_ < TYW; ++p_) {
+                tw[p_] = 0.0;
+                if (NEFF) tsq[p_] = 0.0;
+                wmax[p_] = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) ws[p_][v] = 0.f;
+            }
+            search(std::integral_constant<bool, true>());
+        }
+    }
+
+    const int64_t x = x0 - F + lane;
+    const bool col_out = lane >= F && lane < 64 - F && x < a.chi1;
+    unsigned exact_mask = 0;
+#pragma unroll
+    for (int p_ = 0; p_ < TYW; ++p_) {
+        const int64_t y = y0 + wave * TYW + p_;
+        if (y < a.chi0 && col_out) {
+            if (block_nonfinite || !(wmax[p_] >= 1e-30f) ||
+                (NEFF && nlm_neff_ill(tw[p_], NEFF ? tsq[p_] : 0.0, a.n_eff))) {
+                exact_mask |= 1u << p_;
+                continue;
+            }
+            bool fail;
+            const double wself = nlm_self_weight(tw[p_], NEFF ? tsq[p_] : 0.0, (double)wmax[p_], a.n_eff,
+                                                 a.neff_policy, a.status, &fail);
+            if (!fail) {
+                const double total = tw[p_] + wself;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float c = P[F + p_][FZ][v];
+                    const float sfin = (float)((double)ws[p_][v] + (wself * (double)c));
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] = (float)((double)sfin / total);
+                }
+            }
+        }
+    }
+    if (__any(exact_mask != 0u)) {
+        for (int p_ = 0; p_ < TYW; ++p_) {
+            if (!((exact_mask >> p_) & 1u)) continue;
+            // nd/_filters.pyx:363-420 for this one pixel, from the staged planes, in double
+            const int py = cy0 + p_;
+            const int64_t y = y0 + wave * TYW + p_;
+            if (!(a.n_eff >= 0 && (a.n_eff - 1.0) == 0) &&
+                nlm_own_patch_nan3<F, FZ, V>(lds, pzc - FZ, pstride, vstride, cols, py, cx)) {
+                // a NaN in the pixel's own patch: every distance, weight and sum is NaN (nd/_filters.pyx:386-420)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] = __builtin_nanf("");
+                continue;
+            }
+            double t_w = 0.0, t_sq = 0.0, m_w = 0.0;
+            float wsum[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) wsum[v] = 0.f;
+            for (int dz = -rz; dz <= rz; ++dz)
+                for (int dy = -r0; dy <= r0; ++dy)
+                    for (int dx = -r1; dx <= r1; ++dx) {
+                        if (dz == 0 && dy == 0 && dx == 0) continue;
+                        double dsq = 0.0;
+                        for (int z = -FZ; z <= FZ; ++z)
+                            for (int i = -F; i <= F; ++i)
+                                for (int j = -F; j <= F; ++j)
+#pragma unroll
+                                    for (int v = 0; v < V; ++v) {
+                                        const float *pb = lds + (pzc + z) * pstride + v * vstride;
+                                        const float *qb = lds + (pzc + z + dz) * pstride + v * vstride;
+                                        const float df = pb[(py + i) * cols + cx + j] - qb[(py + dy + i) * cols + cx + dx + j];
+                                        const float sq = df * df;
+                                        dsq = dsq + (double)sq;
+                                    }
+                        dsq = dsq / (double)a.dsq_norm;
+                        const double t = dsq - a.two_sigma2;
+                        const double m = (0.0 > t) ? 0.0 : t;
+                        const double w = exp((-m) / a.h2);
+                        t_w = t_w + w;
+                        t_sq = t_sq + (w * w);
+                        if (w > m_w) m_w = w;
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+                            wsum[v] = (float)((double)wsum[v] +
+                                              (w * (double)lds[(pzc + dz) * pstride + v * vstride + (py + dy) * cols + cx + dx]));
+                    }
+            bool fail;
+            const double wself = nlm_self_weight(t_w, t_sq, m_w, a.n_eff, a.neff_policy, a.status, &fail);
+            if (!fail) {
+                const double total = t_w + wself;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float c = lds[pzc * pstride + v * vstride + py * cols + cx];
+                    const float sfin = (float)((double)wsum[v] + (wself * (double)c));
+                    a.out[i2 * a.so2 + (int64_t)v * a.so3 + y * a.so0 + x] = (float)((double)sfin / total);
+                }
+            }
+        }
+    }
+}
+
+constexpr int kPatch3RMax = 4;
+
+template <int F, int FZ, int V>
+static int launch_patch3(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
+{
+    if (a.n_eff >= 0) {
+        if (lds > 64 * 1024)
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&nlmeans_patch3_kernel<F, FZ, V, true, kPatch3RMax>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((nlmeans_patch3_kernel<F, FZ, V, true, kPatch3RMax>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+    } else {
+        if (lds > 64 * 1024)
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&nlmeans_patch3_kernel<F, FZ, V, false, kPatch3RMax>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((nlmeans_patch3_kernel<F, FZ, V, false, kPatch3RMax>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+    }
+    return ND_AMD_OK;
+}
+
+template <int F, int FZ>
+static int launch_patch3_v(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
+{
+    switch (a.nvars) {
+    case 1: return launch_patch3<F, FZ, 1>(a, nb, lds, stream);
+    case 2: return launch_patch3<F, FZ, 2>(a, nb, lds, stream);
+    case 3: return launch_patch3<F, FZ, 3>(a, nb, lds, stream);
+    default: return launch_patch3<F, FZ, 4>(a, nb, lds, stream);
+    }
+}
+
 static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[3], int64_t nvars,
                          const int64_t si[4], const int64_t so[4], const uint32_t r[3],
                          const uint32_t f[3], double sigma, double h, double n_eff, int patch_mode,
@@ -1684,9 +2031,35 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
             hipLaunchKernelGGL((nlmeans_window_kernel<float, 16>), dim3((unsigned)nb), dim3(256), lds, stream, a);
         return 1;
     }
-    // true patch distances (patch_mode 1, or f = 0 in either mode: the loops run once); the third
-    // axis must be a plain slice axis here
-    if (rz != 0 || fz != 0) return 0;
+    // true patch distances (patch_mode 1, or f = 0 in either mode: the loops run once)
+    if (rz != 0 || fz != 0) {
+        // a window along the third axis (round 6): nlmeans_patch3_kernel -- the visiting order is the
+        // reference's only where that axis is the outermost filter dimension (layout B)
+        static const bool no_patch3 = getenv("ND_AMD_NLM_NOPATCH3") != nullptr;
+        const uint32_t F0z = (patch_mode == 1) ? f[A0] : 0u, F1z = (patch_mode == 1) ? f[A1] : 0u;
+        const uint32_t FZz = (patch_mode == 1) ? fz : 0u;
+        if (no_patch3 || A2 != 0 || f64 || nvars > 4) return 0;
+        if (patch_mode == 0 && (f[A0] != 0 || f[A1] != 0 || fz != 0)) return 0;
+        if (F0z != F1z || F0z > 2 || FZz > 1 || rz > 2 || a.r0 > kPatch3RMax || a.r1 > kPatch3RMax) return 0;
+        const int Fp = (int)F0z;
+        const size_t cols3 = 64 + 2 * (size_t)kPatch3RMax, rows3 = kPatch3TY + 2 * (size_t)(kPatch3RMax + Fp);
+        const size_t np3 = 2 * (size_t)(rz + FZz) + 1;
+        const size_t lds3 = np3 * (size_t)nvars * rows3 * cols3 * sizeof(float) + (rows3 + cols3) * sizeof(int);
+        a.tiles_x = (int)ceil_div(ex, 64 - 2 * Fp);
+        a.tiles_y = (int)ceil_div(ey, kPatch3TY);
+        const int64_t nb3 = (int64_t)a.tiles_x * a.tiles_y * nsl;
+        if (lds3 > kBigLds || nb3 > 0x7fffffffLL) return 0;
+        KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
+        int rc3 = ND_AMD_OK;
+        if (Fp == 0 && FZz == 0) rc3 = launch_patch3_v<0, 0>(a, nb3, lds3, stream);
+        else if (Fp == 1 && FZz == 0) rc3 = launch_patch3_v<1, 0>(a, nb3, lds3, stream);
+        else if (Fp == 1 && FZz == 1) rc3 = launch_patch3_v<1, 1>(a, nb3, lds3, stream);
+        else if (Fp == 2 && FZz == 0) rc3 = launch_patch3_v<2, 0>(a, nb3, lds3, stream);
+        else if (Fp == 2 && FZz == 1) rc3 = launch_patch3_v<2, 1>(a, nb3, lds3, stream);
+        else if (Fp == 0 && FZz == 1) rc3 = launch_patch3_v<0, 1>(a, nb3, lds3, stream);
+        else return 0;
+        return rc3 == ND_AMD_OK ? 1 : 0;
+    }
     const uint32_t F0 = (patch_mode == 1) ? f[A0] : 0u, F1 = (patch_mode == 1) ? f[A1] : 0u;
     if (patch_mode == 0 && (f[A0] != 0 || f[A1] != 0)) return 0;
     if (F0 != F1 || F0 > 3 || nvars > 4) return 0;

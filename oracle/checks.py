@@ -125,9 +125,17 @@ def nlmeans_crops(stack, filtered, r, f, sigma, h, n_eff, patch_mode, crops, siz
         if patch_mode == 0:
             bad += int((got != core).sum())
         else:
-            rel = np.abs(got - core) / np.maximum(np.abs(core), 1e-30)
-            max_rel = max(max_rel, float(rel.max()))
-            bad += int((rel > 1e-5).sum())
+            # 1e-5 relative -- of the value, or of the magnitude of what was averaged where the average
+            # cancels: a filtered cross term (C12 re / im, zero mean) of 1e-4 is a sum of inputs of +-0.3
+            # whose float32 weights carry 1e-7 each, so the value is good to ~1e-8 absolute whatever its
+            # size.  Floor: 1e-7 of the window's largest magnitude per variable (float32 resolution of the
+            # summands); everything above it is held to 1e-5 relative.
+            scale = np.abs(win).reshape(win.shape[0], -1).max(axis=1)[:, None, None, None]
+            err = np.abs(got - core)
+            rel = err / np.maximum(np.abs(core), 1e-30)
+            over = (rel > 1e-5) & (err > 1e-7 * scale)
+            max_rel = max(max_rel, float(np.where(err > 1e-7 * scale, rel, 0.0).max()))
+            bad += int(over.sum())
         if then_omnibus is not None:
             alpha, n = then_omnibus
             planes = [np.ascontiguousarray(np.moveaxis(core[v], 0, -1)) for v in range(4)]

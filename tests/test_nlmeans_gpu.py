@@ -356,3 +356,55 @@ def test_one_column_patch_kernel_forced(tmp_path):
     log = (tmp_path / 'log').read_text()
     assert p.returncode == 0, log[-3000:]
     assert ' passed' in log and 'failed' not in log, log[-1000:]
+
+
+@pytest.mark.parametrize('case', [
+    # (nvars, k, ny, nx, r, f, sigma, h, n_eff)
+    (4, 6, 45, 150, (1, 3, 3), (1, 1, 1), 0.5, 0.5, -1),       # the tutorial's window, 4 variables
+    (4, 5, 40, 131, (1, 3, 3), (1, 1, 1), 0.5, 0.5, 30.0),     # ... with n_eff (find_weight)
+    (1, 7, 37, 200, (2, 4, 4), (1, 1, 1), 0.3, 0.4, -1),       # two dates either side, radius 4
+    (2, 4, 33, 90, (1, 2, 2), (0, 1, 1), 0.4, 0.5, -1),        # no patch extent along time
+    (3, 5, 50, 70, (1, 3, 3), (1, 2, 2), 0.5, 0.6, -1),        # 5 x 5 x 3 patches (3 variables: the image fits)
+    (2, 4, 20, 64, (1, 1, 1), (1, 0, 0), 0.4, 0.5, -1),        # patch along time only
+])
+def test_signed_mode_search_along_time_tiled_kernel(oracle, device, case):
+    """patch_mode 1 with a search (and patch) extent along time on (time, y, x) arrays: nlmeans_patch3_kernel
+    (staged planes, the thread's own patch values in registers, cross-lane row sums) against the oracle's
+    double arithmetic, 1e-5 relative -- ragged tiles, several variables, n_eff, NaN / inf / zero nodata, and a
+    row tile with halo in global coordinates (nd/_filters.pyx:363-420)."""
+    import torch
+    from nd_amd import kernels
+    nv, k, ny, nx, r, f, sigma, h, ne = case
+    rng = np.random.default_rng(nv * 100 + k)
+    a = rng.gamma(4.0, 0.25, size=(k, ny, nx, nv)).astype(np.float32)
+    a[2, 5:9, 20:30, :] *= 6.0                                  # a bright block: tiny weights around it
+    for label, arr in (('plain', a), ('nodata', None)):
+        if arr is None:
+            arr = a.copy()
+            arr[:, 0:6, 0:40, :] = np.nan                       # a NaN margin
+            arr[1, min(20, ny - 1), 50, 0] = np.inf
+            arr[:, 30:33, 100:120, :] = 0.0
+        want = np.empty_like(arr)
+        with np.errstate(all='ignore'):
+            oracle.pixelwise_nlmeans_3d(arr, want, r, f, sigma, h, ne, neff_policy=0, njobs=8, patch_mode=1)
+        planar = torch.from_numpy(np.ascontiguousarray(np.transpose(arr, (3, 0, 1, 2)))).to(device)   # (v, t, y, x)
+        out = torch.empty_like(planar)
+        kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, sigma, h, ne,
+                                     patch_mode=1, neff_policy=0)
+        torch.cuda.synchronize()
+        got = np.transpose(out.cpu().numpy(), (1, 2, 3, 0))
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-30, equal_nan=True, err_msg=label)
+    # a row tile with its halo, reflection in GLOBAL coordinates: rows [c0, c1) of the raster
+    halo = r[1] + f[1]
+    c0, c1 = ny // 3, min(ny // 3 + 18, ny)
+    lo, hi = max(c0 - halo, 0), min(c1 + halo, ny)
+    tile = torch.from_numpy(np.ascontiguousarray(np.transpose(a[:, lo:hi], (3, 0, 1, 2)))).to(device)
+    tout = torch.zeros_like(tile)
+    kernels.pixelwise_nlmeans_3d(tile.permute(1, 2, 3, 0), tout.permute(1, 2, 3, 0), r, f, sigma, h, ne,
+                                 patch_mode=1, neff_policy=0, global_shape=(k, ny, nx), tile_offset=(0, lo, 0),
+                                 core=((0, k), (c0 - lo, c1 - lo), (0, nx)))
+    torch.cuda.synchronize()
+    want = np.empty_like(a)
+    oracle.pixelwise_nlmeans_3d(a, want, r, f, sigma, h, ne, neff_policy=0, njobs=8, patch_mode=1)
+    got = np.transpose(tout.cpu().numpy(), (1, 2, 3, 0))[:, c0 - lo:c1 - lo]
+    np.testing.assert_allclose(got, want[:, c0:c1], rtol=1e-5, atol=1e-30, equal_nan=True)
