@@ -51,7 +51,7 @@ PER_FILE = {'nlmeans.hip': ['-fno-slp-vectorize'] + os.environ.get('ND_AMD_NLM_F
 # and statistics forms are known to spill in their tails (bytes per lane) otherwise.
 NO_SCRATCH = {'omnibus_ml.hip': 'omnibus_c2_ml_kernel'}
 # bytes per lane by the kernel's template arguments <K, KMAX, STATS, CHAIN>, keyed (STATS, CHAIN)
-SCRATCH_BUDGET = {(False, False): 0, (False, True): 96, (True, False): 256}
+SCRATCH_BUDGET = {(False, False): 0, (False, True): 96, (True, False): 256, (True, True): 384}
 
 
 def _template_bools(mangled, symbol):

@@ -1332,6 +1332,34 @@ omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Stre
     const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
     uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
 
+    // STATS: the reference's forward fold of the whole series IN FRONT of the search -- its result is six
+    // registers carried through the search (four sums, the double product), while the logarithms and the
+    // chi-square series behind the search then run with the series itself dead.  (Round 4 had the fold behind
+    // the search as well: the series stayed alive into the chi-square code, 140 bytes per lane spilled --
+    // 41 scratch operations in the 24-date float32 instantiation.)
+    // The fold's result waits in LDS (this thread's own five words, no barrier): carried in registers it cost
+    // the search its last free ones (the 24-date float32 form is held to three waves per SIMD: 88 scratch
+    // operations).
+    __shared__ T stat_s[STATS ? 4 : 1][kRetainThreads];
+    __shared__ double stat_p[STATS ? kRetainThreads : 1];
+    if (STATS) {
+        Accum<T> Aw;
+        Aw.reset();
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t)
+            if (EXACT || t < k) {
+                // (opaque to the optimiser: it would otherwise share these determinants with the search's
+                //  first pass and keep all of them alive in between)
+                T a0 = v[t][0];
+                if (sizeof(T) == 4) asm volatile("" : "+v"(a0));      // (float64, 24 dates: 288 instead of 108 bytes spilled with it)
+                Aw.step(a0, v[t][1], v[t][2], v[t][3]);
+            }
+        stat_s[0][tid] = Aw.s11;
+        stat_s[1][tid] = Aw.s12r;
+        stat_s[2][tid] = Aw.s12i;
+        stat_s[3][tid] = Aw.s22;
+        stat_p[tid] = Aw.prod;
+    }
     // ---- the search; a wave with few candidates lists them for pass B instead of using it ----
     MT mask;
     bool handoff, cand;
@@ -1393,12 +1421,13 @@ omnibus_c2_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Stre
     // chi-square series' registers pushed the 24-date form over the cap of three waves per SIMD)
     __builtin_amdgcn_sched_barrier(0);
     if (STATS) {
-        Accum<T> A;
-        A.reset();
-#pragma unroll
-        for (int t = 0; t < KMAX; ++t)
-            if (EXACT || t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
-        const T z = z_stat<T>(A, k, g.nlooks, g.e);
+        Accum<T> Aw;
+        Aw.s11 = stat_s[0][tid];
+        Aw.s12r = stat_s[1][tid];
+        Aw.s12i = stat_s[2][tid];
+        Aw.s22 = stat_s[3][tid];
+        Aw.prod = stat_p[tid];
+        const T z = z_stat<T>(Aw, k, g.nlooks, g.e);
         double zd[1] = {(double)z}, P1[1], P2[1];
         chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
         const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
@@ -2092,7 +2121,14 @@ omnibus_c2_stream_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
 // several times the streaming pass itself (48 x 2048 x 4096, alpha = 0.2: 6.6 ms).  Twice the
 // traffic of the one-pass forms: the choice for these thresholds only.
 // -----------------------------------------------------------------------------------------
-template <typename T, int PF, int MODE, int MW>
+// STATS (round 6): the z / P rasters of the whole-series test from the SAME two passes -- the second pass
+// walks the dates first to last anyway, so it carries the reference's forward fold of the whole series
+// (nd/_change.pyx:53-77: four sums in `floating`, the double product) next to the running state of the
+// current segment, five additions and a multiplication per date; every wave then takes the second pass.
+// (Up to round 5 a plain pass A of its own produced the rasters in front of the search: a third read of the
+// stack -- 96 dates x 2048 x 4096: + 2.3 ms.  The one-pass streaming search cannot do this: it walks the
+// dates last to first, and the reference's forward float32 sums cannot be formed backwards.)
+template <typename T, int PF, int MODE, int MW, bool STATS = false>
 __global__ void __launch_bounds__(kRetainThreads)
 omnibus_c2_stream_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const StreamScreen<stream_nj(MW)> ss)
 {
@@ -2216,7 +2252,7 @@ omnibus_c2_stream_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, con
     const int wnp = wleft > 64 ? 64 : (wleft > 0 ? (int)wleft : 0);
     uint8_t *wob = g.change + (row * g.nx + wpx0) * (int64_t)k;
     const bool cand = in && (bad || mask_bit(gF, 0) || mask_bit(gI, 0));
-    const bool dense = __popcll(__ballot(cand)) >= g.dense_min;
+    const bool dense = STATS || __popcll(__ballot(cand)) >= g.dense_min;
     bool listed = cand;
     if (dense) {
         // ---- pass 2: marginal tests and restarts, dates first to last ----
@@ -2240,9 +2276,12 @@ omnibus_c2_stream_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, con
         T s11 = (T)0, s12r = (T)0, s12i = (T)0, s22 = (T)0;
         double PP = 1.0;
         int j = 0;
+        Accum<T> W;                                              // STATS: the whole series, never restarted
+        W.reset();
         auto fwd = [&](const DateVal<T> &q, const int t) {
             const bool last = (t == k - 1);
             const T det = (q.a * q.d) - ((q.b * q.b) + (q.c * q.c));
+            if (STATS) W.step(q.a, q.b, q.c, q.d);
             s11 = s11 + q.a;
             s12r = s12r + q.b;
             s12i = s12i + q.c;
@@ -2334,6 +2373,17 @@ omnibus_c2_stream_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, con
             for (int t = 0; t < k; ++t) res[t] = (uint8_t)(mask_bit(mask, t) ? 1 : 0);
         }
         listed = handoff;
+        if (STATS) {
+            const T z = z_stat<T>(W, k, g.nlooks, g.e);
+            double zd[1] = {(double)z}, P1[1], P2[1];
+            chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
+            const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+            if (in) {
+                const int64_t pix = row * g.nx + x0;
+                if (g.z_out) g.z_out[pix] = z;
+                if (g.p_out) g.p_out[pix] = P;
+            }
+        }
     }
     if (__any(listed)) {
         const unsigned long long lm_ = __ballot(listed);
@@ -3183,7 +3233,16 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     const bool ml_chain = mlp != nullptr && k >= 2 && dense_env <= 64 && alpha < fused_alpha_regs;
     // z / P rasters asked for on top: they come from one launch of the plain pass A (which
     // evaluates the whole-series test of every pixel anyway), the map from the streaming search
-    const bool stats_split = stream_long && stats;
+    // ND_AMD_STATS_SPLIT=1: the rasters from a pass of their own in front of every fused search, as before round 6
+    static const bool stats_split_env0 = [] {
+        const char *e = getenv("ND_AMD_STATS_SPLIT");
+        return e ? atoi(e) != 0 : false;
+    }();
+    // (round 6) with rasters, a long series takes the chain form at EVERY low threshold -- in registers (float64,
+    // 17 .. 24 dates) or in two streaming passes -- whose forward pass carries the whole-series fold: no separate
+    // read for the rasters
+    const bool stats_long_chain = stream_long && stats && !stats_split_env0 && k >= 3;
+    const bool stats_split = stream_long && stats && !stats_long_chain;
     // (round 6) the sparse regime beyond the register-retaining lengths: the time-split pass A hands the
     // candidates' series to pass B from its registers (omnibus_c2_split_kernel).  ND_AMD_C2_SPLIT=0: the
     // plain pass A and the gather, as before.
@@ -3494,7 +3553,10 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 return ND_AMD_EWORKSPACE;
             }
             if (ml_chain) {
-                if (stats) {            // the rasters from a pass of their own, the map from the fused search
+                // (round 6) the rasters from the fused kernel itself: the multilooked series is still in its
+                // registers behind the search; ND_AMD_STATS_SPLIT=1: from a pass of their own, as before
+                const bool stats_here = stats && !stats_split_env0;
+                if (stats && !stats_here) {
                     KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
                     const int rc = launch_ml_pass_a(g, tab, *mlp, nullptr, true, false, stream);
                     if (rc != ND_AMD_OK) return rc;
@@ -3504,7 +3566,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 const DenseScreen scr = make_dense_screen<T>(htab, (int)k, n_looks);
                 const StreamScreen<32> ss0 = make_stream_screen<T, 32>(htab, scr, (int)k, n_looks);
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_FUSED, stream);
-                const int rc = launch_ml_pass_a(g, tab, *mlp, &ss0, false, true, stream);
+                const int rc = launch_ml_pass_a(g, tab, *mlp, &ss0, stats_here, true, stream);
                 if (rc != ND_AMD_OK) return rc;
             } else {
                 KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
@@ -3837,21 +3899,31 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             // chain form.  (33 .. 48 float32 dates: that instantiation spilled 2 KB per lane under the
             // 256-register cap of two waves per SIMD and was no faster than the streaming search with
             // its deep searches -- 6.9 against 6.6 ms at alpha = 0.2 on 48 x 2048 x 4096; deleted in round 4.)
-            if (retain && sizeof(T) == 8 && (fused_form_long == 2 || (fused_form_long < 0 && alpha > 0.02))) {
-                launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream);
-            } else if (fused_form_long == 3 || (fused_form_long < 0 && alpha > 0.02)) {
+            if (retain && sizeof(T) == 8 && (stats_long_chain || fused_form_long == 2 || (fused_form_long < 0 && alpha > 0.02))) {
+                launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream, stats_long_chain);
+            } else if (stats_long_chain || fused_form_long == 3 || (fused_form_long < 0 && alpha > 0.02)) {
                 // longer series between the streaming search's thresholds and the sparse regime: the
                 // chain search in two streaming passes (ND_AMD_FUSED_FORM=3 forces it, 0 the one-pass form)
+#define ND_LAUNCH_SCHAIN(MODE_, MW_, NJ_)                                                                         \
+    do {                                                                                                          \
+        if (stats_long_chain)                                                                                     \
+            hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, MODE_, MW_, true>), grid, block, 0, stream, g, tab, \
+                               make_stream_screen<T, NJ_>(htab, scr, (int)k, n_looks));                           \
+        else                                                                                                      \
+            hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, MODE_, MW_, false>), grid, block, 0, stream, g, tab, \
+                               make_stream_screen<T, NJ_>(htab, scr, (int)k, n_looks));                           \
+    } while (0)
                 if (k <= 32) {
-                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));
-                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 0>), grid, block, 0, stream, g, tab, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));
+                    if (buf) ND_LAUNCH_SCHAIN(1, 0, 32);
+                    else ND_LAUNCH_SCHAIN(0, 0, 32);
                 } else if (k <= 64) {
-                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 1>), grid, block, 0, stream, g, tab, make_stream_screen<T, 64>(htab, scr, (int)k, n_looks));
-                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 1>), grid, block, 0, stream, g, tab, make_stream_screen<T, 64>(htab, scr, (int)k, n_looks));
+                    if (buf) ND_LAUNCH_SCHAIN(1, 1, 64);
+                    else ND_LAUNCH_SCHAIN(0, 1, 64);
                 } else {
-                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 2>), grid, block, 0, stream, g, tab, make_stream_screen<T, 128>(htab, scr, (int)k, n_looks));
-                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 2>), grid, block, 0, stream, g, tab, make_stream_screen<T, 128>(htab, scr, (int)k, n_looks));
+                    if (buf) ND_LAUNCH_SCHAIN(1, 2, 128);
+                    else ND_LAUNCH_SCHAIN(0, 2, 128);
                 }
+#undef ND_LAUNCH_SCHAIN
             } else
             if (k <= 32) {
                 if (buf) hipLaunchKernelGGL((omnibus_c2_stream_kernel<T, PF, 1, 0>), grid, block, 0, stream, g, tab, nopm, make_stream_screen<T, 32>(htab, scr, (int)k, n_looks));

@@ -508,6 +508,23 @@ omnibus_c2_ml_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const Omn
             dense_chain<float, KMAX, 32>(v, ks, in, ss, tab_lds, mask, handoff, cand);
             dense = true;
             if (handoff) mask = 0u;                              // pass B writes that pixel's changes
+            if (STATS) {
+                // (round 6) the z / P rasters from the series the search just walked: the reference's forward fold
+                // (nd/_change.pyx:53-77) and the chi-square pair (the same evaluation as every other form: the rasters are bit-identical whichever kernel writes them)
+                Accum<float> A;
+                A.reset();
+#pragma unroll
+                for (int t = 0; t < KMAX; ++t)
+                    if (t < k) A.step(v[t][0], v[t][1], v[t][2], v[t][3]);
+                const float z = z_stat<float>(A, k, g.nlooks, g.e);
+                double zd[1] = {(double)z}, P1[1], P2[1];
+                chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
+                const float P = combine_P<float>(P1[0], P2[0], g.e.omega2);
+                if (in) {
+                    if (g.z_out) g.z_out[pix] = z;
+                    if (g.p_out) g.p_out[pix] = P;
+                }
+            }
             if (wnp > 0) {
                 if ((k & 3) == 0) {
                     // (the wave's rows of the result area are its own until the next step's barrier)
@@ -624,7 +641,9 @@ static int launch_ml_k(const OmniGlobalArgs<float> &g, const OmniTab &tab, const
         hipLaunchKernelGGL((omnibus_c2_ml_kernel<K, KMAX, STATS_, CHAIN_>), grid, block, lds, stream, g, tab, a, \
                            ss ? *ss : none);                                                                  \
     } while (0)
-    if (ss)
+    if (ss && stats)
+        ND_ML_LAUNCH(true, true);
+    else if (ss)
         ND_ML_LAUNCH(false, true);
     else if (stats)
         ND_ML_LAUNCH(true, false);

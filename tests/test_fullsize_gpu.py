@@ -309,7 +309,8 @@ def test_long_series_statistics_at_scale(oracle, dtype, k):
     """Series beyond the register forms on a raster large enough for the device-side density gate:
     the map of the streaming search (64- / 128-bit masks) equals the oracle on sampled pixels and
     whole rows, asking for the z / P rasters does not change it, and the rasters themselves do not
-    depend on the threshold (they come from the plain pass A in both regimes)."""
+    depend on the threshold, bit for bit (the chain form's forward pass below the sparse regime, the plain
+    pass A in it: the same fold and the same chi-square evaluation)."""
     import torch
     from nd_amd import kernels, synth as dsynth
     from oracle import checks
@@ -333,8 +334,12 @@ import hashlib, sys, torch
 sys.path.insert(0, %r)
 from nd_amd import kernels, synth
 dev = torch.device('cuda:0')
-for k, dt in ((24, torch.float32), (16, torch.float32), (12, torch.float64)):
-    st = synth.wishart_c2_stack(k, 1536, 2048, looks=9, seed=40 + k, device=dev, change_frac=0.02).to(dt)
+for k, dt in ((24, torch.float32), (16, torch.float32), (12, torch.float64),
+              # (round 6) long series: the rasters from the chain form -- in registers for 17 .. 24 float64 dates,
+              # in two streaming passes beyond -- at every low threshold
+              (24, torch.float64), (40, torch.float32), (96, torch.float32), (40, torch.float64)):
+    ny = 1536 if k <= 40 else 512
+    st = synth.wishart_c2_stack(k, ny, 2048, looks=9, seed=40 + k, device=dev, change_frac=0.02).to(dt)
     for alpha in (1e-4, 0.01, 0.3):
         ch, z, P = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9, stats=True)
         ch0 = kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)
@@ -343,12 +348,26 @@ for k, dt in ((24, torch.float32), (16, torch.float32), (12, torch.float64)):
         for t in (ch, z, P):
             h.update(t.cpu().numpy().tobytes())
         print('RASTERS', k, str(dt), alpha, h.hexdigest())
+    del st
+# the fused multilooking kernel: rasters from the kernel itself against the separate pass
+st = synth.wishart_c2_stack(12, 768, 2048, looks=4, seed=77, device=dev, change_frac=0.02)
+for ml in (3, 5):
+    for alpha in (0.01, 0.3):
+        ch, z, P = kernels.change_detection_multilooked(st[0], st[1], st[2], st[3], alpha=alpha, ml=ml, stats=True)
+        ch0 = kernels.change_detection_multilooked(st[0], st[1], st[2], st[3], alpha=alpha, ml=ml)
+        assert torch.equal(ch, ch0)
+        h = hashlib.sha1()
+        for t in (ch, z, P):
+            h.update(t.cpu().numpy().tobytes())
+        print('RASTERS ml', ml, alpha, h.hexdigest())
 '''
 
 
 def test_rasters_from_chain_form_equal_separate_pass():
-    """Below the sparse regime the z / P rasters come from the chain form's retained series (round 4: one
-    read of the planes); ND_AMD_STATS_SPLIT=1 restores the separate pass A in front of the search.  Both give
+    """Below the sparse regime the z / P rasters come from the chain form -- its retained series (round 4), for
+    long series the forward pass of its two streaming passes, and the fused multilooking kernel's retained
+    multilooked series (round 6): no separate read of the planes; ND_AMD_STATS_SPLIT=1 restores the separate
+    pass A in front of the search.  Both give
     the same map and bit-identical rasters, at the thresholds of the streaming and of the chain form, on a
     raster large enough for the device-side density gate (each mode in a fresh process: the switch is read
     once)."""
@@ -363,7 +382,7 @@ def test_rasters_from_chain_form_equal_separate_pass():
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith('RASTERS')])
-    assert len(outs[0]) == 9 and outs[0] == outs[1], (outs[0], outs[1])
+    assert len(outs[0]) == 25 and outs[0] == outs[1], (outs[0], outs[1])
 
 
 @pytest.mark.parametrize('ml', [3, 5])

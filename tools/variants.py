@@ -67,6 +67,10 @@ VARIANTS = {
 #undef ND_ISSUE_FROM
 ''', 'first'),
     ], []),
+    # where the cost of the z / P rasters goes (timing only): the chi-square pair skipped
+    'stats_nochisq': ('omnibus.hip', [
+        ("chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);", "P1[0] = P2[0] = zd[0] * 1e-3;", 'all'),
+    ], []),
 }
 
 
@@ -89,9 +93,9 @@ def build(names):
             patches = []
         for patch in patches:
             old, new = patch[0], patch[1]
-            if len(patch) > 2 and patch[2] == 'first':        # the first of several occurrences
+            if len(patch) > 2 and patch[2] in ('first', 'all'):   # the first of several occurrences / every one
                 assert s.count(old) >= 1, (name, old[:70])
-                s = s.replace(old, new, 1)
+                s = s.replace(old, new, 1) if patch[2] == 'first' else s.replace(old, new)
                 continue
             assert s.count(old) == 1, (name, s.count(old), old[:70])
             s = s.replace(old, new)
