@@ -339,7 +339,7 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 }
 
 // -----------------------------------------------------------------------------------------
-// pass A, TIME-SPLIT register-retaining form (round 6; float32, 49 .. 192 dates, sparse regime).
+// pass A, TIME-SPLIT register-retaining form (round 6; float32 49 .. 192 dates, float64 25 .. 96, sparse regime).
 // Beyond 48 dates one thread cannot hold a pixel's series, the plain pass A did not dump, and pass B
 // gathered every listed pixel again from the planes: 4 k isolated 4-byte reads, one 64-byte sector each
 // (96 dates x 2048 x 4096 at alpha = 0.99: 1.3 ms of a 3.45 ms call, for data pass A had just read).
@@ -364,12 +364,11 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 //   * a determinant that is NaN or exactly 0 makes the whole-series statistic NaN or infinite: no change
 //     anywhere, not listed (as the plain screen does not list it).
 // -----------------------------------------------------------------------------------------
-template <int KQ, int NS>
+template <typename T, int KQ, int NS>
 __global__ void __launch_bounds__(64 * NS)
-omnibus_c2_split_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const float retain_rel)
+omnibus_c2_split_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const float retain_rel)
 {
-    typedef float T;
-    __shared__ float part_s[NS][4][64];
+    __shared__ T part_s[NS][4][64];
     __shared__ double part_p[NS][64];
     __shared__ int part_e[NS][3][64];              // lowest / highest exponent of the slice's running product, flags
     __shared__ unsigned long long flag_mask;
@@ -489,9 +488,11 @@ omnibus_c2_split_kernel(const OmniGlobalArgs<float> g, const OmniTab tab, const 
         bool isbad = ((fl & 1) != 0) | !range_ok;
         const T dd = S11 * S22;
         const T det_of_sum = dd - ((S12r * S12r) + (S12i * S12i));
-        const T smin = fminf(S11, S22), smax = fmaxf(S11, S22);
-        isbad = isbad | !((smin > 9.094947e-13f) & (smax < 1.0995116e12f));          // 2^-40, 2^40
-        const float rel = retain_rel * (dd * __builtin_amdgcn_rcpf(det_of_sum));
+        const T smin = S11 < S22 ? S11 : S22, smax = S11 > S22 ? S11 : S22;
+        // (no under- or overflow inside the determinant of the sums: 2^+-40 in float32, 2^+-400 in float64)
+        isbad = isbad | !((smin > (sizeof(T) == 4 ? (T)9.094947e-13 : (T)3.8725919148493183e-121)) &
+                          (smax < (sizeof(T) == 4 ? (T)1.0995116e12 : (T)2.5822498780869086e120)));
+        const float rel = retain_rel * ((float)dd * __builtin_amdgcn_rcpf((float)det_of_sum));
         isbad = isbad | !((det_of_sum > (T)0) & (rel < 0.01f));
         const double logQ = g.nlooks * ((g.e.pklogk + approx_ln(PP)) - ((double)k * approx_ln((double)det_of_sum)));
         const double za = g.e.m2rho * logQ;
@@ -3250,7 +3251,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const char *e = getenv("ND_AMD_C2_SPLIT");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool split_ok = split_env && sizeof(T) == 4 && !retain && !stream_long && !stats && k <= 192 &&
+    const bool split_ok = split_env && !retain && !stream_long && !stats && k <= (sizeof(T) == 4 ? 192 : 96) &&
                           pm_ids == nullptr && mlp == nullptr && sx == 1;
     // The threshold only says that dense waves are LIKELY; whether they are is a property of the
     // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
@@ -3945,32 +3946,41 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         }
         g.gate_mode = 0;
     } else if (split_ok) {
+        KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
+        g.blocks_per_row = ceil_div(g.nx, (int64_t)64);
+        const int64_t nbs = g.blocks_per_row * g.nrows;
+        if (nbs > 0x7fffffffLL) {
+            set_error("nd_amd_omnibus_c2: raster too large for one launch (%lld blocks)", (long long)nbs);
+            return ND_AMD_EUNSUPPORTED;
+        }
+        // rounding band of the re-associated sums: 3 (5 k + 8) u (see the kernel), u = half an ulp of T
+        const float rel = 3.f * (5.f * (float)k + 8.f) * (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f);
+        const dim3 grid((unsigned)nbs);
+#define ND_LAUNCH_SPLIT(TT_, KQ_, NS_)                                                                         \
+    hipLaunchKernelGGL((omnibus_c2_split_kernel<TT_, KQ_, NS_>), grid, dim3(64 * NS_), 0, stream,               \
+                       reinterpret_cast<const OmniGlobalArgs<TT_> &>(g), tab, rel)
         if constexpr (std::is_same<T, float>::value) {
-            KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-            g.blocks_per_row = ceil_div(g.nx, (int64_t)64);
-            const int64_t nbs = g.blocks_per_row * g.nrows;
-            if (nbs > 0x7fffffffLL) {
-                set_error("nd_amd_omnibus_c2: raster too large for one launch (%lld blocks)", (long long)nbs);
-                return ND_AMD_EUNSUPPORTED;
-            }
-            const float rel = 3.f * (5.f * (float)k + 8.f) * 5.9604645e-08f;
+            // 4 KQ registers per lane: four waves up to 96 dates, eight beyond
             const int ns = k <= 96 ? 4 : 8;
             const int kqc = (int)ceil_div(k, ns);
             const int kq = kqc <= 16 ? 16 : (kqc <= 20 ? 20 : 24);
-            const dim3 grid((unsigned)nbs);
-#define ND_LAUNCH_SPLIT(KQ_, NS_) \
-    hipLaunchKernelGGL((omnibus_c2_split_kernel<KQ_, NS_>), grid, dim3(64 * NS_), 0, stream, g, tab, rel)
             if (ns == 4) {
-                if (kq <= 16) ND_LAUNCH_SPLIT(16, 4);
-                else if (kq == 20) ND_LAUNCH_SPLIT(20, 4);
-                else ND_LAUNCH_SPLIT(24, 4);
+                if (kq <= 16) ND_LAUNCH_SPLIT(float, 16, 4);
+                else if (kq == 20) ND_LAUNCH_SPLIT(float, 20, 4);
+                else ND_LAUNCH_SPLIT(float, 24, 4);
             } else {
-                if (kq == 16) ND_LAUNCH_SPLIT(16, 8);
-                else if (kq == 20) ND_LAUNCH_SPLIT(20, 8);
-                else ND_LAUNCH_SPLIT(24, 8);
+                if (kq == 16) ND_LAUNCH_SPLIT(float, 16, 8);
+                else if (kq == 20) ND_LAUNCH_SPLIT(float, 20, 8);
+                else ND_LAUNCH_SPLIT(float, 24, 8);
             }
-#undef ND_LAUNCH_SPLIT
+        } else {
+            // float64 (25 .. 96 dates): 8 KQ registers per lane -- 8 or 12 dates per wave
+            if (k <= 32) ND_LAUNCH_SPLIT(double, 8, 4);
+            else if (k <= 48) ND_LAUNCH_SPLIT(double, 12, 4);
+            else if (k <= 64) ND_LAUNCH_SPLIT(double, 8, 8);
+            else ND_LAUNCH_SPLIT(double, 12, 8);
         }
+#undef ND_LAUNCH_SPLIT
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (retain)

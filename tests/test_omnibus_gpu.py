@@ -257,9 +257,11 @@ def test_nodata_margins_at_low_thresholds(oracle, device, dtype, k):
         assert got[:, 215:].any()
 
 
-@pytest.mark.parametrize('k', [49, 57, 64, 80, 96, 97, 130, 192])
-def test_long_series_sparse_regime(oracle, device, k):
-    """49 .. 192 float32 dates in the sparse regime (alpha >= 0.75): the time-split pass A
+@pytest.mark.parametrize('dtype,k', [(np.float32, k_) for k_ in (49, 57, 64, 80, 96, 97, 130, 192)] +
+                         [(np.float64, k_) for k_ in (25, 33, 48, 49, 64, 80, 96, 97)])
+def test_long_series_sparse_regime(oracle, device, dtype, k):
+    """49 .. 192 float32 dates (25 .. 96 float64 dates; 97: beyond, the plain pass A) in the sparse regime
+    (alpha >= 0.75): the time-split pass A
     (omnibus_c2_split_kernel: four or eight waves share a pixel's time axis, candidates dumped from
     registers) and the LDS-DMA ring search behind it; with the minimal workspace (no dump: every
     candidate gathered from the planes) and with degenerate values -- whatever the re-associated screen
@@ -267,7 +269,7 @@ def test_long_series_sparse_regime(oracle, device, k):
     import torch
     from nd_amd import kernels
     rng = np.random.default_rng(k)
-    planes = [p.copy() for p in synth.omnibus_stack(seed=700 + k, k=k, ny=5, nx=333, dtype=np.float32,
+    planes = [p.copy() for p in synth.omnibus_stack(seed=700 + k, k=k, ny=5, nx=333, dtype=dtype,
                                                     change_frac=0.25)]
     planes[1][:, 0, 10:40] *= 6.0                      # |C12|^2 > C11 C22: not positive semi-definite
     planes[0][:, 1, 5:25] *= -1.0

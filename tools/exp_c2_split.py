@@ -24,7 +24,8 @@ def child(tag):
     nx = int(os.environ.get('EXP_NX', '4096'))
     alpha = float(os.environ.get('EXP_ALPHA', '0.99'))
     dev = torch.device('cuda:0')
-    st = synth.wishart_c2_stack(k, ny, nx, looks=9, seed=1234, device=dev, change_frac=0.01)
+    tdt = torch.float64 if os.environ.get('EXP_DTYPE', 'f32') == 'f64' else torch.float32
+    st = synth.wishart_c2_stack(k, ny, nx, looks=9, seed=1234, device=dev, change_frac=0.01, dtype=tdt)
     fn = lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9)   # noqa: E731
     for _ in range(2):
         out = fn()
@@ -41,7 +42,7 @@ def child(tag):
         by.setdefault(n_, []).append(ms)
     avg = {n_: round(sum(v) / len(v), 4) for n_, v in by.items()}
     digest = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16]
-    print(json.dumps({'tag': tag, 'k': k, 'ny': ny, 'nx': nx, 'alpha': alpha, 'ms': round(dt * 1e3, 4), 'kernels_ms': avg,
+    print(json.dumps({'tag': tag, 'dtype': str(tdt)[6:], 'k': k, 'ny': ny, 'nx': nx, 'alpha': alpha, 'ms': round(dt * 1e3, 4), 'kernels_ms': avg,
                       'changes': int(out.sum().item()), 'changed_px_frac': round(float((out.sum(dim=2) > 0).float().mean().item()), 6),
                       'map_sha1': digest}), flush=True)
 
@@ -51,7 +52,6 @@ def main():
              ('plain_pass_A_then_gather_float_screen', {'ND_AMD_C2_SPLIT': '0'}),
              ('time_split_sweep_double_screen', {'ND_AMD_C2_SPLIT': '1', 'ND_AMD_SEARCH_FS': '0'}),
              ('time_split_sweep_float_screen', {'ND_AMD_C2_SPLIT': '1'}),
-             ('time_split_ring_float_screen', {'ND_AMD_C2_SPLIT': '1', 'ND_AMD_SEARCH_RING': '1'}),
              ('time_split_image_float_screen', {'ND_AMD_C2_SPLIT': '1', 'ND_AMD_SEARCH_MODE': '0'})]
     for tag, env in forms:
         e = dict(os.environ)
