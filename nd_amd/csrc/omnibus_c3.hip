@@ -1879,6 +1879,8 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
             return ND_AMD_EUNSUPPORTED;
         }
         g.pm_vec = 1;                        // (the checks above are what the 16-byte loads of pass B need as well)
+        // (four LANES sharing a pixel's time axis -- 16-byte loads straight into registers, quad broadcasts, no LDS --
+        //  were built and measured slower: 3.64 / 4.55 ms against 3.38 / 3.16 ms, DESIGN-EXPERIMENTS.md round 6)
         C3PmArgs pa;
         int off = 0;
         for (int c = 0; c < 9; ++c) {
