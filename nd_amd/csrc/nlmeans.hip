@@ -1621,17 +1621,19 @@ __device__ __forceinline__ float nlm_row_sum_lanes(const float e)
     return acc;
 }
 
-constexpr int kPatch3TYW = 4, kPatch3TY = 4 * kPatch3TYW;
+constexpr int kPatch3TYW = 4;
 constexpr float kPatch3Redo = 1e-2f;      // a pixel whose largest float32 weight is below this: the wave searches again in double
 
 // RMAX: the search radius along rows and columns the tile is laid out for (r0, r1 <= RMAX): the pitches of
 // the staged planes are compile-time constants then, and the (2 FZ + 1) V (TYW + 2 F) reads of a search
 // offset are immediate offsets of three address registers instead of one address computation each.
-template <int F, int FZ, int V, bool NEFF, int RMAX>
+// TYW: rows per thread (4: a 16-row tile; 2: an 8-row tile for windows whose planes would not fit otherwise --
+// seven planes of four variables)
+template <int F, int FZ, int V, bool NEFF, int RMAX, int TYW>
 __global__ void __launch_bounds__(256) nlmeans_patch3_kernel(const NlmTiledArgs a)
 {
     extern __shared__ __align__(16) unsigned char nd_smem_p3[];
-    constexpr int TYW = kPatch3TYW, TY = kPatch3TY, TXO = 64 - 2 * F, NPP = 2 * FZ + 1, NS = TYW + 2 * F;
+    constexpr int TY = 4 * TYW, TXO = 64 - 2 * F, NPP = 2 * FZ + 1, NS = TYW + 2 * F;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r0 = a.r0, r1 = a.r1, rz = a.rz;
@@ -1890,31 +1892,38 @@ __global__ void __launch_bounds__(256) nlmeans_patch3_kernel(const NlmTiledArgs 
 
 constexpr int kPatch3RMax = 4;
 
-template <int F, int FZ, int V>
+template <int F, int FZ, int V, int TYW>
 static int launch_patch3(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
 {
     if (a.n_eff >= 0) {
         if (lds > 64 * 1024)
-            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&nlmeans_patch3_kernel<F, FZ, V, true, kPatch3RMax>),
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&nlmeans_patch3_kernel<F, FZ, V, true, kPatch3RMax, TYW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((nlmeans_patch3_kernel<F, FZ, V, true, kPatch3RMax>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((nlmeans_patch3_kernel<F, FZ, V, true, kPatch3RMax, TYW>), dim3((unsigned)nb), dim3(256), lds, stream, a);
     } else {
         if (lds > 64 * 1024)
-            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&nlmeans_patch3_kernel<F, FZ, V, false, kPatch3RMax>),
+            ND_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&nlmeans_patch3_kernel<F, FZ, V, false, kPatch3RMax, TYW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((nlmeans_patch3_kernel<F, FZ, V, false, kPatch3RMax>), dim3((unsigned)nb), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((nlmeans_patch3_kernel<F, FZ, V, false, kPatch3RMax, TYW>), dim3((unsigned)nb), dim3(256), lds, stream, a);
     }
     return ND_AMD_OK;
 }
 
-template <int F, int FZ>
+template <int F, int FZ, int TYW>
 static int launch_patch3_v(const NlmTiledArgs &a, int64_t nb, size_t lds, hipStream_t stream)
 {
-    switch (a.nvars) {
-    case 1: return launch_patch3<F, FZ, 1>(a, nb, lds, stream);
-    case 2: return launch_patch3<F, FZ, 2>(a, nb, lds, stream);
-    case 3: return launch_patch3<F, FZ, 3>(a, nb, lds, stream);
-    default: return launch_patch3<F, FZ, 4>(a, nb, lds, stream);
+    // (the 8-row tiles exist for the plane counts that need them: three and four variables)
+    if constexpr (TYW == 4) {
+        switch (a.nvars) {
+        case 1: return launch_patch3<F, FZ, 1, TYW>(a, nb, lds, stream);
+        case 2: return launch_patch3<F, FZ, 2, TYW>(a, nb, lds, stream);
+        case 3: return launch_patch3<F, FZ, 3, TYW>(a, nb, lds, stream);
+        default: return launch_patch3<F, FZ, 4, TYW>(a, nb, lds, stream);
+        }
+    } else {
+        if (a.nvars == 3) return launch_patch3<F, FZ, 3, TYW>(a, nb, lds, stream);
+        if (a.nvars == 4) return launch_patch3<F, FZ, 4, TYW>(a, nb, lds, stream);
+        return ND_AMD_EUNSUPPORTED;
     }
 }
 
@@ -2040,24 +2049,36 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
         const uint32_t FZz = (patch_mode == 1) ? fz : 0u;
         if (no_patch3 || A2 != 0 || f64 || nvars > 4) return 0;
         if (patch_mode == 0 && (f[A0] != 0 || f[A1] != 0 || fz != 0)) return 0;
-        if (F0z != F1z || F0z > 2 || FZz > 1 || rz > 2 || a.r0 > kPatch3RMax || a.r1 > kPatch3RMax) return 0;
+        // (3 x 3 patches, or none, in the plane; 5 x 5 and larger: the per-pixel kernel -- every instantiation costs
+        //  build time, and no caller of the reference uses them with a window along time)
+        if (F0z != F1z || F0z > 1 || FZz > 1 || rz > 2 || a.r0 > kPatch3RMax || a.r1 > kPatch3RMax) return 0;
         const int Fp = (int)F0z;
-        const size_t cols3 = 64 + 2 * (size_t)kPatch3RMax, rows3 = kPatch3TY + 2 * (size_t)(kPatch3RMax + Fp);
+        const size_t cols3 = 64 + 2 * (size_t)kPatch3RMax;
         const size_t np3 = 2 * (size_t)(rz + FZz) + 1;
-        const size_t lds3 = np3 * (size_t)nvars * rows3 * cols3 * sizeof(float) + (rows3 + cols3) * sizeof(int);
+        // 16-row tiles where their planes fit the LDS, 8-row tiles otherwise (seven planes of four variables)
+        int tyw = kPatch3TYW;
+        size_t rows3 = 4 * (size_t)tyw + 2 * (size_t)(kPatch3RMax + Fp);
+        size_t lds3 = np3 * (size_t)nvars * rows3 * cols3 * sizeof(float) + (rows3 + cols3) * sizeof(int);
+        if (lds3 > kBigLds) {
+            if (nvars < 3) return 0;
+            tyw = 2;
+            rows3 = 4 * (size_t)tyw + 2 * (size_t)(kPatch3RMax + Fp);
+            lds3 = np3 * (size_t)nvars * rows3 * cols3 * sizeof(float) + (rows3 + cols3) * sizeof(int);
+        }
         a.tiles_x = (int)ceil_div(ex, 64 - 2 * Fp);
-        a.tiles_y = (int)ceil_div(ey, kPatch3TY);
+        a.tiles_y = (int)ceil_div(ey, 4 * tyw);
         const int64_t nb3 = (int64_t)a.tiles_x * a.tiles_y * nsl;
         if (lds3 > kBigLds || nb3 > 0x7fffffffLL) return 0;
         KernelTimer timer(ND_AMD_KERNEL_NLMEANS_TILED, stream);
         int rc3 = ND_AMD_OK;
-        if (Fp == 0 && FZz == 0) rc3 = launch_patch3_v<0, 0>(a, nb3, lds3, stream);
-        else if (Fp == 1 && FZz == 0) rc3 = launch_patch3_v<1, 0>(a, nb3, lds3, stream);
-        else if (Fp == 1 && FZz == 1) rc3 = launch_patch3_v<1, 1>(a, nb3, lds3, stream);
-        else if (Fp == 2 && FZz == 0) rc3 = launch_patch3_v<2, 0>(a, nb3, lds3, stream);
-        else if (Fp == 2 && FZz == 1) rc3 = launch_patch3_v<2, 1>(a, nb3, lds3, stream);
-        else if (Fp == 0 && FZz == 1) rc3 = launch_patch3_v<0, 1>(a, nb3, lds3, stream);
+#define ND_P3(F_, FZ_)                                                                     \
+    (tyw == 4 ? launch_patch3_v<F_, FZ_, 4>(a, nb3, lds3, stream) : launch_patch3_v<F_, FZ_, 2>(a, nb3, lds3, stream))
+        if (Fp == 0 && FZz == 0) rc3 = ND_P3(0, 0);
+        else if (Fp == 1 && FZz == 0) rc3 = ND_P3(1, 0);
+        else if (Fp == 1 && FZz == 1) rc3 = ND_P3(1, 1);
+        else if (Fp == 0 && FZz == 1) rc3 = ND_P3(0, 1);
         else return 0;
+#undef ND_P3
         return rc3 == ND_AMD_OK ? 1 : 0;
     }
     const uint32_t F0 = (patch_mode == 1) ? f[A0] : 0u, F1 = (patch_mode == 1) ? f[A1] : 0u;

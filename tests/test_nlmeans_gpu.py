@@ -364,7 +364,9 @@ def test_one_column_patch_kernel_forced(tmp_path):
     (4, 5, 40, 131, (1, 3, 3), (1, 1, 1), 0.5, 0.5, 30.0),     # ... with n_eff (find_weight)
     (1, 7, 37, 200, (2, 4, 4), (1, 1, 1), 0.3, 0.4, -1),       # two dates either side, radius 4
     (2, 4, 33, 90, (1, 2, 2), (0, 1, 1), 0.4, 0.5, -1),        # no patch extent along time
-    (3, 5, 50, 70, (1, 3, 3), (1, 2, 2), 0.5, 0.6, -1),        # 5 x 5 x 3 patches (3 variables: the image fits)
+    (3, 5, 50, 70, (1, 3, 3), (1, 2, 2), 0.5, 0.6, -1),        # 5 x 5 x 3 patches: the per-pixel kernel (not tiled)
+    (4, 7, 30, 100, (2, 3, 3), (1, 1, 1), 0.5, 0.5, -1),       # two dates either side, 4 variables: 8-row tiles
+    (3, 6, 26, 90, (2, 2, 2), (0, 1, 1), 0.4, 0.5, 20.0),      # ... 3 variables, n_eff
     (2, 4, 20, 64, (1, 1, 1), (1, 0, 0), 0.4, 0.5, -1),        # patch along time only
 ])
 def test_signed_mode_search_along_time_tiled_kernel(oracle, device, case):
