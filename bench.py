@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # workload's kernels, from separate rocprofv3 --pmc passes over `bench.py --traffic-run KEY`
 # (tools/collect_traffic.sh writes the file, with the commit it was taken at).  Reported with its
 # source; a workload or kernel the file does not hold gets traffic = null.
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r05_traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r06_traffic.json')
 
 
 def csrc_sha():
