@@ -57,6 +57,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # (tools/collect_traffic.sh writes the file, with the commit it was taken at).  Reported with its
 # source; a workload or kernel the file does not hold gets traffic = null.
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r06_traffic.json')
+FULL_SYNTH = os.environ.get('ND_AMD_TRAFFIC_FULL_SYNTH', '') == '1'
 
 
 def csrc_sha():
@@ -455,10 +456,13 @@ class OmnibusC3(Workload):
         super().__init__(a, rank, world, dev)
         from nd_amd import synth
         # (under the profiler's counter pass only six dates are drawn and repeated: the full synthesis is
-        # 17 000 small launches, at which rocprofv3 --pmc segfaults; the kernels' traffic is the same)
+        # 17 000 small launches, at which rocprofv3 --pmc segfaults -- unless the counters are restricted to
+        # this library's kernels (--kernel-include-regex nd_amd), which tools/collect_traffic.sh does since
+        # round 6 with ND_AMD_TRAFFIC_FULL_SYNTH=1: six repeated dates are NOT the workload -- 575 527
+        # candidates instead of 168 025 at the benchmark's threshold, 3.4 x the traffic of pass B)
         self.stack = synth.wishart_c3_stack(self.k, self.rows, self.nx, looks=a.looks,
                                             seed=4321 + rank, device=dev, change_frac=a.change_frac,
-                                            cycle=6 if TRAFFIC_MODE else 0)
+                                            cycle=6 if (TRAFFIC_MODE and not FULL_SYNTH) else 0)
         self.alg_bytes = self.npix * self.k * (9 * self.stack.element_size() + 1)
 
     def step(self):
@@ -510,7 +514,7 @@ class Pipeline(Workload):
         self.halo = TUT['r'][1] + TUT['f'][1]
         self.shard = tiles.empty_shard((4, self.k), self.global_ny, self.nx, self.halo, dev,
                                        rank=rank, world=world)
-        if TRAFFIC_MODE:
+        if TRAFFIC_MODE and not FULL_SYNTH:
             # (under the profiler's counter passes the Wishart synthesis -- thousands of small launches, each
             #  with its counters read out -- takes longer than the run may stay silent; the filter's traffic does
             #  not depend on the values: uniform planes, three launches per date)

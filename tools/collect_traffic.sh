@@ -14,7 +14,9 @@ HB=$!
 for K in $KEYS; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/tr_$C
-    timeout -k 5 1000 rocprofv3 --kernel-trace --pmc $C -d /tmp/tr_$C -o p --output-format csv -- python3 $R/bench.py --traffic-run $K > $OUT/run_${K}_$C.log 2>&1
+    # (counters of this library's kernels only: the synthesis of a full-pol stack is 17 000 torch launches, at which a
+    #  counter pass over every dispatch gives up; with the filter the REAL workload can be profiled -- ND_AMD_TRAFFIC_FULL_SYNTH)
+    ND_AMD_TRAFFIC_FULL_SYNTH=1 timeout -k 5 1000 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex nd_amd -d /tmp/tr_$C -o p --output-format csv -- python3 $R/bench.py --traffic-run $K > $OUT/run_${K}_$C.log 2>&1
     F=$(ls /tmp/tr_$C/*/p_counter_collection.csv /tmp/tr_$C/p_counter_collection.csv 2>/dev/null | head -1)
     cp "$F" $OUT/${K}_$C.csv
   done

@@ -71,6 +71,21 @@ VARIANTS = {
     'stats_nochisq': ('omnibus.hip', [
         ("chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);", "P1[0] = P2[0] = zd[0] * 1e-3;", 'all'),
     ], []),
+    # full-pol search on the dump: chunks of eight instead of four dates (traffic / time of partially used lines)
+    'c3_search_cd8': ('omnibus_c3.hip', [
+        ("    constexpr int CD = 4;                                // dates per chunk", "    constexpr int CD = 8;                                // dates per chunk"),
+        ('''                    ND_C3_PICK(2)
+                default:
+                    ND_C3_PICK(3)
+''', '''                    ND_C3_PICK(2)
+                    ND_C3_PICK(3)
+                    ND_C3_PICK(4)
+                    ND_C3_PICK(5)
+                    ND_C3_PICK(6)
+                default:
+                    ND_C3_PICK(7)
+'''),
+    ], []),
 }
 
 
