@@ -808,7 +808,7 @@ def extras(main, barrier, dev, only=None, light=False):
             res = w.check(ch, nsample=5000 if light else 20000)
             dom = w.dom if (alpha > 0.5 and w.dom in km) else max(km, key=km.get)
             entry(key, w.describe(), dt, nst, w.npix, km,
-                  roof(key, 'omnibus_c3_global' if alpha > 0.5 else 'omnibus_c3_stream', dom, km, w.alg_bytes,
+                  roof(key, 'omnibus_c3_retain' if alpha > 0.5 else 'omnibus_c3_stream', dom, km, w.alg_bytes,
                        note=None if alpha > 0.5 else 'search fused into the streaming pass (omnibus_c3_stream_kernel)'),
                   res['bad'] == 0, sample=res, alg_bytes=w.alg_bytes)
             del ch
