@@ -518,7 +518,11 @@ omnibus_c2_split_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const floa
     if (m != 0ull && t_lo < k) {
         const unsigned slot = list_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         if (((m >> lane) & 1ull) && slot < g.dump_cap) {
-            T *dptr = g.dump + ((int64_t)shard * g.dump_cap + slot) * (int64_t)(4 * k) + 4 * t_lo;
+            // BLOCKED layout (dump_cap is a multiple of 64 here): [shard][slot / 64][date][slot % 64][4] -- the 64
+            // series of a block of list entries interleaved date by date, so that pass B, which gives those entries
+            // the 64 lanes of a wave and walks the dates in lockstep (omnibus_c2_search_rounds_kernel), reads one
+            // contiguous kilobyte per date
+            T *dptr = g.dump + ((((int64_t)shard * (g.dump_cap >> 6) + (slot >> 6)) * (int64_t)k + t_lo) * 64 + (slot & 63u)) * 4;
 #pragma unroll
             for (int tt = 0; tt < KQ; ++tt) {
                 if (t_lo + tt < k) {
@@ -527,7 +531,7 @@ omnibus_c2_split_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const floa
                     q.v[1] = v[tt][1];
                     q.v[2] = v[tt][2];
                     q.v[3] = v[tt][3];
-                    *reinterpret_cast<Pack<T, 4> *>(dptr + 4 * tt) = q;
+                    *reinterpret_cast<Pack<T, 4> *>(dptr + (int64_t)tt * 256) = q;
                 }
             }
         }
@@ -2439,6 +2443,9 @@ struct OmniSearchArgs {
     // Shards whose list holds at most this many pixels are searched by omnibus_c2_search_starts_kernel
     // (one lane per segment start), the longer ones by the LDS form; 0: the LDS form takes everything.
     uint32_t starts_max;
+    // omnibus_c2_search_kernel starts at this entry of every shard's list (the entries in front of it
+    // belong to omnibus_c2_search_rounds_kernel); 0: every entry
+    uint32_t first;
 };
 
 // MODE 0: series staged in LDS; MODE 1: no LDS, each date read straight from the dump (or the
@@ -2497,7 +2504,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
     const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
     if (n <= s.starts_max) return;             // omnibus_c2_search_starts_kernel searches this shard
 
-    for (uint32_t base = lblock * (unsigned)PXW; base < n; base += nlblock * (unsigned)PXW) {
+    for (uint32_t base = s.first + lblock * (unsigned)PXW; base < n; base += nlblock * (unsigned)PXW) {
         const uint32_t idx = base + lane;
         bool active = idx < n && lane < PXW;
         if (s.hand_bits != nullptr) {
@@ -2674,6 +2681,134 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_kernel(const OmniSearchA
                     } else {
                         done = true;                       // :241-242
                     }
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// pass B behind the time-split pass A (round 6): the sweep in LOCKSTEP ROUNDS on the blocked dump.
+// The from-memory form (MODE 1 above) lets every lane walk its own dates: each step of the wave is one
+// instruction whose 64 lanes address 64 different lines, and the rate at which a CU looks those up bounds
+// the kernel (96 dates x 164 000 pixels: 0.40 ms whatever the read-ahead, the arithmetic or the chunking:
+// DESIGN-EXPERIMENTS.md).  Here the 64 listed pixels of a wave are a BLOCK of the dump -- their series
+// interleaved date by date -- and the date index is wave-uniform: a round walks the dates from the earliest
+// segment start among the wave's unfinished pixels to the end, one contiguous kilobyte per date (four dates
+// in flight), every lane folding from its own segment start on; behind the last date a lane commits the first
+// firing date of its segment if the global test fired (nd/_change.pyx:235-257, one sweep per segment as in
+// omnibus_c2_search_kernel) and starts its next segment there; rounds repeat while a lane has a segment
+// left.  The fold, the float32 screen and the exact evaluation behind a wave-uniform branch are the
+// sweep's, operation for operation.  List entries beyond the dump's capacity: omnibus_c2_search_kernel
+// (OmniSearchArgs::first).
+// -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64) omnibus_c2_search_rounds_kernel(const OmniSearchArgs<T> s, const DenseScreenLong fscr)
+{
+    constexpr int PF = 4;                                // dates in flight
+    extern __shared__ __align__(16) unsigned char nd_smem_rd[];
+    DenseScreenEntry *scr_f = reinterpret_cast<DenseScreenEntry *>(nd_smem_rd);
+    const int lane = threadIdx.x;
+    const int k = s.k;
+    const OmniTabEntry *tabp = s.tab;
+    for (int j = lane; j <= k; j += 64) scr_f[j] = fscr.e[j];
+    __syncthreads();
+    const unsigned shard = blockIdx.x % kShards;
+    const unsigned lblock = blockIdx.x / kShards;
+    const unsigned nlblock = gridDim.x / kShards;
+    const uint32_t nall = s.flag_count[shard * kCounterStride];
+    const uint32_t n = nall < s.dump_cap ? nall : s.dump_cap;          // (dump_cap: a multiple of 64)
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+
+    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < n;
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+        // this lane's values of date t: blk + t * 256 (elements)
+        const T *blk = s.dump + (((int64_t)shard * (s.dump_cap >> 6) + (base >> 6)) * (int64_t)k * 64 + lane) * 4;
+        uint8_t *res = s.change + pix * (int64_t)k;
+        Accum<T> A;
+        A.reset();
+        int l = 0, fire_at = -1;
+        bool done = !active;
+        while (__any(!done)) {
+            // the round starts at the earliest segment start among the unfinished lanes
+            int t0 = done ? k : l;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(t0, off);
+                t0 = o < t0 ? o : t0;
+            }
+            t0 = __builtin_amdgcn_readfirstlane(t0);
+            bool fires = false;                                  // of the test met last: at t = k - 1 the global test
+            Pack<T, 4> ring[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int tu = t0 + u < k ? t0 + u : k - 1;
+                ring[u] = *reinterpret_cast<const Pack<T, 4> *>(blk + (int64_t)tu * 256);
+            }
+            for (int tb = t0; tb < k; tb += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int t = tb + u;                        // wave-uniform
+                    if (t < k) {
+                        const Pack<T, 4> cur = ring[u];
+                        const int tn = t + PF < k ? t + PF : k - 1;
+                        ring[u] = *reinterpret_cast<const Pack<T, 4> *>(blk + (int64_t)tn * 256);
+                        const bool on = !done && t >= l;
+                        if (on) A.step(cur.v[0], cur.v[1], cur.v[2], cur.v[3]);
+                        const int jj = t - l + 1;
+                        const bool last = (t == k - 1);
+                        const bool need = on && (jj >= 2) && (fire_at < 0 || last);
+                        bool f = false, inband = false;
+                        if (need) {
+                            const T dets = (A.s11 * A.s22) - ((A.s12r * A.s12r) + (A.s12i * A.s12i));
+                            const bool ok = (dets > (T)0) & (dets < (T)INFINITY) & __builtin_amdgcn_class(A.prod, 0x100);
+                            const DenseScreenEntry c = scr_f[jj];
+                            int es, eP;
+                            float ms, mP;
+                            log2_parts(ok ? dets : (T)1, es, ms);
+                            log2_parts(ok ? A.prod : 1.0, eP, mP);
+                            const int E = (eP - c.re) - __mul24(jj, es);
+                            const float x = (float)E + __builtin_fmaf(-(float)jj, ms, mP - c.rf);
+                            f = ok & (x < c.a);
+                            inband = !(f | (ok & (x > c.b)));
+                        }
+                        if (__any(inband)) {
+                            if (inband) {
+                                const OmniTabEntry e = tabp[jj];
+                                const T zp = z_stat<T>(A, jj, s.nlooks, e);
+                                const double zd = (double)zp;
+                                int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                                if (verdict == 2) {
+                                    double zv[1] = {zd}, P1[1], P2[1];
+                                    chisq_pair<1>(zv, 4 * (jj - 1), e.lgam, P1, P2);
+                                    const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                                    verdict = ((double)P > s.alpha) ? 1 : 0;
+                                }
+                                f = (verdict == 1);
+                            }
+                        }
+                        if (need) {
+                            if (f && fire_at < 0) fire_at = t;
+                            if (last) fires = f;
+                        }
+                    }
+                }
+            }
+            // behind the last date: `fires` is the global test of ts[l:] (a segment of one date has none)
+            if (!done) {
+                if (fires && (k - l) >= 2) {
+                    res[fire_at] = 1;                          // :252
+                    l = fire_at;                               // :255
+                    if (l >= k - 1) {
+                        done = true;                           // :256
+                    } else {
+                        A.reset();
+                        fire_at = -1;
+                    }
+                } else {
+                    done = true;                               // :241-242
                 }
             }
         }
@@ -3113,6 +3248,18 @@ static void launch_retain(const OmniGlobalArgs<T> &g, const OmniTab &tab, int64_
     }
 }
 
+// ND_AMD_SEARCH_FS=0: the sweeps of pass B screen a test with z_approx in double, as before round 6, instead of the
+// float32 screen -- and the sparse regime of long series takes the plain pass A and the gather (the lockstep sweep
+// behind the time-split pass A has the float32 screen only)
+static bool search_fs_enabled()
+{
+    static const bool v = [] {
+        const char *e = getenv("ND_AMD_SEARCH_FS");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return v;
+}
+
 // ND_AMD_FUSED_FORM: which fused search serves the thresholds below the sparse regime -- 0 the
 // streaming search, 2 dense_chain on the retained series, 3 dense_chain in two streaming passes
 // (longer series); unset (-1): by threshold and series length.  Speed only: every form gives the same
@@ -3251,8 +3398,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const char *e = getenv("ND_AMD_C2_SPLIT");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool split_ok = split_env && !retain && !stream_long && !stats && k <= (sizeof(T) == 4 ? 192 : 96) &&
-                          pm_ids == nullptr && mlp == nullptr && sx == 1;
+    const bool split_ok = split_env && search_fs_enabled() && !retain && !stream_long && !stats &&
+                          k <= (sizeof(T) == 4 ? 192 : 96) && pm_ids == nullptr && mlp == nullptr && sx == 1;
     // The threshold only says that dense waves are LIKELY; whether they are is a property of the
     // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
     // is therefore made on the device from a sample (omnibus_c2_sample_kernel): both variants are
@@ -3271,6 +3418,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         size_t cap = (retain || stream_long || split_ok) ? (workspace_bytes - w.off_dump) / per / kShards : 0;   // per shard
         g.seg = w.seg;
         if (cap > g.seg) cap = g.seg;
+        if (split_ok) cap &= ~(size_t)63;            // (the blocked layout of the time-split pass A: whole blocks of 64 entries)
         g.dump = reinterpret_cast<T *>(ws + w.off_dump);
         g.dump_cap = (uint32_t)cap;
     }
@@ -3399,17 +3547,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         s.hand_words = hand_words;
         s.hand_count = const_cast<uint32_t *>(count) + 3;    // word 3 of the lists' first counter line
         s.starts_max = 0;
+        s.first = 0;
         const size_t scr_bytes = (size_t)(k + 1) * 4 * sizeof(double);      // screen constants
         const size_t lds_bytes = (size_t)k * 4 * 64 * sizeof(T) + scr_bytes;
         // the LDS image of 64 series may take up to 150 KB of the CU's 160 KB: for long series that is
         // one or two waves per CU, still well ahead of a dependent plane access per date and lane
         const bool use_lds = lds_bytes <= 150 * 1024;
         // the float32 screen of the sweep (FS): its per-j band, for tests over up to 192 dates
-        static const bool fs_env = [] {
-            const char *e = getenv("ND_AMD_SEARCH_FS");          // 0: z_approx in double, as before round 6
-            return e ? atoi(e) != 0 : true;
-        }();
-        const bool fs = fs_env && k <= kScreenLong;
+        const bool fs = search_fs_enabled() && k <= kScreenLong;
         DenseScreenLong fscr;
         memset(&fscr, 0, sizeof(fscr));
         for (int j = 0; j <= kScreenLong; ++j) {
@@ -3507,6 +3652,19 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const bool from_dump = split_ok && dump_cap > 0;
         const int mode = (mode_env == 0 || mode_env == 1) ? mode_env : ((use_lds && !behind && !from_dump) ? 0 : 1);
         const int64_t xblocks = behind ? (per_shard > 16 ? 16 : per_shard) * kShards : sblocks;
+        // behind the time-split pass A the dump is BLOCKED (64 series interleaved date by date): the lockstep sweep
+        // is its only reader; what the dump could not hold is gathered from the planes by the from-memory form
+        // (ND_AMD_SEARCH_MODE / ND_AMD_SEARCH_PXW do not apply to this path)
+        if (split_ok && dump_cap > 0) {
+            if (!fs) {
+                set_error("nd_amd_omnibus_c2: internal: the time-split pass A needs the float32 screen's table (k <= %d)", kScreenLong);
+                return ND_AMD_EINVAL;
+            }
+            hipLaunchKernelGGL((omnibus_c2_search_rounds_kernel<T>), dim3((unsigned)sblocks), dim3(64), (size_t)(k + 1) * sizeof(DenseScreenEntry), sq, s, fscr);
+            s.first = dump_cap;
+            ND_LAUNCH_SWEEP(1, 64, dim3((unsigned)sblocks), scr_bytes);
+            return ND_AMD_OK;
+        }
         // images beyond 48 KB (three waves per CU or fewer at 64 series per wave): 16 series per wave
         // (96 dates x 8.4 Mpx at alpha = 0.99: pass B 1.84 ms with 64, 1.35 with 32, 1.30 with 16)
         static const int pxw_env = [] {

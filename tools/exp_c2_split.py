@@ -48,11 +48,8 @@ def child(tag):
 
 
 def main():
-    forms = [('plain_pass_A_then_gather', {'ND_AMD_C2_SPLIT': '0', 'ND_AMD_SEARCH_FS': '0'}),
-             ('plain_pass_A_then_gather_float_screen', {'ND_AMD_C2_SPLIT': '0'}),
-             ('time_split_sweep_double_screen', {'ND_AMD_C2_SPLIT': '1', 'ND_AMD_SEARCH_FS': '0'}),
-             ('time_split_sweep_float_screen', {'ND_AMD_C2_SPLIT': '1'}),
-             ('time_split_image_float_screen', {'ND_AMD_C2_SPLIT': '1', 'ND_AMD_SEARCH_MODE': '0'})]
+    forms = [('plain_pass_A_then_gather', {'ND_AMD_C2_SPLIT': '0'}),
+             ('time_split_pass_A_lockstep_rounds_on_the_blocked_dump', {'ND_AMD_C2_SPLIT': '1'})]
     for tag, env in forms:
         e = dict(os.environ)
         e.update(env)
