@@ -13,8 +13,8 @@
 // 1728 B per pixel at k = 48 float32: no thread retains that.  Sparse regime (alpha >= 0.75), float32 up
 // to 64 dates (round 6): FOUR WAVES SHARE A PIXEL'S TIME AXIS (omnibus_c3_retain_kernel), screen the
 // re-associated whole-series statistic and dump the candidates' series from their registers; pass B
-// (omnibus_c3_search_dump_kernel) reads the dump one lane per pixel and runs the one-sweep-per-segment
-// search of the dual-pol kernel.  Elsewhere in the sparse regime pass A streams the planes in chunks of
+// (omnibus_c3_search_rounds_kernel) walks the dump, blocked by 64 series, in lockstep rounds and runs the
+// one-sweep-per-segment search of the dual-pol kernel.  Elsewhere in the sparse regime pass A streams the planes in chunks of
 // dates without retention (omnibus_c3_global_kernel) and pass B gathers a listed pixel's series from the
 // planes (LDS-staged when it fits).  Low thresholds: the search fused into a streaming pass
 // (omnibus_c3_stream_kernel), between 0.02 and the sparse regime the chain search in two streaming passes
@@ -107,7 +107,10 @@ struct C3Args {
     int mult[9];              // element-offset multiplier per plane (pixel-major inputs: 2 for the halves of an
                               // interleaved complex array, else 1): pass B reads plane c at pl[c][o * mult[c]]
     // Series of the listed pixels, written by the time-split pass A (omnibus_c3_retain_kernel) from its
-    // registers: entry i of shard s's list has its series at dump[(s * dump_cap + i) * dump_stride + t * 9 + c]
+    // registers, BLOCKED for the lockstep sweep of pass B (omnibus_c3_search_rounds_kernel): the 64 series of a block
+    // of list entries interleaved by groups of four dates and by component --
+    //   value (t, c) of entry i of shard s:  dump[((((s * dump_cap / 64 + i / 64) * G + t / 4) * 9 + c) * 64 + i % 64) * 4 + t % 4],
+    //   G = dump_stride / 36 groups per series (dump_stride = 9 x the dates a slot holds, dump_cap a multiple of 64)
     // while i < dump_cap; later entries are gathered from the planes as before.  nullptr: no dump.
     T *dump;
     uint32_t dump_cap, dump_stride;
@@ -378,22 +381,28 @@ __global__ void __launch_bounds__(64 * kC3Slices) omnibus_c3_retain_kernel(const
         }
     }
     __syncthreads();
-    // a candidate's slice leaves the registers: 9 KQ values as 16-byte pieces, the series of a pixel one run
+    // a candidate's slice leaves the registers: per component and group of four dates one 16-byte piece, into the
+    // blocked dump (see C3Args::dump)
     const unsigned long long m = flag_mask;
     if (m != 0ull && t_lo < k) {
         const unsigned pos = list_base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
         if (((m >> lane) & 1ull) && pos < g.dump_cap) {
             typedef float f4 __attribute__((ext_vector_type(4)));
-            f4 *dst = reinterpret_cast<f4 *>(g.dump + ((size_t)shard * g.dump_cap + pos) * g.dump_stride + t_lo * 9);
+            const unsigned G = g.dump_stride / 36u;
+            // first group of this wave's slice (KQ is a multiple of 4)
+            f4 *dst = reinterpret_cast<f4 *>(g.dump) +
+                      ((((size_t)shard * (g.dump_cap >> 6) + (pos >> 6)) * G + (unsigned)(t_lo >> 2)) * 9) * 64 + (pos & 63u);
 #pragma unroll
-            for (int i = 0; i < (KQ * 9) / 4; ++i) {
-                f4 q;
-                q.x = v[(4 * i) / 9][(4 * i) % 9];
-                q.y = v[(4 * i + 1) / 9][(4 * i + 1) % 9];
-                q.z = v[(4 * i + 2) / 9][(4 * i + 2) % 9];
-                q.w = v[(4 * i + 3) / 9][(4 * i + 3) % 9];
-                dst[i] = q;
-            }
+            for (int gq = 0; gq < KQ / 4; ++gq)
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    f4 q;
+                    q.x = v[4 * gq + 0][c];
+                    q.y = v[4 * gq + 1][c];
+                    q.z = v[4 * gq + 2][c];
+                    q.w = v[4 * gq + 3][c];
+                    dst[(size_t)(gq * 9 + c) * 64] = q;
+                }
         }
     }
 }
@@ -1588,6 +1597,134 @@ __global__ void __launch_bounds__(64) omnibus_c3_search_dump_kernel(const C3Args
     }
 }
 
+// ---- pass B behind the time-split pass A: lockstep rounds on the blocked dump (round 6) ---------------
+// One lane per listed pixel walking its own dates (omnibus_c3_search_dump_kernel<T, 0>, the first form of this
+// round: 0.235 ms on config 4's share) issues, at every step, one instruction whose 64 lanes address 64
+// different lines; the rate at which a CU looks those up bounds such a sweep (the dual-pol twin measured it:
+// DESIGN-EXPERIMENTS.md).  Here the 64 listed pixels of a wave are a BLOCK of the dump -- their series
+// interleaved by groups of four dates and by component -- and the date index is wave-uniform: a round walks the
+// dates from the earliest segment start among the wave's unfinished pixels to the end, nine contiguous kilobytes
+// per group of four dates (the next group in flight), every lane folding from its own segment start on; behind
+// the last date a lane commits the first firing date of its segment if the global test fired
+// (nd/_change.pyx:235-257, one sweep per segment) and starts its next segment there; rounds repeat while a lane
+// has a segment left.  Fold, screen and exact evaluation are omnibus_c3_search_kernel's, operation for operation.
+// The screen of a test is the float32 one of the dual-pol sweeps (x = log2 prod det - j log2 det(sum) relative to the
+// decision point, from exponents and the hardware log2 of the mantissas of the reference's own running values, against
+// the per-j band of make_dense_entry -- p-agnostic): whatever it cannot decide takes the exact evaluation.
+template <typename T>
+__global__ void __launch_bounds__(64) omnibus_c3_search_rounds_kernel(const C3Args<T> s, const DenseScreen fscr)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) unsigned char nd_smem3r[];
+    DenseScreenEntry *scr_f = reinterpret_cast<DenseScreenEntry *>(nd_smem3r);
+    const int lane = threadIdx.x;
+    const int k = s.k;
+    const unsigned shard = blockIdx.x % kC3Shards;
+    const unsigned lblock = blockIdx.x / kC3Shards, nlblock = gridDim.x / kC3Shards;
+    const uint32_t nall = s.flag_count[shard * kC3CounterStride];
+    const uint32_t n = nall < s.dump_cap ? nall : s.dump_cap;            // (dump_cap: a multiple of 64)
+    const uint32_t *list = s.flag_idx + (size_t)shard * s.seg;
+    if (lblock * 64u >= n) return;
+    for (int j = lane; j <= k; j += 64) scr_f[j] = fscr.e[j];
+    __syncthreads();
+    const unsigned G = s.dump_stride / 36u;
+
+    for (uint32_t base = lblock * 64u; base < n; base += nlblock * 64u) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < n;
+        const int64_t pix = active ? (int64_t)list[idx] : 0;
+        // group g, component c of this lane's series: blk[(g * 9 + c) * 64]
+        const f4 *blk = reinterpret_cast<const f4 *>(s.dump) + ((size_t)shard * (s.dump_cap >> 6) + (base >> 6)) * G * 9 * 64 + lane;
+        uint8_t *res = s.change + pix * (int64_t)k;
+        Accum3<T> A;
+        A.reset();
+        int l = 0, fire_at = -1;
+        bool done = !active;
+        while (__any(!done)) {
+            int t0 = done ? k : l;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(t0, off);
+                t0 = o < t0 ? o : t0;
+            }
+            t0 = __builtin_amdgcn_readfirstlane(t0);
+            const int g0 = t0 >> 2, gn = (k + 3) >> 2;
+            bool fires = false;                                  // of the test met at the last date: the global test
+            f4 cur[9], nxt[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) nxt[c] = blk[((size_t)g0 * 9 + c) * 64];
+            for (int gq = g0; gq < gn; ++gq) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) cur[c] = nxt[c];
+                const int gq1 = gq + 1 < gn ? gq + 1 : gq;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) nxt[c] = blk[((size_t)gq1 * 9 + c) * 64];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = 4 * gq + tt;                   // wave-uniform
+                    if (t < k && t >= t0) {
+                        T v[9];
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) v[c] = cur[c][tt];
+                        const bool on = !done && t >= l;
+                        if (on) A.step(v);
+                        const int jj = t - l + 1;
+                        const bool last = (t == k - 1);
+                        const bool need = on && (jj >= 2) && (fire_at < 0 || last);
+                        bool f = false, inband = false;
+                        if (need) {
+                            const T dets = det3<T>(A.s);
+                            const bool ok = (dets > (T)0) & (dets < (T)INFINITY) & __builtin_amdgcn_class(A.prod, 0x100);
+                            const DenseScreenEntry c = scr_f[jj];
+                            int es, eP;
+                            float ms, mP;
+                            log2_parts(ok ? dets : (T)1, es, ms);
+                            log2_parts(ok ? A.prod : 1.0, eP, mP);
+                            const int E = (eP - c.re) - __mul24(jj, es);
+                            const float x = (float)E + __builtin_fmaf(-(float)jj, ms, mP - c.rf);
+                            f = ok & (x < c.a);
+                            inband = !(f | (ok & (x > c.b)));
+                        }
+                        if (__any(inband)) {
+                            if (inband) {
+                                const OmniTabEntry e = s.tab_dev[jj];
+                                const T zp = z_stat3<T>(A, jj, s.nlooks, e);
+                                const double zd = (double)zp;
+                                int verdict = !(zd >= e.zlo) ? 0 : ((zd > e.zhi && zd < INFINITY) ? 1 : 2);
+                                if (verdict == 2) {
+                                    double zv[1] = {zd}, P1[1], P2[1];
+                                    chisq_pair<1>(zv, 9 * (jj - 1), e.lgam, P1, P2);
+                                    const T P = combine_P<T>(P1[0], P2[0], e.omega2);
+                                    verdict = ((double)P > s.alpha) ? 1 : 0;
+                                }
+                                f = (verdict == 1);
+                            }
+                        }
+                        if (need) {
+                            if (f && fire_at < 0) fire_at = t;
+                            if (last) fires = f;
+                        }
+                    }
+                }
+            }
+            if (!done) {
+                if (fires && (k - l) >= 2) {
+                    res[fire_at] = 1;                          // :252
+                    l = fire_at;                               // :255
+                    if (l >= k - 1) {
+                        done = true;                           // :256
+                    } else {
+                        A.reset();
+                        fire_at = -1;
+                    }
+                } else {
+                    done = true;                               // :241-242
+                }
+            }
+        }
+    }
+}
+
 // ---- pass B, one lane per SEGMENT START (short lists behind the streaming search) ------------------
 // The full-pol counterpart of omnibus_c2_search_starts_kernel (omnibus.hip).  What the streaming search
 // hands over are a few thousand pixels of 8 M (2 070 at alpha = 0.01 on config 4's share), nearly every
@@ -1726,7 +1863,7 @@ static C3Workspace c3_layout(int64_t npix, int64_t ny, int64_t k)
     w.off_dump = w.off_idx + align256((size_t)w.seg * kC3Shards * sizeof(uint32_t));
     w.kq = (int)(ceil_div(ceil_div(k, kC3Slices), 4) * 4);
     if (k >= 2 && k <= kC3RetainMaxK) {
-        w.dump_cap = (uint32_t)ceil_div(ceil_div(npix, kC3DumpShare), kC3Shards);
+        w.dump_cap = (uint32_t)(ceil_div(ceil_div(ceil_div(npix, kC3DumpShare), kC3Shards), 64) * 64);   // whole blocks of 64
         w.dump_stride = (uint32_t)(kC3Slices * w.kq * 9);
     } else {
         w.dump_cap = w.dump_stride = 0;
@@ -2016,13 +2153,16 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
                              : (lds_bytes <= 33 * 1024 ? 64 : (lds_bytes <= 66 * 1024 ? 32 : 16));
     const bool halves = use_lds && c3_lanes != 64;
     if (g.dump != nullptr) {
-        // the candidates whose series pass A dumped: one lane per pixel, read where they lie
+        // the candidates whose series pass A dumped from its registers
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, stream);
         int64_t per_shard_d = ceil_div((int64_t)g.dump_cap, 64);
         if (per_shard_d > 64) per_shard_d = 64;
         if (per_shard_d < 1) per_shard_d = 1;
-        hipLaunchKernelGGL((omnibus_c3_search_dump_kernel<T, 0>), dim3((unsigned)(per_shard_d * kC3Shards)), dim3(64),
-                           scr_bytes, stream, g);
+        // lockstep rounds on the blocked dump; the lane-per-pixel form (omnibus_c3_search_dump_kernel<T, 1 / 2>) stays
+        // for pixel-major inputs, whose series are read where they lie
+        const DenseScreen fscr = make_dense_screen<T>(htab, (int)k, n_looks);
+        hipLaunchKernelGGL((omnibus_c3_search_rounds_kernel<T>), dim3((unsigned)(per_shard_d * kC3Shards)), dim3(64),
+                           (size_t)(k + 1) * sizeof(DenseScreenEntry), stream, g, fscr);
         ND_HIP_CHECK(hipGetLastError());
     }
     // ND_AMD_C3_PM_SEARCH=image: the LDS-image search on pixel-major inputs, as before round 6 (A/B)
