@@ -22,7 +22,7 @@ if what == 'c2':
                     ms = t_ms(lambda: kernels.change_detection(st[0], st[1], st[2], st[3], alpha=alpha, n=9, stats=stats), 2)
                     print('c2 %s k=%d 2048x4096 alpha=%g stats=%d: %.2f ms' % (str(dt)[6:], k, alpha, stats, ms), flush=True)
             del st; torch.cuda.empty_cache()
-else:
+if what == 'c3':
     k, ny, nx = 48, 512, 4096
     st = synth.wishart_c3_stack(k, ny, nx, looks=9, seed=2, device=dev, change_frac=0.01)
     for alpha in (0.99, 0.5, 0.01):
