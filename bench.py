@@ -974,14 +974,19 @@ def extras(main, barrier, dev, only=None, light=False):
 
 
 SECONDARY = (('nlm_cc_pm0', 'nlm_pm0'), ('nlm_cc_pm1', 'nlm_pm1'), ('c3_share_a0.99', 'c3_a0.99'),
-             ('pipeline_share', 'pipeline'))
+             ('pipeline_share', 'pipeline'),
+             # the headline stack at the reference's DEFAULT threshold (nd/change.py:32, alpha = 0.01: 99 % of the
+             # pixels change), planar and in the reference's own (y, x, time) layout with C12 complex64 --
+             # the literal drop-in call
+             ('c2_a0.01', 'omnibus_a0.01'), ('c2_yxt_a0.01', 'pm_a0.01'))
 
 
 def secondary(main, barrier, dev):
     """The other BASELINE configs in the driver-run line, compactly: config 3 (non-local
     means 7 x 7 / 21 x 21 on 12t x 4096 x 4096, the reference-compatible and the signed patch distances), one
     GPU's share of config 4 (full-pol C3 48t x 1024 x 8192 at alpha = 0.99) and of config 5 (the tutorial
-    pipeline on 24t x 2048 x 16384 x 4).  -> ({key: [ms_per_step, frac, 'hbm' | 'valu', matches_oracle_on_sample]},
+    pipeline on 24t x 2048 x 16384 x 4); and the headline stack at the reference's default alpha = 0.01,
+    planar and in the reference's (y, x, time) layout.  -> ({key: [ms_per_step, frac, 'hbm' | 'valu', matches_oracle_on_sample]},
     the long entries for bench_detail.json).  frac is of the WHOLE step: algorithmic bytes per step against the
     HBM peak, or the algorithm's dependent float32 additions per step against the packed-add rate."""
     block, long_form = {}, []

@@ -58,7 +58,8 @@ def test_secondary_block_fits_the_drivers_tail():
     import bench
     m = _stub(1)
     m['secondary'] = {'nlm_cc_pm0': [2.112345, 0.4412345, 'valu', True], 'nlm_cc_pm1': [41.81234, 0.404123, 'valu', True],
-                      'c3_share_a0.99': [2.851234, 0.661234, 'hbm', True], 'pipeline_share': [14.85912, 0.494123, 'valu', True]}
+                      'c3_share_a0.99': [2.851234, 0.661234, 'hbm', True], 'pipeline_share': [14.85912, 0.494123, 'valu', True],
+                      'c2_a0.01': [1.395912, 0.612345, 'hbm', True], 'c2_yxt_a0.01': [1.612123, 0.530123, 'hbm', True]}
     text = bench.emit(bench.headline(m))
     assert len(text.encode()) < 1900, len(text)
     line = json.loads(text)

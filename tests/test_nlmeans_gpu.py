@@ -339,6 +339,33 @@ def test_window_kernels_with_nodata(oracle, device):
             np.testing.assert_allclose(got[ok], want[ok], rtol=RTOL)
 
 
+def test_signed_mode_far_on_the_no_solution_side(oracle, device):
+    """n_eff beyond what the neighbours can give (n_eff - 1 > W^2 / W2 at every pixel: find_weight raises at each,
+    the reference's self weight is 0 under neff_policy 0).  The tiled kernels keep those pixels in the fast path
+    when the verdict is more than 5 % clear (round 6; before, every pixel was recomputed one by one) and send the
+    neighbourhood of the boundary to the exact path: n_eff = 60 / 26 with 48 neighbours covers both, as do the
+    3-D search (146 neighbours) and the f = 0 kernel."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(191)
+    a = rng.gamma(4.0, 0.25, (4, 37, 141, 2)).astype(np.float32)          # (t, y, x, var)
+    planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)
+    for r, f, ne in (((0, 3, 3), (0, 1, 1), 60.0), ((0, 3, 3), (0, 1, 1), 26.0), ((0, 3, 3), (0, 0, 0), 60.0),
+                     ((1, 3, 3), (1, 1, 1), 200.0), ((1, 3, 3), (0, 1, 1), 75.0)):
+        want = np.empty_like(a)
+        oracle.pixelwise_nlmeans_3d(a, want, r, f, 0.5, 0.5, ne, neff_policy=0, njobs=8, patch_mode=1)
+        out = torch.empty_like(planar)
+        kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, 0.5, 0.5, ne,
+                                     patch_mode=1, neff_policy=0)
+        torch.cuda.synchronize()
+        got = out.permute(1, 2, 3, 0).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=str((r, f, ne)))
+    # neff_policy 1: the reference's ValueError
+    with pytest.raises(ValueError, match='No solution'):
+        kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), (0, 3, 3), (0, 1, 1), 0.5, 0.5,
+                                     60.0, patch_mode=1, neff_policy=1)
+
+
 def test_one_column_patch_kernel_forced(tmp_path):
     """The one-column-per-lane patch kernel normally serves only f = 0 and tiles beyond 150 KB of
     LDS; forced for every signed-mode case (ND_AMD_NLM_PATCH1, read once per process, hence the one
