@@ -21,6 +21,27 @@ def kernel_stats(d):
     return [r for r in csv.DictReader(open(f)) if 'nd_amd' in r['Name']]
 
 
+def kernel_trace_split(d):
+    """{kernel name: (n_gated, avg_us_gated, n_working, avg_us_working)} for the kernels whose launches are of two
+    kinds -- the device-side gate (omni_gate_skip: both forms of a call are launched, the unfavoured one returns at
+    once) makes launches of a few microseconds of kernels that otherwise take a millisecond, and one average over
+    both says nothing.  From the per-dispatch trace; a launch counts as gated below a tenth of the longest."""
+    fs = glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*kernel_trace.csv')
+    if not fs:
+        return {}
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if 'nd_amd' in r['Kernel_Name']:
+            acc[r['Kernel_Name']].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3)
+    out = {}
+    for k, v in acc.items():
+        cut = 0.1 * max(v)
+        lo, hi = [x for x in v if x < cut], [x for x in v if x >= cut]
+        if lo and hi and max(v) > 100.0:
+            out[k] = (len(lo), sum(lo) / len(lo), len(hi), sum(hi) / len(hi))
+    return out
+
+
 def pmc(d, counter):
     f = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*counter_collection.csv'))[0]
     acc = collections.defaultdict(list)
@@ -39,6 +60,14 @@ def main():
         lines.append('%-86s %6s %12.1f %12.1f %12.1f' % (
             r['Name'].split('(')[0][-86:], r['Calls'], float(r['AverageNs']) / 1e3,
             float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3))
+    split = kernel_trace_split(dstats)
+    if split:
+        lines.append('')
+        lines.append('kernels launched both as the working form and as the form the device-side gate sends back at once')
+        lines.append('(the secondary block runs the headline stack at alpha = 0.01, where the sparse pass A is launched and returns):')
+        lines.append('%-86s %6s %12s %8s %12s' % ('kernel', 'calls', 'avg_us', 'gated', 'avg_us'))
+        for k, (nl, al, nh, ah) in split.items():
+            lines.append('%-86s %6d %12.1f %8d %12.1f' % (k.split('(')[0][-86:], nh, ah, nl, al))
     lines.append('')
     lines.append('--pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), averages per launch:')
     fe, wr = pmc(dfetch, 'FETCH_SIZE'), pmc(dwrite, 'WRITE_SIZE')
