@@ -364,11 +364,19 @@ omnibus_c2_retain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab)
 //   * a determinant that is NaN or exactly 0 makes the whole-series statistic NaN or infinite: no change
 //     anywhere, not listed (as the plain screen does not list it).
 // -----------------------------------------------------------------------------------------
-template <typename T, int KQ, int NS>
+// STATS (round 6, later): the z / P rasters of the whole-series test from the same launch.  They are the reference's
+// FORWARD fold (nd/_change.pyx:53-77: four sums in `floating`, the double product, date by date) -- not the
+// re-associated sums of the screen -- so the fold is handed from wave to wave through LDS in time order, bit for bit
+// (six instructions per date, one wave after the other: about a microsecond per block), and the last slice's wave
+// evaluates z_stat / chisq_pair / combine_P exactly as omnibus_c2_retain_kernel<..., STATS> does: the rasters are
+// identical to those of every other form.  (Before: a call with rasters took the plain pass A and the gather.)
+template <typename T, int KQ, int NS, bool STATS = false>
 __global__ void __launch_bounds__(64 * NS)
 omnibus_c2_split_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const float retain_rel)
 {
     __shared__ T part_s[NS][4][64];
+    __shared__ T fwd_s[STATS ? 4 : 1][64];
+    __shared__ double fwd_p[64];
     __shared__ double part_p[NS][64];
     __shared__ int part_e[NS][3][64];              // lowest / highest exponent of the slice's running product, flags
     __shared__ unsigned long long flag_mask;
@@ -513,6 +521,35 @@ omnibus_c2_split_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const floa
         }
     }
     __syncthreads();
+    // STATS: the reference's forward fold, slice after slice
+    Accum<T> W;
+    W.reset();
+    const bool last_slice = t_lo < k && t_lo + KQ >= k;
+    if (STATS) {
+#pragma unroll 1
+        for (int sl = 0; sl < NS; ++sl) {
+            if (w == sl && t_lo < k) {
+                if (sl > 0) {
+                    W.s11 = fwd_s[0][lane];
+                    W.s12r = fwd_s[1][lane];
+                    W.s12i = fwd_s[2][lane];
+                    W.s22 = fwd_s[3][lane];
+                    W.prod = fwd_p[lane];
+                }
+#pragma unroll
+                for (int tt = 0; tt < KQ; ++tt)
+                    if (t_lo + tt < k) W.step(v[tt][0], v[tt][1], v[tt][2], v[tt][3]);
+                if (!last_slice) {
+                    fwd_s[0][lane] = W.s11;
+                    fwd_s[1][lane] = W.s12r;
+                    fwd_s[2][lane] = W.s12i;
+                    fwd_s[3][lane] = W.s22;
+                    fwd_p[lane] = W.prod;
+                }
+            }
+            __syncthreads();
+        }
+    }
     // a candidate's slice leaves the registers: one 16-byte store per date
     const unsigned long long m = flag_mask;
     if (m != 0ull && t_lo < k) {
@@ -534,6 +571,19 @@ omnibus_c2_split_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const floa
                     *reinterpret_cast<Pack<T, 4> *>(dptr + (int64_t)tt * 256) = q;
                 }
             }
+        }
+    }
+    // (behind the dump: the series is dead here, the chi-square series have the registers to themselves)
+    if (STATS && last_slice) {
+        __builtin_amdgcn_sched_barrier(0);
+        const T z = z_stat<T>(W, k, g.nlooks, g.e);
+        double zd[1] = {(double)z}, P1[1], P2[1];
+        chisq_pair<1>(zd, 4 * (k - 1), g.e.lgam, P1, P2);
+        const T P = combine_P<T>(P1[0], P2[0], g.e.omega2);
+        if (in) {
+            const int64_t pix = row * g.nx + x0;
+            if (g.z_out) g.z_out[pix] = z;
+            if (g.p_out) g.p_out[pix] = P;
         }
     }
 }
@@ -3398,7 +3448,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const char *e = getenv("ND_AMD_C2_SPLIT");
         return e ? atoi(e) != 0 : true;
     }();
-    const bool split_ok = split_env && search_fs_enabled() && !retain && !stream_long && !stats &&
+    // ND_AMD_C2_SPLIT_STATS=0: with rasters the plain pass A and the gather, as before
+    static const bool split_stats_env = [] {
+        const char *e = getenv("ND_AMD_C2_SPLIT_STATS");
+        return e ? atoi(e) != 0 : true;
+    }();
+    // (float64 beyond 48 dates -- eight slices of doubles in turn -- measured slower with the rasters than the
+    //  plain pass A and the gather: 3.65 against 3.43 ms on 96 x 1024 x 4096)
+    const bool split_stats_ok = split_stats_env && !(sizeof(T) == 8 && k > 48);
+    const bool split_ok = split_env && search_fs_enabled() && !retain && !stream_long && (!stats || split_stats_ok) &&
                           k <= (sizeof(T) == 4 ? 192 : 96) && pm_ids == nullptr && mlp == nullptr && sx == 1;
     // The threshold only says that dense waves are LIKELY; whether they are is a property of the
     // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
@@ -4115,8 +4173,14 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const float rel = 3.f * (5.f * (float)k + 8.f) * (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f);
         const dim3 grid((unsigned)nbs);
 #define ND_LAUNCH_SPLIT(TT_, KQ_, NS_)                                                                         \
-    hipLaunchKernelGGL((omnibus_c2_split_kernel<TT_, KQ_, NS_>), grid, dim3(64 * NS_), 0, stream,               \
-                       reinterpret_cast<const OmniGlobalArgs<TT_> &>(g), tab, rel)
+    do {                                                                                                       \
+        if (stats)                                                                                             \
+            hipLaunchKernelGGL((omnibus_c2_split_kernel<TT_, KQ_, NS_, true>), grid, dim3(64 * NS_), 0, stream, \
+                               reinterpret_cast<const OmniGlobalArgs<TT_> &>(g), tab, rel);                     \
+        else                                                                                                   \
+            hipLaunchKernelGGL((omnibus_c2_split_kernel<TT_, KQ_, NS_, false>), grid, dim3(64 * NS_), 0, stream, \
+                               reinterpret_cast<const OmniGlobalArgs<TT_> &>(g), tab, rel);                     \
+    } while (0)
         if constexpr (std::is_same<T, float>::value) {
             // 4 KQ registers per lane: four waves up to 96 dates, eight beyond
             const int ns = k <= 96 ? 4 : 8;

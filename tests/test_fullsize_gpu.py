@@ -304,13 +304,15 @@ def test_chain_form_series_lengths():
             assert 'omnibus_c2_fused' in r['kernels_ms'], (label, r)
 
 
-@pytest.mark.parametrize('dtype,k', [('float32', 40), ('float64', 24), ('float32', 80)])
+@pytest.mark.parametrize('dtype,k', [('float32', 40), ('float64', 24), ('float32', 80), ('float64', 40), ('float32', 112)])
 def test_long_series_statistics_at_scale(oracle, dtype, k):
     """Series beyond the register forms on a raster large enough for the device-side density gate:
     the map of the streaming search (64- / 128-bit masks) equals the oracle on sampled pixels and
     whole rows, asking for the z / P rasters does not change it, and the rasters themselves do not
-    depend on the threshold, bit for bit (the chain form's forward pass below the sparse regime, the plain
-    pass A in it: the same fold and the same chi-square evaluation)."""
+    depend on the threshold, bit for bit (the chain form's forward pass below the sparse regime; in it the
+    register-retaining pass A or -- 80 / 112 float32 and 40 float64 dates -- the time-split pass A, whose
+    waves hand the reference's forward fold from slice to slice: the same fold and the same chi-square
+    evaluation)."""
     import torch
     from nd_amd import kernels, synth as dsynth
     from oracle import checks
