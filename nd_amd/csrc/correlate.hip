@@ -1365,9 +1365,10 @@ __device__ __forceinline__ int extend_line32(int cc, int len, int mode)      // 
     return m < 0 ? 0 : (m >= len ? len - 1 : m);
 }
 
+template <typename T>
 struct Corr2PassArgs {
-    const float *in;
-    float *out;
+    const T *in;
+    T *out;
     int64_t ny, nx;
     int64_t sin_b, sin_y, sout_b, sout_y;
     int mode;
@@ -1386,9 +1387,28 @@ __device__ __forceinline__ float f32_from_next(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xF, 0xF, true));
 }
 
-template <int R, bool DWIN>
-__global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs a)
+// float64 planes (round 6): the same kernel on doubles -- a lane's four columns are two 16-byte loads, the
+// intermediate array is float64 itself (scipy rounds it to the ARRAY dtype), a value crosses lanes as two DPP moves.
+__device__ __forceinline__ double f32_from_prev(double x)
 {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x138, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x138, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double f32_from_next(double x)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x130, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x130, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <typename T, int R, bool DWIN>
+__global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs<T> a)
+{
+    static_assert(sizeof(T) == 4 || !DWIN, "float64 rows are their own window");
+    constexpr int ES = (int)sizeof(T);
     constexpr int FEED = (R + 3) / 4;               // feeder lanes at either end of the wave
     constexpr int NY = 2 * R + 1, PD = 3;
     // DWIN: the window of 2 R + 1 rows is kept as float64 (a row is converted once, when it enters
@@ -1411,25 +1431,42 @@ __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs
 
     int xm[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xm[c] = 4 * extend_line32(x + c, nx, a.mode);
+    for (int c = 0; c < 4; ++c) xm[c] = ES * extend_line32(x + c, nx, a.mode);
     const bool inside = x >= 0 && x + 3 < nx;
     const bool wave_vec = a.vec_in && __builtin_amdgcn_ballot_w64(!inside) == 0ull;
-    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + plane * a.sin_b), 0,
+    const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(a.in + plane * a.sin_b), 0,
                                                        0x7fffffff, 0x00020000);
     const auto rout = __builtin_amdgcn_make_buffer_rsrc(a.out + plane * a.sout_b, 0, 0x7fffffff,
                                                         0x00020000);
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef T f32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
     auto load_row = [&](int t) -> f32x4 {            // input row of step t: ys - R + t
         const int m = extend_line32(ys - R + t, ny, a.mode);
-        const int soff = __builtin_amdgcn_readfirstlane(m * (int)a.sin_y * 4);
+        const int soff = __builtin_amdgcn_readfirstlane(m * (int)a.sin_y * ES);
         f32x4 v;
-        if (wave_vec) {
-            v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xm[0], soff, 0));
-        } else {
+        if constexpr (sizeof(T) == 4) {
+            if (wave_vec) {
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xm[0], soff, 0));
+            } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, xm[c], soff, 0));
+                for (int c = 0; c < 4; ++c)
+                    v[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, xm[c], soff, 0));
+            }
+        } else {
+            if (wave_vec) {
+                const f64x2 lo = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rin, xm[0], soff, 0));
+                const f64x2 hi = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rin, xm[0] + 16, soff, 0));
+                v[0] = lo[0];
+                v[1] = lo[1];
+                v[2] = hi[0];
+                v[3] = hi[1];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    v[c] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rin, xm[c], soff, 0));
+            }
         }
         return v;
     };
@@ -1458,7 +1495,7 @@ __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs
                 }
                 if (t >= 2 * R) {
                     // ---- pass along y on this lane's four columns: rows t - 2R .. t, centre t - R
-                    float ty[4];
+                    T ty[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         double o;
@@ -1475,14 +1512,14 @@ __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs
                                 o = o + ((double)ring[(pu + 2 * RING - R - d) % RING][c] +
                                          (double)ring[(pu + RING - R + d) % RING][c]) * a.wy[d];
                         }
-                        ty[c] = (float)o;           // the intermediate array, in the array dtype
+                        ty[c] = (T)o;               // the intermediate array, in the array dtype
                     }
                     // ---- pass along x: R values from either side through the neighbouring lanes
                     double ax[4 + 2 * R];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) ax[R + c] = (double)ty[c];
                     {
-                        float pl[4], nr[4];
+                        T pl[4], nr[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             pl[c] = f32_from_prev(ty[c]);
@@ -1502,26 +1539,40 @@ __global__ void __launch_bounds__(256) correlate1d_yx_kernel(const Corr2PassArgs
                             }
                         }
                     }
-                    float res[4];
+                    T res[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         double o = ax[R + c] * a.wx[0];
 #pragma unroll
                         for (int d = R; d >= 1; --d) o = o + (ax[R + c - d] + ax[R + c + d]) * a.wx[d];
-                        res[c] = (float)o;
+                        res[c] = (T)o;
                     }
                     const int y = ys + t - 2 * R;
-                    const int ooff = __builtin_amdgcn_readfirstlane(y * (int)a.sout_y * 4);
+                    const int ooff = __builtin_amdgcn_readfirstlane(y * (int)a.sout_y * ES);
                     if (writer) {
-                        if (store_vec) {
-                            const f32x4 o4 = {res[0], res[1], res[2], res[3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rout, x * 4, ooff, ND_CORR_ST_AUX);
-                        } else {
+                        if constexpr (sizeof(T) == 4) {
+                            if (store_vec) {
+                                const f32x4 o4 = {res[0], res[1], res[2], res[3]};
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rout, x * 4, ooff, ND_CORR_ST_AUX);
+                            } else {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                if (x + c < nx)
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[c]), rout,
-                                                                          (x + c) * 4, ooff, 0);
+                                for (int c = 0; c < 4; ++c)
+                                    if (x + c < nx)
+                                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[c]), rout,
+                                                                              (x + c) * 4, ooff, 0);
+                            }
+                        } else {
+                            if (store_vec) {
+                                const f64x2 lo = {res[0], res[1]}, hi = {res[2], res[3]};
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rout, x * 8, ooff, ND_CORR_ST_AUX);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rout, x * 8 + 16, ooff, ND_CORR_ST_AUX);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (x + c < nx)
+                                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, res[c]), rout,
+                                                                              (x + c) * 8, ooff, 0);
+                            }
                         }
                     }
                 }
@@ -1569,11 +1620,14 @@ extern "C" int nd_amd_correlate1d_yx(const void *in, void *out, int dtype, const
     const int R = nweights / 2;
     const int64_t *si = in_strides, *so = out_strides;
     const int64_t ny = dims[2], nx = dims[3];
-    bool fits = !disabled && dtype == ND_AMD_F32 && mode != ND_AMD_MODE_CONSTANT && (nweights & 1) &&
+    const int64_t es = dtype == ND_AMD_F64 ? 8 : 4;
+    static const bool no_f64 = getenv("ND_AMD_YX_F64") != nullptr && atoi(getenv("ND_AMD_YX_F64")) == 0;
+    bool fits = !disabled && (dtype == ND_AMD_F32 || (dtype == ND_AMD_F64 && !no_f64)) && mode != ND_AMD_MODE_CONSTANT &&
+                (nweights & 1) &&
                 R >= 1 && R <= 8 && R != 7 && corr1d_symmetric(weights_y, nweights) &&
                 corr1d_symmetric(weights_x, nweights) && si[3] == 1 && so[3] == 1 && si[2] >= 0 &&
                 so[2] >= 0 && ny <= 0x3fffffff && nx <= 0x3fffffff && nx >= 8 &&
-                (ny * si[2] + nx) * 4 < 0x7fffffffLL && (ny * so[2] + nx) * 4 < 0x7fffffffLL;
+                (ny * si[2] + nx) * es < 0x7fffffffLL && (ny * so[2] + nx) * es < 0x7fffffffLL;
     int64_t nb = dims[0] * dims[1], sbi = 0, sbo = 0;
     if (dims[0] == 1) {
         sbi = si[1];
@@ -1588,65 +1642,84 @@ extern "C" int nd_amd_correlate1d_yx(const void *in, void *out, int dtype, const
         fits = false;
     }
     if (!fits) {
-        set_error("nd_amd_correlate1d_yx: not a case of the fused kernel (float32, x-contiguous planes, "
+        set_error("nd_amd_correlate1d_yx: not a case of the fused kernel (float32 / float64, x-contiguous planes, "
                   "symmetric kernels of one radius 1..6 or 8, no constant mode): run two nd_amd_correlate1d passes");
         return ND_AMD_EUNSUPPORTED;
     }
-    Corr2PassArgs a;
-    a.in = static_cast<const float *>(in);
-    a.out = static_cast<float *>(out);
-    a.ny = ny;
-    a.nx = nx;
-    a.sin_b = sbi;
-    a.sin_y = si[2];
-    a.sout_b = sbo;
-    a.sout_y = so[2];
-    a.mode = mode;
-    a.nbatch = nb;
     const int feed = (R + 3) / 4, sw = (64 - 2 * feed) * 4;
-    a.nstrips = (int)ceil_div(nx, sw);
+    const int nstrips = (int)ceil_div(nx, sw);
     // rows per wave: the 2 R rows read ahead of the first output are re-read by the next chunk
     int64_t rpc = R >= 3 ? 128 : 64;
-    while (rpc > 16 && (int64_t)a.nstrips * ceil_div(ny, rpc) * nb < 12288) rpc /= 2;
+    while (rpc > 16 && (int64_t)nstrips * ceil_div(ny, rpc) * nb < 12288) rpc /= 2;
     static const int rpc_env = getenv("ND_AMD_YX_RPC") ? atoi(getenv("ND_AMD_YX_RPC")) : 0;
     if (rpc_env > 0) rpc = rpc_env;
-    a.rows_per_chunk = (int)rpc;
-    a.nchunks = (int)ceil_div(ny, rpc);
-    a.vec_in = (((uintptr_t)in & 15) == 0 && (sbi & 3) == 0 && (si[2] & 3) == 0) ? 1 : 0;
-    a.vec_out = (((uintptr_t)out & 15) == 0 && (sbo & 3) == 0 && (so[2] & 3) == 0) ? 1 : 0;
-    for (int d = 0; d < 9; ++d) {
-        // NI_Correlate1D's symmetric form reads the weights left of the centre: fw[j], j < 0
-        a.wy[d] = d <= R ? weights_y[R - d] : 0.0;
-        a.wx[d] = d <= R ? weights_x[R - d] : 0.0;
-    }
-    const int64_t nwaves = (int64_t)a.nstrips * a.nchunks * nb;
+    const int nchunks = (int)ceil_div(ny, rpc);
+    const int64_t nwaves = (int64_t)nstrips * nchunks * nb;
     const int64_t nblocks = ceil_div(nwaves, 4);
     if (nblocks > 0x7fffffffLL) {
         set_error("nd_amd_correlate1d_yx: array too large for one launch");
         return ND_AMD_EUNSUPPORTED;
     }
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    auto fill = [&](auto &a) {
+        a.ny = ny;
+        a.nx = nx;
+        a.sin_b = sbi;
+        a.sin_y = si[2];
+        a.sout_b = sbo;
+        a.sout_y = so[2];
+        a.mode = mode;
+        a.nbatch = nb;
+        a.nstrips = nstrips;
+        a.rows_per_chunk = (int)rpc;
+        a.nchunks = nchunks;
+        a.vec_in = (((uintptr_t)in & 15) == 0 && (sbi & 3) == 0 && (si[2] & 3) == 0) ? 1 : 0;
+        a.vec_out = (((uintptr_t)out & 15) == 0 && (sbo & 3) == 0 && (so[2] & 3) == 0) ? 1 : 0;
+        for (int d = 0; d < 9; ++d) {
+            // NI_Correlate1D's symmetric form reads the weights left of the centre: fw[j], j < 0
+            a.wy[d] = d <= R ? weights_y[R - d] : 0.0;
+            a.wx[d] = d <= R ? weights_x[R - d] : 0.0;
+        }
+    };
     {
         KernelTimer timer(ND_AMD_KERNEL_CORRELATE1D, stream);
         const dim3 grid((unsigned)nblocks), block(256);
-        static const int dwin_env = getenv("ND_AMD_YX_DWIN") ? atoi(getenv("ND_AMD_YX_DWIN")) : -1;
-        // measured on 24 x 4096 x 4096 (tools/exp_gauss_yx.py): the float64 window wins from radius 6
-        // (sigma 1.5: 0.90 -> 0.85 ms, sigma 2: 1.14 -> 0.98 ms) and loses below (registers: 118 vs 82
-        // at radius 4)
-        const bool dw = dwin_env >= 0 ? dwin_env != 0 : R >= 6;
+        if (dtype == ND_AMD_F64) {
+            Corr2PassArgs<double> a;
+            a.in = static_cast<const double *>(in);
+            a.out = static_cast<double *>(out);
+            fill(a);
+#define ND_YX64(RR)                                                                                  \
+    case RR: hipLaunchKernelGGL((correlate1d_yx_kernel<double, RR, false>), grid, block, 0, stream, a); break;
+            switch (R) {
+                ND_YX64(1) ND_YX64(2) ND_YX64(3) ND_YX64(4) ND_YX64(5) ND_YX64(6)
+            default: hipLaunchKernelGGL((correlate1d_yx_kernel<double, 8, false>), grid, block, 0, stream, a); break;
+            }
+#undef ND_YX64
+        } else {
+            Corr2PassArgs<float> a;
+            a.in = static_cast<const float *>(in);
+            a.out = static_cast<float *>(out);
+            fill(a);
+            static const int dwin_env = getenv("ND_AMD_YX_DWIN") ? atoi(getenv("ND_AMD_YX_DWIN")) : -1;
+            // measured on 24 x 4096 x 4096 (tools/exp_gauss_yx.py): the float64 window wins from radius 6
+            // (sigma 1.5: 0.90 -> 0.85 ms, sigma 2: 1.14 -> 0.98 ms) and loses below (registers: 118 vs 82
+            // at radius 4)
+            const bool dw = dwin_env >= 0 ? dwin_env != 0 : R >= 6;
 #define ND_YX(RR)                                                                                  \
     case RR:                                                                                       \
-        if (dw) hipLaunchKernelGGL((correlate1d_yx_kernel<RR, true>), grid, block, 0, stream, a);   \
-        else hipLaunchKernelGGL((correlate1d_yx_kernel<RR, false>), grid, block, 0, stream, a);     \
+        if (dw) hipLaunchKernelGGL((correlate1d_yx_kernel<float, RR, true>), grid, block, 0, stream, a);   \
+        else hipLaunchKernelGGL((correlate1d_yx_kernel<float, RR, false>), grid, block, 0, stream, a);     \
         break;
-        switch (R) {
-            ND_YX(1) ND_YX(2) ND_YX(3) ND_YX(4) ND_YX(5) ND_YX(6)
-        default:
-            if (dw) hipLaunchKernelGGL((correlate1d_yx_kernel<8, true>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((correlate1d_yx_kernel<8, false>), grid, block, 0, stream, a);
-            break;
-        }
+            switch (R) {
+                ND_YX(1) ND_YX(2) ND_YX(3) ND_YX(4) ND_YX(5) ND_YX(6)
+            default:
+                if (dw) hipLaunchKernelGGL((correlate1d_yx_kernel<float, 8, true>), grid, block, 0, stream, a);
+                else hipLaunchKernelGGL((correlate1d_yx_kernel<float, 8, false>), grid, block, 0, stream, a);
+                break;
+            }
 #undef ND_YX
+        }
     }
     ND_HIP_CHECK(hipGetLastError());
     return ND_AMD_OK;

@@ -591,11 +591,11 @@ def _gaussian_kernel1d(sigma, radius):
 
 
 def _gaussian_yx_fused(inp, out, axes, nd, mode, truncate):
-    """The common GaussianFilter(dims=('y', 'x')) case on x-contiguous float32 planes: both passes
-    in one kernel (nd_amd_correlate1d_yx), the intermediate rounded to float32 like scipy's.
+    """The common GaussianFilter(dims=('y', 'x')) case on x-contiguous float32 / float64 planes: both
+    passes in one kernel (nd_amd_correlate1d_yx), the intermediate in the array dtype like scipy's.
     Returns False when the request is not one the fused kernel takes."""
     if (len(axes) != 2 or [ax for ax, _ in axes] != [nd - 2, nd - 1] or nd > 4
-            or inp.dtype != torch.float32 or mode not in _lib.MODES or mode == 'constant'
+            or inp.dtype not in (torch.float32, torch.float64) or mode not in _lib.MODES or mode == 'constant'
             or inp.stride(-1) != 1 or out.stride(-1) != 1 or inp.data_ptr() == out.data_ptr()
             or inp.shape != out.shape or inp.device != out.device):
         return False

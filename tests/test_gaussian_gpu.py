@@ -62,22 +62,24 @@ def test_gaussian_filter_class(device):
         np.testing.assert_allclose(a[v].values, out[v].values, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize('npdt', [np.float32, np.float64])
 @pytest.mark.parametrize('mode', ['reflect', 'nearest', 'mirror', 'wrap'])
-def test_fused_y_then_x_kernel(device, mode):
-    """GaussianFilter(dims=('y', 'x')) on x-contiguous float32 planes runs both passes in one
+def test_fused_y_then_x_kernel(device, mode, npdt):
+    """GaussianFilter(dims=('y', 'x')) on x-contiguous float32 / float64 planes runs both passes in one
     kernel (nd_amd_correlate1d_yx); every radius it is instantiated for, strip borders (248 / 240
     written columns per wave), planes shorter than the kernel, unaligned pitches, non-finite
-    values -- bit-equal to scipy, whose intermediate array is float32 too."""
+    values -- bit-equal to scipy, whose intermediate array is in the array dtype too."""
     import scipy.ndimage as ndi
     import torch
     from nd_amd import kernels
     rng = np.random.default_rng(41)
+    tdt = torch.float32 if npdt == np.float32 else torch.float64
     for shape in [(2, 70, 248), (1, 40, 249), (3, 5, 500), (1, 3, 9), (2, 140, 8), (1, 33, 1003), (2, 9, 241)]:
-        a = rng.normal(size=shape).astype(np.float32)
+        a = rng.normal(size=shape).astype(npdt)
         for sigma in (0.3, 0.5, 0.75, 1.0, 1.25, 1.5, 2.0):         # radii 1, 2, 3, 4, 5, 6, 8
             np.testing.assert_array_equal(_gpu_gauss(a, (0, sigma, sigma), device, mode=mode),
                                           ndi.gaussian_filter(a, (0, sigma, sigma), mode=mode))
-    a = rng.normal(size=(2, 60, 300)).astype(np.float32)
+    a = rng.normal(size=(2, 60, 300)).astype(npdt)
     # different sigmas with one radius (fused), with different radii (two passes), truncate
     for sigma, tr in (((0, 1.0, 1.1), 4.0), ((0, 1.0, 2.0), 4.0), ((0, 1.6, 1.6), 2.0)):
         np.testing.assert_array_equal(_gpu_gauss(a, sigma, device, mode=mode, truncate=tr),
@@ -92,9 +94,9 @@ def test_fused_y_then_x_kernel(device, mode):
     np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
     np.testing.assert_array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
     # views with odd pitches in and out
-    base = torch.from_numpy(rng.normal(size=(2, 50, 263)).astype(np.float32)).to(device)
+    base = torch.from_numpy(rng.normal(size=(2, 50, 263)).astype(npdt)).to(device)
     view = base[:, 3:47, 1:260]
-    obuf = torch.empty((2, 44, 261), dtype=torch.float32, device=device)
+    obuf = torch.empty((2, 44, 261), dtype=tdt, device=device)
     out = obuf[:, :, :259]
     kernels.gaussian_filter(view, (0, 1, 1), out=out, mode=mode)
     torch.cuda.synchronize()
