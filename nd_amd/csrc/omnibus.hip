@@ -1612,7 +1612,9 @@ struct PlaneReader {
 // MW: width of the six test masks and of the change mask -- 0: 32 bits (k <= 32), 1: 64 bits
 // (k <= 64), 2: two 64-bit words (k <= 128; the screen's entries 65 .. 128 then sit in a second
 // set of registers, the sum of the mantissa logs is 64 bits wide)
-constexpr int stream_nj(const int MW) { return MW == 0 ? 32 : (MW == 1 ? 64 : kDenseMax); }
+// (MW = 3, round 6: 129 .. 192 dates, the two-pass chain search only)
+constexpr int kStreamChainMax = 192;
+constexpr int stream_nj(const int MW) { return MW == 0 ? 32 : (MW == 1 ? 64 : (MW == 2 ? kDenseMax : kStreamChainMax)); }
 
 template <typename T, int PF, int MODE, int MW = 0>
 __global__ void __launch_bounds__(MODE == 2 ? 64 : kRetainThreads)
@@ -2190,8 +2192,8 @@ omnibus_c2_stream_chain_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, con
     static_assert(MODE == 0 || MODE == 1, "planar inputs");
     if (omni_gate_skip(g)) return;
     constexpr int kMaxDates = stream_nj(MW);
-    typedef typename std::conditional<MW == 2, Bits128,
-                                      typename std::conditional<MW == 1, unsigned long long, unsigned>::type>::type MT;
+    typedef typename std::conditional<MW == 3, Bits192, typename std::conditional<MW == 2, Bits128,
+                                      typename std::conditional<MW == 1, unsigned long long, unsigned>::type>::type>::type MT;
     __shared__ StreamEntry tab_lds[kMaxDates + 1];
     __shared__ __align__(16) uint32_t out_img[(kRetainThreads / 64) * 16 * kMaxDates];
     const int tid = threadIdx.x;
@@ -2883,11 +2885,11 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
     const int lane = threadIdx.x;
     const int k = s.k;
     const int ns = k - 1;                       // segment starts per pixel: 0 .. k - 2
-    // up to 64 starts: 64 / ns pixels per wave, one start per lane; 65 .. 128 starts (series of up
-    // to 129 dates): one pixel per wave, lane l takes the starts l and l + 64, one after the other
+    // up to 64 starts: 64 / ns pixels per wave, one start per lane; 65 .. 192 starts (series of up
+    // to 193 dates): one pixel per wave, lane l takes the starts l, l + 64 (and l + 128), one after the other
     const int ppw = ns <= 64 ? 64 / ns : 1;     // pixels per wave
     const int nsw = ns <= 64 ? ns : 64;         // lanes per pixel
-    const int nsweep = ns <= 64 ? 1 : 2;
+    const int nsweep = ns <= 64 ? 1 : (ns <= 128 ? 2 : 3);
     const int grp = lane / nsw;
     const int l0 = lane - grp * nsw;
     const unsigned shard = blockIdx.x % kShards;
@@ -2946,7 +2948,7 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
             }
             return q;
         };
-        int nxt_a = -1, nxt_b = -1;             // per sweep: the next segment start, or stop
+        int nxt_a = -1, nxt_b = -1, nxt_c = -1; // per sweep: the next segment start, or stop
         for (int sweep = 0; sweep < nsweep; ++sweep) {
         const int l = l0 + 64 * sweep;
         const bool lact = active && l < ns;
@@ -3009,15 +3011,15 @@ __global__ void __launch_bounds__(64) omnibus_c2_search_starts_kernel(const Omni
                 if (on && last && fires) nxt = fire_at;      // the global test of ts[l:] fired (jj >= 2 here)
             }
         }
-        if (sweep == 0) nxt_a = nxt; else nxt_b = nxt;
+        if (sweep == 0) nxt_a = nxt; else if (sweep == 1) nxt_b = nxt; else nxt_c = nxt;
         }
         // follow the chain from l = 0; the group's first lane writes the changes
         int at = 0;
         for (int step = 0; step < ns; ++step) {
             const int ats = (at >= 0 && at < ns) ? at : 0;
             const int src = grp * nsw + (ats & 63) % nsw;
-            const int na = __shfl(nxt_a, src), nb = __shfl(nxt_b, src);
-            const int n1 = (ns > 64 && ats >= 64) ? nb : na;
+            const int na = __shfl(nxt_a, src), nb = __shfl(nxt_b, src), nc = __shfl(nxt_c, src);
+            const int n1 = (ns > 64 && ats >= 128) ? nc : ((ns > 64 && ats >= 64) ? nb : na);
             if (at >= 0 && at < ns) {
                 if (n1 < 0) {
                     at = -1;                                   // :241-242
@@ -3423,7 +3425,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // Series beyond the register forms (33 .. 128 dates; float64: 17 .. 128): the streaming search with
     // 64- or 128-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
     // (k = 48 at alpha = 0.01: 118 ms per 16.7 Mpx).
-    const bool stream_long = !dense_ok && pm_ids == nullptr && mlp == nullptr && k <= kDenseMax &&
+    // (round 6, later) 129 .. 192 dates: the chain search in two streaming passes with three-word masks -- before,
+    // every pixel of a low-threshold run on such a series went through pass B (136 dates x 512 x 4096 at the
+    // reference's default alpha = 0.01: 340 ms; 128 dates: 2.3 ms).  ND_AMD_STREAM_CHAIN_192=0: as before.
+    static const bool chain192_env = [] {
+        const char *e = getenv("ND_AMD_STREAM_CHAIN_192");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool stream_long = !dense_ok && pm_ids == nullptr && mlp == nullptr &&
+                             k <= (chain192_env ? kStreamChainMax : kDenseMax) &&
                              dense_env <= 64 && alpha < fused_alpha;
     // multilooking pass A: the search fused in (dense_chain on the retained, multilooked series) at
     // every threshold below the sparse regime -- by alpha alone: the density sample reads the planes
@@ -3665,7 +3675,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             const char *e = getenv("ND_AMD_SEARCH_STARTS");      // list length per shard up to which ...; 0 = off
             return e ? atoi(e) : 512;
         }();
-        const bool starts_form = low_threshold && k >= 2 && k <= 129 && starts_env > 0 && mode_env < 0;
+        const bool starts_form = low_threshold && k >= 2 && k <= 193 && starts_env > 0 && mode_env < 0;
         if (starts_form) {
             s.starts_max = (uint32_t)starts_env;
             KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_SEARCH, sq);
@@ -4118,6 +4128,33 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             // its deep searches -- 6.9 against 6.6 ms at alpha = 0.2 on 48 x 2048 x 4096; deleted in round 4.)
             if (retain && sizeof(T) == 8 && (stats_long_chain || fused_form_long == 2 || (fused_form_long < 0 && alpha > 0.02))) {
                 launch_chain<T>(g, tab, htab, scr, n_looks, nblocks, stream, stats_long_chain);
+            } else if (k > kDenseMax) {
+                // 129 .. 192 dates: the two-pass chain search at every low threshold (three-word masks; the constants
+                // of the tests from make_dense_entry directly: DenseScreen ends at 128)
+                StreamScreen<kStreamChainMax> ss3 = make_stream_screen<T, kDenseMax>(htab, scr, (int)k, n_looks).template widen<kStreamChainMax>();
+                for (int j = kDenseMax + 1; j <= kStreamChainMax; ++j) {
+                    DenseScreenEntry de;
+                    de.re = 0;
+                    de.rf = 0.f;
+                    de.a = -INFINITY;
+                    de.b = INFINITY;
+                    if (j <= (int)k) de = make_dense_entry<T>(htab[(size_t)j], j, n_looks);
+                    ss3.e[j].re = de.re;
+                    ss3.e[j].rf = de.rf;
+                    ss3.e[j].a = de.a;
+                    ss3.e[j].b = de.b;
+                    ss3.e[j].jf = (float)j;
+                    ss3.e[j].cj = (sizeof(T) == 4 ? 5.9604645e-08f : 1.1102230e-16f) * 7.5f * (float)j;
+                    ss3.e[j].mj = (float)j * 1.01f;
+                    ss3.e[j].pad = 0.f;
+                }
+                if (stats_long_chain) {
+                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 3, true>), grid, block, 0, stream, g, tab, ss3);
+                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 3, true>), grid, block, 0, stream, g, tab, ss3);
+                } else {
+                    if (buf) hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 1, 3, false>), grid, block, 0, stream, g, tab, ss3);
+                    else hipLaunchKernelGGL((omnibus_c2_stream_chain_kernel<T, PF, 0, 3, false>), grid, block, 0, stream, g, tab, ss3);
+                }
             } else if (stats_long_chain || fused_form_long == 3 || (fused_form_long < 0 && alpha > 0.02)) {
                 // longer series between the streaming search's thresholds and the sparse regime: the
                 // chain search in two streaming passes (ND_AMD_FUSED_FORM=3 forces it, 0 the one-pass form)

@@ -403,6 +403,20 @@ struct StreamScreen {
     StreamEntry e[NJ + 1];
     f2_t ca, cb;          // .x: the 2-date test, .y: the 3-date test (pairs: operands of packed multiplications)
     float dlo, dhi;       // a date's determinant and those of the 2- / 3-date sums: strictly inside (dlo, dhi)
+    // the same constants in a longer table (entries beyond NJ: for the caller to fill)
+    template <int NJ2>
+    StreamScreen<NJ2> widen() const
+    {
+        static_assert(NJ2 >= NJ, "widen");
+        StreamScreen<NJ2> w;
+        memset(&w, 0, sizeof(w));
+        for (int j = 0; j <= NJ; ++j) w.e[j] = e[j];
+        w.ca = ca;
+        w.cb = cb;
+        w.dlo = dlo;
+        w.dhi = dhi;
+        return w;
+    }
 };
 
 template <typename T>
@@ -542,10 +556,19 @@ __device__ __forceinline__ float dense_x(const T dets, const bool ok, const int 
 struct Bits128 {
     unsigned long long lo, hi;
 };
+// Up to 192 dates (round 6: the two-pass chain search of series of 129 .. 192 dates): three words.
+struct Bits192 {
+    unsigned long long w0, w1, w2;
+};
 template <typename M>
 __device__ __forceinline__ M mask_zero()
 {
     return (M)0;
+}
+template <>
+__device__ __forceinline__ Bits192 mask_zero<Bits192>()
+{
+    return Bits192{0ull, 0ull, 0ull};
 }
 template <>
 __device__ __forceinline__ Bits128 mask_zero<Bits128>()
@@ -634,6 +657,38 @@ __device__ __forceinline__ Bits128 mask_undecided(const Bits128 &f, const Bits12
 }
 __device__ __forceinline__ int mask_ctz(const unsigned m) { return __builtin_ctz(m); }
 __device__ __forceinline__ int mask_ctz(const unsigned long long m) { return __builtin_ctzll(m); }
+// ---- three-word masks ----
+__device__ __forceinline__ void mask_set(Bits192 &m, const int i, const bool on)
+{
+    const unsigned long long b = on ? (1ull << (i & 63)) : 0ull;
+    m.w0 |= i < 64 ? b : 0ull;
+    m.w1 |= (i >= 64 && i < 128) ? b : 0ull;
+    m.w2 |= i >= 128 ? b : 0ull;
+}
+__device__ __forceinline__ bool mask_bit(const Bits192 &m, const int i)
+{
+    return (((i < 64 ? m.w0 : (i < 128 ? m.w1 : m.w2)) >> (i & 63)) & 1ull) != 0ull;
+}
+__device__ __forceinline__ void mask_push(Bits192 &m, const bool bit)
+{
+    m.w2 = (m.w2 + m.w2) + (m.w1 >> 63);
+    m.w1 = (m.w1 + m.w1) + (m.w0 >> 63);
+    m.w0 = (m.w0 + m.w0) + (bit ? 1ull : 0ull);
+}
+__device__ __forceinline__ void mask_keep_low(Bits192 &m, const int n)
+{
+    m.w0 &= mask_low<unsigned long long>(n < 64 ? (n < 0 ? 0 : n) : 64);
+    m.w1 &= mask_low<unsigned long long>(n < 64 ? 0 : (n < 128 ? n - 64 : 64));
+    m.w2 &= mask_low<unsigned long long>(n < 128 ? 0 : n - 128);
+}
+__device__ __forceinline__ Bits192 mask_undecided(const Bits192 &f, const Bits192 &c)
+{
+    return Bits192{~(f.w0 | c.w0), ~(f.w1 | c.w1), ~(f.w2 | c.w2)};
+}
+__device__ __forceinline__ unsigned mask_nibble(const Bits192 &m, const int q)
+{
+    return (unsigned)((q < 16 ? m.w0 : (q < 32 ? m.w1 : m.w2)) >> (4 * (q & 15))) & 0xFu;
+}
 // bits 4 q .. 4 q + 3
 template <typename M>
 __device__ __forceinline__ unsigned mask_nibble(const M &m, const int q)

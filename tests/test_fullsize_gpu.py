@@ -283,6 +283,8 @@ def test_every_kernel_form_gives_the_same_map(k, forms):
 
 _CHAIN_LENGTHS = [(20, 'f64', {}), (24, 'f64', {}), (33, 'f32', {}), (32, 'f32', {}), (12, 'f64', {}),
                   (40, 'f32', {}), (63, 'f32', {}), (96, 'f32', {}), (128, 'f32', {}), (40, 'f64', {}),
+                  # (round 6) 129 .. 192 dates: three-word masks, pass B with three starts per lane
+                  (129, 'f32', {}), (160, 'f32', {}), (192, 'f32', {}), (150, 'f64', {}),
                   (96, 'f32', {'ND_AMD_FUSED_FORM': '3', 'ND_AMD_SEARCH_STARTS': '0'})]
 
 
@@ -290,8 +292,8 @@ def test_chain_form_series_lengths():
     """dense_chain beyond the 24 float32 dates of the benchmark: 32 float32 / 16 float64 dates (two
     waves per SIMD), the 64-bit-mask instantiation for 17 .. 24 float64 dates (default between the
     streaming search's thresholds and the sparse regime), and beyond the registers the chain search in
-    two streaming passes (33 .. 128 dates: 64- and 128-bit masks, pending global tests, the per-start
-    pass B with two starts per lane), each against the oracle.  (The 33 .. 48-date float32 register
+    two streaming passes (33 .. 192 dates: 64-, 128- and 192-bit masks, pending global tests, the per-start
+    pass B with two or three starts per lane), each against the oracle.  (The 33 .. 48-date float32 register
     instantiation was deleted in round 4: it spilled and never was the default.)"""
     jobs = []
     for k, dtype, env in _CHAIN_LENGTHS:
@@ -304,7 +306,8 @@ def test_chain_form_series_lengths():
             assert 'omnibus_c2_fused' in r['kernels_ms'], (label, r)
 
 
-@pytest.mark.parametrize('dtype,k', [('float32', 40), ('float64', 24), ('float32', 80), ('float64', 40), ('float32', 112)])
+@pytest.mark.parametrize('dtype,k', [('float32', 40), ('float64', 24), ('float32', 80), ('float64', 40), ('float32', 112),
+                                      ('float32', 160)])
 def test_long_series_statistics_at_scale(oracle, dtype, k):
     """Series beyond the register forms on a raster large enough for the device-side density gate:
     the map of the streaming search (64- / 128-bit masks) equals the oracle on sampled pixels and
