@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(256) correlate_kernel(const CorrArgs<T> a, con
 // time and the inner loop is additions only (same values, same order, half the FP64 work).
 // -----------------------------------------------------------------------------------------
 constexpr int kTileX = 128, kTileY = 32, kOX = 4, kOY = 4;
-constexpr int kMaxKH = 15;
+constexpr int kMaxKH = 31;               // (round 6: windows of 17 .. 31 rows / columns; 15 before)
+constexpr int kSmallKH = 15;             // the register-array class of the windows up to 15 x 15
 
 template <typename T>
 struct TiledArgs {
@@ -382,10 +383,32 @@ static void launch_tiled(const TiledArgs<T> &a, bool box, int64_t nblocks, size_
             hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false, 5>), grid, block, lds, stream, a);
     } else {
         if (box)
-            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, true, kMaxKH>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, true, kSmallKH>), grid, block, lds, stream, a);
         else
-            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false, kMaxKH>), grid, block, lds, stream, a);
+            hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false, kSmallKH>), grid, block, lds, stream, a);
     }
+}
+
+// Windows of 17 .. 31 columns (any height up to 31), and the taller-than-15 windows of fewer columns run as
+// 17 wide with absent columns: one register-array class (31 rows), an LDS image of up to 79 KB (two blocks per
+// CU).  Before round 6 every window beyond 15 x 15 took the per-element kernel: BoxcarFilter(w=17) on
+// 8 x 2048^2 13.4 ms against 0.43 ms for w = 15.
+template <typename T, int KW>
+static bool launch_tiled_big(const TiledArgs<T> &a, bool box, int64_t nblocks, size_t lds, hipStream_t stream)
+{
+    const dim3 grid((unsigned)nblocks), block(256);
+    if (box) {
+        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&correlate_tiled_kernel<T, KW, true, kMaxKH>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return false;
+        hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, true, kMaxKH>), grid, block, lds, stream, a);
+    } else {
+        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&correlate_tiled_kernel<T, KW, false, kMaxKH>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return false;
+        hipLaunchKernelGGL((correlate_tiled_kernel<T, KW, false, kMaxKH>), grid, block, lds, stream, a);
+    }
+    return true;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -749,8 +772,11 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     // width with one absent column on the right: absent taps are skipped like scipy's dropped
     // zero weights, so the sums are the same, term for term.
     const int64_t kh = ymax - ymin + 1, kw_taps = xmax - xmin + 1;
-    const int64_t kw = (kw_taps & 1) ? kw_taps : kw_taps + 1;
+    int64_t kw = (kw_taps & 1) ? kw_taps : kw_taps + 1;
     const int64_t kt = tmax - tmin + 1;
+    // (taller than 15 rows but narrower than 17 columns: as 17 wide, the columns beyond the window absent)
+    const bool big = kh > kSmallKH || kw > kSmallKH;
+    if (big && kw < 17) kw = 17;
     if (kh > kMaxKH || kw > kMaxKH || kt * kh * kw > kMaxKH * kMaxKH) return 0;
     if (dims[2] < 1 || dims[3] < 1 || dims[2] > 0x7fffffffLL || dims[3] > 0x7fffffffLL) return 0;
     // windows reaching farther than twice the plane from it hit the non-periodic corner of
@@ -785,7 +811,7 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     a.tiles_x = (int)ceil_div(dims[3], kTileX);
     a.tiles_y = (int)ceil_div(dims[2], kTileY);
     for (int i = 0; i < kMaxKH * kMaxKH; ++i) a.w[i] = 0.0;
-    bool box = (ntaps == kt * kh * kw);
+    bool box = (ntaps == kt * kh * kw);      // (a window padded to 17 columns is not one: its absent taps are skipped)
     for (int64_t t = 0; t < ntaps; ++t) {
         a.w[((offsets[4 * t + 1] - tmin) * kh + (offsets[4 * t + 2] - ymin)) * kw + (offsets[4 * t + 3] - xmin)] = weights[t];
         if (weights[t] != weights[0]) box = false;
@@ -806,7 +832,22 @@ static int try_tiled(const void *in, void *out, const int64_t dims[4], const int
     const size_t twq = (size_t)(kTileX + kw - 1 + 3) / 4;
     const size_t lds = (size_t)(kTileY + kh - 1) * 4 * twq * sizeof(double) +
                        (size_t)((kTileY + kh - 1) + (kTileX + kw - 1)) * sizeof(int);
-    if (lds > 64 * 1024) return 0;
+    if (lds > (big ? 96 : 64) * 1024) return 0;
+    if (big) {
+        KernelTimer timer(ND_AMD_KERNEL_BOXCAR_TILED, stream);
+        bool ok = false;
+        switch (kw) {
+        case 17: ok = launch_tiled_big<T, 17>(a, box, nblocks, lds, stream); break;
+        case 19: ok = launch_tiled_big<T, 19>(a, box, nblocks, lds, stream); break;
+        case 21: ok = launch_tiled_big<T, 21>(a, box, nblocks, lds, stream); break;
+        case 23: ok = launch_tiled_big<T, 23>(a, box, nblocks, lds, stream); break;
+        case 25: ok = launch_tiled_big<T, 25>(a, box, nblocks, lds, stream); break;
+        case 27: ok = launch_tiled_big<T, 27>(a, box, nblocks, lds, stream); break;
+        case 29: ok = launch_tiled_big<T, 29>(a, box, nblocks, lds, stream); break;
+        default: ok = launch_tiled_big<T, 31>(a, box, nblocks, lds, stream); break;
+        }
+        return ok ? 1 : 0;
+    }
     {
         KernelTimer timer(ND_AMD_KERNEL_BOXCAR_TILED, stream);
         switch (kw) {

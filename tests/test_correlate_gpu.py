@@ -174,6 +174,44 @@ def test_tiled_edges_and_tiny_planes(device):
                                               ndi.convolve(a, k, mode=mode))
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_windows_of_17_to_31_in_the_tiled_kernel(device, dtype):
+    """Windows beyond 15 x 15 (round 6: BoxcarFilter(w=17) took the per-element kernel, 30 x the time of w = 15):
+    every width class 17 .. 31, boxcars and random weights, taller-than-15 windows of few columns (run 17 wide with
+    absent columns), even sizes, a zero tap, a 2 x 17 x 17 window along time, `constant` mode, tile borders and planes
+    smaller than the window -- bit-equal to scipy."""
+    import scipy.ndimage as ndi
+    from nd_amd import kernels
+    rng = np.random.default_rng(317)
+    shapes = [(2, 70, 300), (1, 33, 129), (1, 9, 20)]
+    for shape in shapes:
+        a = rng.normal(size=shape).astype(dtype)
+        for kshape in [(1, 17, 17), (1, 19, 19), (1, 21, 21), (1, 23, 23), (1, 25, 27), (1, 29, 29), (1, 31, 31),
+                       (1, 21, 5), (1, 5, 21), (1, 17, 1), (1, 18, 18), (1, 16, 30)]:
+            for k in (np.ones(kshape) / np.prod(kshape), rng.normal(size=kshape)):
+                for mode in ('reflect', 'wrap'):
+                    np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode), ndi.convolve(a, k, mode=mode),
+                                                  err_msg=str((shape, kshape, mode)))
+    a = rng.normal(size=(3, 40, 200)).astype(dtype)
+    k = rng.normal(size=(1, 19, 21))
+    k[0, 3, 4] = 0.0
+    for mode, kw in (('constant', dict(cval=2.5)), ('nearest', {}), ('mirror', {})):
+        np.testing.assert_array_equal(_gpu_convolve(a, k, device, mode=mode, **kw), ndi.convolve(a, k, mode=mode, **kw))
+    k3 = rng.normal(size=(2, 17, 17))
+    np.testing.assert_array_equal(_gpu_convolve(a, k3, device), ndi.convolve(a, k3))
+    # the tiled kernel took them (not the per-element one): a 21 x 21 boxcar on 4 x 1024^2 in well under 5 ms
+    import time
+    import torch
+    x = torch.from_numpy(rng.normal(size=(4, 1024, 1024)).astype(dtype)).to(device)
+    kb = np.ones((1, 21, 21)) / 441.0
+    kernels.convolve(x, kb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernels.convolve(x, kb)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5e-3
+
+
 @pytest.mark.parametrize('mode', ['reflect', 'nearest', 'mirror', 'wrap'])
 def test_register_window_kernel(device, mode):
     """Square 3 x 3 / 5 x 5 / 7 x 7 windows on float32 planes run in the register-window kernel
