@@ -1047,7 +1047,9 @@ __global__ void __launch_bounds__(256) correlate1d_kernel(const Corr1dArgs<T> a)
 // the loads of the next step are in flight while the current one is computed.  A thread owns one
 // column and 16 rows; lanes read consecutive doubles (conflict-free).  Taps outermost, the 16
 // outputs innermost: each output still receives its terms in the order of the generic kernel.
-constexpr int kT1X = 128, kT1R = 32, kT1MaxW = 31;
+// (round 6: kernels of up to 97 taps -- Gaussian sigma up to 12 at truncate = 4; 31 taps before, beyond which the
+//  per-element kernel took over: sigma = 5 on 8 x 2048^2 1.95 ms against 0.31 ms for sigma = 3)
+constexpr int kT1X = 128, kT1R = 32, kT1MaxW = 97;
 
 template <typename T>
 struct Corr1dTiledArgs {
@@ -1112,28 +1114,38 @@ __global__ void __launch_bounds__(256) correlate1d_tiled_kernel(const Corr1dTile
             }
         }
     }
-    int off2[4];
+    // (the extra columns in groups of 32: NG groups, four rows of each per thread)
+    constexpr int NG = ALONG_X ? (NW - 1 + 31) / 32 : 1;
+    int off2[4 * NG];
     const int ec = kT1X + (tid & 31), er = tid >> 5;
     if (ALONG_X) {
-        const int64_t ecol = ec < ucols ? (int64_t)map[ec] : -1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rr = er + 8 * i;
-            const int64_t row = r0 + rr < a.nrows ? r0 + rr : a.nrows - 1;
-            off2[i] = ecol < 0 ? -1 : (int)(row * a.sr_in + ecol);
+        for (int gq = 0; gq < NG; ++gq) {
+            const int ecg = ec + 32 * gq;
+            const int64_t ecol = ecg < ucols ? (int64_t)map[ecg] : -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = er + 8 * i;
+                const int64_t row = r0 + rr < a.nrows ? r0 + rr : a.nrows - 1;
+                off2[4 * gq + i] = ecol < 0 ? -1 : (int)(row * a.sr_in + ecol);
+            }
         }
     }
 
-    T buf[NR], buf2[4];
+    T buf[NR], buf2[4 * NG];
     auto load_step = [&](int64_t st) {
         const T *src = a.in + b0 * a.sb0_in + st * a.sb1_in;
 #pragma unroll
         for (int i = 0; i < NR; ++i)
             if (sp + 2 * i < trows && off[i] >= 0) buf[i] = src[off[i]];
-        if (ALONG_X && ec < ucols) {
+        if (ALONG_X) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (off2[i] >= 0) buf2[i] = src[off2[i]];
+            for (int gq = 0; gq < NG; ++gq)
+                if (ec + 32 * gq < ucols) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (off2[4 * gq + i] >= 0) buf2[4 * gq + i] = src[off2[4 * gq + i]];
+                }
         }
     };
     auto store_step = [&]() {
@@ -1142,10 +1154,14 @@ __global__ void __launch_bounds__(256) correlate1d_tiled_kernel(const Corr1dTile
             const int rr = sp + 2 * i;
             if (rr < trows) tile[rr * tcols + sc] = off[i] >= 0 ? (double)buf[i] : a.cval;
         }
-        if (ALONG_X && ec < ucols) {
+        if (ALONG_X) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                tile[(er + 8 * i) * tcols + ec] = off2[i] >= 0 ? (double)buf2[i] : a.cval;
+            for (int gq = 0; gq < NG; ++gq)
+                if (ec + 32 * gq < ucols) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        tile[(er + 8 * i) * tcols + ec + 32 * gq] = off2[4 * gq + i] >= 0 ? (double)buf2[4 * gq + i] : a.cval;
+                }
         }
     };
     if (s0 < s1) {
@@ -1317,10 +1333,11 @@ static int correlate1d_impl(const void *in, void *out, const int64_t dims[4], co
             groups = ceil_div(t.nb1, (int64_t)t.ppb);
         }
         const int64_t nb = (int64_t)t.tiles_x * t.tiles_r * dims[bax[0]] * groups;
-        const int nwc = n <= 9 ? 9 : (n <= 17 ? 17 : (n <= 25 ? 25 : kT1MaxW));      // size class of the instantiation
+        // size class of the instantiation
+        const int nwc = n <= 9 ? 9 : (n <= 17 ? 17 : (n <= 25 ? 25 : (n <= 31 ? 31 : (n <= 65 ? 65 : kT1MaxW))));
         const size_t trows = along_x ? kT1R : kT1R + nwc - 1, tcols = along_x ? kT1X + nwc - 1 : kT1X;
         const size_t lds = trows * tcols * sizeof(double) + (along_x ? tcols : trows) * sizeof(int);
-        bool fits = nb <= 0x7fffffffLL && lds <= 64 * 1024 && si[rax] >= 0 && so[rax] >= 0;
+        bool fits = nb <= 0x7fffffffLL && lds <= 150 * 1024 && si[rax] >= 0 && so[rax] >= 0;
         for (int d = 0; d < 4; ++d)
             if (dims[d] > 0x3fffffffLL) fits = false;
         // offsets inside one step (row axis x contiguous axis) are kept as 32-bit integers
@@ -1328,17 +1345,29 @@ static int correlate1d_impl(const void *in, void *out, const int64_t dims[4], co
         if (fits) {
             KernelTimer timer(ND_AMD_KERNEL_CORRELATE1D, stream);
             const dim3 grid((unsigned)nb), block(256);
-#define ND_LAUNCH_1D(AX, NWC) \
-    hipLaunchKernelGGL((correlate1d_tiled_kernel<T, AX, NWC>), grid, block, lds, stream, t)
+#define ND_LAUNCH_1D(AX, NWC)                                                                                       \
+    do {                                                                                                            \
+        if (lds > 64 * 1024) {                                                                                      \
+            static const hipError_t e_ = hipFuncSetAttribute(                                                       \
+                reinterpret_cast<const void *>(&correlate1d_tiled_kernel<T, AX, NWC>),                              \
+                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                                            \
+            ND_HIP_CHECK(e_);                                                                                       \
+        }                                                                                                           \
+        hipLaunchKernelGGL((correlate1d_tiled_kernel<T, AX, NWC>), grid, block, lds, stream, t);                    \
+    } while (0)
             if (along_x) {
                 if (nwc == 9) ND_LAUNCH_1D(true, 9);
                 else if (nwc == 17) ND_LAUNCH_1D(true, 17);
                 else if (nwc == 25) ND_LAUNCH_1D(true, 25);
+                else if (nwc == 31) ND_LAUNCH_1D(true, 31);
+                else if (nwc == 65) ND_LAUNCH_1D(true, 65);
                 else ND_LAUNCH_1D(true, kT1MaxW);
             } else {
                 if (nwc == 9) ND_LAUNCH_1D(false, 9);
                 else if (nwc == 17) ND_LAUNCH_1D(false, 17);
                 else if (nwc == 25) ND_LAUNCH_1D(false, 25);
+                else if (nwc == 31) ND_LAUNCH_1D(false, 31);
+                else if (nwc == 65) ND_LAUNCH_1D(false, 65);
                 else ND_LAUNCH_1D(false, kT1MaxW);
             }
 #undef ND_LAUNCH_1D
