@@ -2089,9 +2089,11 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
     }
     const uint32_t F0 = (patch_mode == 1) ? f[A0] : 0u, F1 = (patch_mode == 1) ? f[A1] : 0u;
     if (patch_mode == 0 && (f[A0] != 0 || f[A1] != 0)) return 0;
-    if (F0 != F1 || F0 > 3 || nvars > 4) return 0;
+    // (round 6: patches of 9 x 9 and 11 x 11 -- f = 4, 5 -- in the one-column-per-lane kernel, whose sliding sums are
+    //  generic in F; before, they took the per-pixel kernel: r = 5, f = 4 on 4 x 1024 x 2048 177 ms)
+    if (F0 != F1 || F0 > 5 || nvars > 4) return 0;
     static const bool no_patch2 = getenv("ND_AMD_NLM_PATCH1") != nullptr;
-    if (!no_patch2 && F0 >= 1) {
+    if (!no_patch2 && F0 >= 1 && F0 <= 3) {
         // cross-lane form: two columns per lane
         const int hl = (F0 == 3) ? 2 : 1, tx2 = 2 * (64 - 2 * hl), tyw2 = (nvars == 1) ? Patch2Rows<1>::TYW : Patch2Rows<2>::TYW;
         int m = a.r1 + 2 * hl + (a.r1 & 1);
@@ -2125,7 +2127,9 @@ static int nlm_try_tiled(const void *arr, void *out, int dtype, const int64_t N[
     case 0: ok = launch_patch_v<0>(a, nsl, lds, stream); break;
     case 1: ok = launch_patch_v<1>(a, nsl, lds, stream); break;
     case 2: ok = launch_patch_v<2>(a, nsl, lds, stream); break;
-    default: ok = launch_patch_v<3>(a, nsl, lds, stream); break;
+    case 3: ok = launch_patch_v<3>(a, nsl, lds, stream); break;
+    case 4: ok = launch_patch_v<4>(a, nsl, lds, stream); break;
+    default: ok = launch_patch_v<5>(a, nsl, lds, stream); break;
     }
     return ok ? 1 : 0;
 }

@@ -339,6 +339,42 @@ def test_window_kernels_with_nodata(oracle, device):
             np.testing.assert_allclose(got[ok], want[ok], rtol=RTOL)
 
 
+def test_signed_mode_patches_of_9x9_and_11x11(oracle, device):
+    """f = 4 and 5 in the signed mode run in the one-column-per-lane patch kernel (round 6; the per-pixel kernel
+    before: 500 x slower than f = 2): 1 - 4 variables, n_eff, ragged tiles, NaN / inf nodata -- 1e-5 against the
+    oracle's double arithmetic."""
+    import torch
+    from nd_amd import kernels
+    rng = np.random.default_rng(451)
+    for nv, shape in ((1, (2, 70, 131)), (3, (1, 37, 70)), (4, (2, 20, 65))):
+        a = rng.gamma(4.0, 0.25, shape + (nv,)).astype(np.float32)          # (t, y, x, var)
+        planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)
+        for r, f, ne in (((0, 5, 5), (0, 4, 4), -1), ((0, 6, 6), (0, 5, 5), -1), ((0, 4, 4), (0, 4, 4), 30.0)):
+            want = np.empty_like(a)
+            oracle.pixelwise_nlmeans_3d(a, want, r, f, 0.5, 0.5, ne, neff_policy=0, njobs=8, patch_mode=1)
+            out = torch.empty_like(planar)
+            kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), r, f, 0.5, 0.5, ne,
+                                         patch_mode=1, neff_policy=0)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(out.permute(1, 2, 3, 0).cpu().numpy(), want, rtol=RTOL, err_msg=str((nv, r, f, ne)))
+    a = rng.gamma(4.0, 0.25, (1, 40, 90, 2)).astype(np.float32)
+    a[0, 10, 20, 0] = np.nan
+    a[0, 30, 60, 1] = np.inf
+    a[0, :, :6, :] = np.nan
+    planar = torch.from_numpy(np.ascontiguousarray(a.transpose(3, 0, 1, 2))).to(device)
+    want = np.empty_like(a)
+    with np.errstate(all='ignore'):
+        oracle.pixelwise_nlmeans_3d(a, want, (0, 5, 5), (0, 4, 4), 0.5, 0.5, -1, neff_policy=0, njobs=8, patch_mode=1)
+    out = torch.empty_like(planar)
+    kernels.pixelwise_nlmeans_3d(planar.permute(1, 2, 3, 0), out.permute(1, 2, 3, 0), (0, 5, 5), (0, 4, 4), 0.5, 0.5, -1,
+                                 patch_mode=1, neff_policy=0)
+    torch.cuda.synchronize()
+    got = out.permute(1, 2, 3, 0).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=RTOL)
+
+
 def test_signed_mode_far_on_the_no_solution_side(oracle, device):
     """n_eff beyond what the neighbours can give (n_eff - 1 > W^2 / W2 at every pixel: find_weight raises at each,
     the reference's self weight is 0 under neff_policy 0).  The tiled kernels keep those pixels in the fast path
