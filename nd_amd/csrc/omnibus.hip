@@ -3403,6 +3403,19 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     g.dense_min = dense_ok ? dense_env : 65;
     const bool stats = (z_out != nullptr) || (p_out != nullptr);
     const bool retain = k <= (sizeof(T) == 4 ? kRetainMaxF32 : kRetainMaxF64);
+    // (round 6) The screen of the whole-series test is unusable where omega2 leaves [0, 1] (omni_bounds): P is then not
+    // monotonic in z.  That is the case for the reference's DEFAULT n = 1 on a series of more than a few dates, whatever
+    // the data were multilooked with -- and every screen-based form then handed EVERY pixel to the exact pass B
+    // (24 x 2048 x 4096, n = 1: 9.2 ms against 0.7 ms with n = 9).  Pass A evaluates that one test exactly instead
+    // (its STATS instantiation: z, the chi-square pair, P > alpha as the reference decides it) and lists only the
+    // pixels whose whole-series test fires -- for n = 1 on multilooked data none, as in the reference.
+    // ND_AMD_EXACT_FLAGS=0: as before.
+    static const bool exact_flags_env = [] {
+        const char *e = getenv("ND_AMD_EXACT_FLAGS");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool global_screen_ok = (htab[(size_t)k].zlo > -INFINITY) || (htab[(size_t)k].zhi < INFINITY);
+    const bool exact_flags = exact_flags_env && !global_screen_ok && pm_ids == nullptr && mlp == nullptr && k >= 2;
     // Low thresholds make nearly every wave dense (P > alpha holds for a fraction 1 - alpha of
     // stationary pixels): the search is then fused into pass A.  Speed only -- every form gives the
     // same map.  ND_AMD_FUSED_ALPHA overrides the switch-over (0 = never fuse, 2 = always).
@@ -3420,7 +3433,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         return e ? atof(e) : 0.93;
     }();
     // (z / P rasters asked for on top: they come from one launch of the plain pass A first, see below)
-    const bool fused = retain && dense_ok && g.dense_min <= 64 && alpha < fused_alpha_regs;
+    const bool fused = retain && dense_ok && g.dense_min <= 64 && alpha < fused_alpha_regs && !exact_flags;
     const bool fused_stats = fused && stats;
     // Series beyond the register forms (33 .. 128 dates; float64: 17 .. 128): the streaming search with
     // 64- or 128-bit masks.  Without it every pixel of a low-threshold run went through pass B one by one
@@ -3434,7 +3447,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     }();
     const bool stream_long = !dense_ok && pm_ids == nullptr && mlp == nullptr &&
                              k <= (chain192_env ? kStreamChainMax : kDenseMax) &&
-                             dense_env <= 64 && alpha < fused_alpha;
+                             dense_env <= 64 && alpha < fused_alpha && !exact_flags;
     // multilooking pass A: the search fused in (dense_chain on the retained, multilooked series) at
     // every threshold below the sparse regime -- by alpha alone: the density sample reads the planes
     // as they are, not multilooked
@@ -3466,7 +3479,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     // (float64 beyond 48 dates -- eight slices of doubles in turn -- measured slower with the rasters than the
     //  plain pass A and the gather: 3.65 against 3.43 ms on 96 x 1024 x 4096)
     const bool split_stats_ok = split_stats_env && !(sizeof(T) == 8 && k > 48);
-    const bool split_ok = split_env && search_fs_enabled() && !retain && !stream_long && (!stats || split_stats_ok) &&
+    const bool split_ok = split_env && search_fs_enabled() && !retain && !stream_long && (!stats || split_stats_ok) && !exact_flags &&
                           k <= (sizeof(T) == 4 ? 192 : 96) && pm_ids == nullptr && mlp == nullptr && sx == 1;
     // The threshold only says that dense waves are LIKELY; whether they are is a property of the
     // data (a low alpha on strongly filtered data fires rarely).  Above a minimum size the choice
@@ -4243,11 +4256,11 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
     } else {
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (retain)
-            launch_retain<T>(g, tab, nblocks, stats, stream);
+            launch_retain<T>(g, tab, nblocks, stats || exact_flags, stream);
         else if (aligned)
-            launch_global<T, VPPT>(g, tab, nblocks, stats, stream);
+            launch_global<T, VPPT>(g, tab, nblocks, stats || exact_flags, stream);
         else
-            launch_global<T, 1>(g, tab, nblocks, stats, stream);
+            launch_global<T, 1>(g, tab, nblocks, stats || exact_flags, stream);
     }
     ND_HIP_CHECK(hipGetLastError());
 

@@ -72,6 +72,30 @@ def test_number_of_looks(oracle, device, n):
     _compare(got, want)
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_default_number_of_looks_on_multilooked_data(oracle, device, dtype):
+    """n = 1 -- the reference's DEFAULT -- on nine-look data: omega2 of the whole-series test leaves [0, 1], no screen can
+    decide it, and pass A evaluates it exactly instead (round 6; before, every pixel went through pass B: 14 x the time).
+    Maps (with and without the rasters) equal the oracle's at every threshold and series length (the reference reports
+    no change at all there: its P is negative), as do those of n = 2, 3, whose screens are usable or not by length."""
+    import torch
+    from nd_amd import kernels
+    for k, ny, nx in ((3, 20, 70), (5, 33, 129), (24, 40, 300), (40, 12, 200), (70, 6, 130)):
+        planes = synth.omnibus_stack(seed=300 + k, k=k, ny=ny, nx=nx, looks=9, dtype=dtype, change_frac=0.3)
+        for n in (1, 2, 3):
+            for alpha in (0.01, 0.5, 0.99):
+                want = _run_oracle(oracle, planes, alpha, n)
+                got = _run_gpu(planes, alpha, n, device)
+                _compare(got, want)
+                ts = [torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in planes]
+                ch = kernels.change_detection(*ts, alpha=alpha, n=n)
+                torch.cuda.synchronize()
+                assert np.array_equal(ch.cpu().numpy(), want[0]), (k, n, alpha)
+    # (with n = 1 the reference's P is negative everywhere on such data -- no change at any length; n = 3 finds changes)
+    planes = synth.omnibus_stack(seed=303, k=3, ny=20, nx=70, looks=9, dtype=dtype, change_frac=0.3)
+    assert _run_oracle(oracle, planes, 0.01, 1)[0].sum() == 0 and _run_oracle(oracle, planes, 0.01, 3)[0].sum() > 0
+
+
 def test_reference_known_answer(oracle, device):
     """nd/tests/test_change_omnibus.py:6-19."""
     dims = {'y': 5, 'x': 5, 'time': 10}
