@@ -3415,7 +3415,8 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         return e ? atoi(e) != 0 : true;
     }();
     const bool global_screen_ok = (htab[(size_t)k].zlo > -INFINITY) || (htab[(size_t)k].zhi < INFINITY);
-    const bool exact_flags = exact_flags_env && !global_screen_ok && pm_ids == nullptr && mlp == nullptr && k >= 2;
+    const bool exact_flags = exact_flags_env && !global_screen_ok && mlp == nullptr && k >= 2;
+    const bool stats_a = stats || exact_flags;      // the pass A instantiation that evaluates the whole-series test exactly
     // Low thresholds make nearly every wave dense (P > alpha holds for a fraction 1 - alpha of
     // stationary pixels): the search is then fused into pass A.  Speed only -- every form gives the
     // same map.  ND_AMD_FUSED_ALPHA overrides the switch-over (0 = never fuse, 2 = always).
@@ -3598,7 +3599,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             hipLaunchKernelGGL((omnibus_c2_dense_kernel<float, 32>), gridd, blockd, 0, sq,
                                reinterpret_cast<const OmniDenseArgs<float> &>(d), ssd);
     };
-    const bool low_threshold = fused || stream_long || ml_chain || (pm_ids != nullptr && alpha < fused_alpha);
+    const bool low_threshold = fused || stream_long || ml_chain || (pm_ids != nullptr && alpha < fused_alpha && !exact_flags);
     auto launch_search = [&](hipStream_t sq, const uint32_t *count, const uint32_t *idx, const T *dump,
                              uint32_t seg, uint32_t dump_cap, int64_t npix_listed,
                              unsigned long long *hand, uint32_t hand_words) -> int {
@@ -3834,7 +3835,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                            : (16 * per_px * (int64_t)sizeof(T) <= 48 * 1024 ? 16 : 0));
         const bool four_real = pm_ids[0] == 1 && pm_ids[1] == 1 && pm_ids[2] == 1 && pm_ids[3] == 1;
         const bool joint = pm_ids[0] == 1 && pm_ids[3] == 1 && dm.c12_joint;
-        if (!dma_ok || pxw == 0 || !(alpha >= fused_alpha) || !(four_real || joint)) {
+        if (!dma_ok || pxw == 0 || !(alpha >= fused_alpha || exact_flags) || !(four_real || joint)) {
             set_error("nd_amd_omnibus_c2_pixel_major: %lld dates: beyond the register-retaining sizes only 16-byte "
                       "aligned series of a multiple of %d dates, up to 48 KB per 16 pixels, at alpha >= %g "
                       "(transpose and call nd_amd_omnibus_c2 otherwise)", (long long)k, VE, fused_alpha);
@@ -3857,9 +3858,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
 #define ND_LAUNCH_PM_LONG(PXW_)                                                                               \
     do {                                                                                                      \
-        if (stats && joint)                                                                                   \
+        if (stats_a && joint)                                                                                   \
             hipLaunchKernelGGL((omnibus_c2_pm_long_kernel<T, PXW_, true, true>), gridw, blockw, lds_long, stream, g, tab, dm);   \
-        else if (stats)                                                                                       \
+        else if (stats_a)                                                                                       \
             hipLaunchKernelGGL((omnibus_c2_pm_long_kernel<T, PXW_, true, false>), gridw, blockw, lds_long, stream, g, tab, dm);  \
         else if (joint)                                                                                       \
             hipLaunchKernelGGL((omnibus_c2_pm_long_kernel<T, PXW_, false, true>), gridw, blockw, lds_long, stream, g, tab, dm);  \
@@ -3895,7 +3896,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         const bool dma_ok = pm_form != 1 && (k % VE) == 0 &&
                             (((uintptr_t)c11 | (uintptr_t)c22 | (uintptr_t)c12re) & 15) == 0 &&
                             (pm.c12_joint || ((uintptr_t)c12im & 15) == 0);
-        const bool fused_pm = dma_ok && !stats && k <= 32 && dense_env <= 64 && alpha < fused_alpha;
+        const bool fused_pm = dma_ok && !stats && !exact_flags && k <= 32 && dense_env <= 64 && alpha < fused_alpha;
         if (fused_pm) g.dense_min = dense_env;
         if (dma_ok) {
             OmniPmDmaArgs<T> dm;
@@ -3985,7 +3986,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             memset(&ss_unused, 0, sizeof(ss_unused));
 #define ND_LAUNCH_DMA(KM)                                                                              \
     do {                                                                                              \
-        if (stats)                                                                                    \
+        if (stats_a)                                                                                  \
             hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, true>), gridw, blockw, lds_dma, stream, g, tab, dm, ss_unused);  \
         else                                                                                          \
             hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, KM, false>), gridw, blockw, lds_dma, stream, g, tab, dm, ss_unused); \
@@ -4010,7 +4011,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
 #define ND_LAUNCH_PM(KM)                                                                              \
     do {                                                                                              \
-        if (stats)                                                                                    \
+        if (stats_a)                                                                                  \
             hipLaunchKernelGGL((omnibus_c2_retain_pm_kernel<T, KM, true>), grid, block, lds, stream, g, tab, pm);  \
         else                                                                                          \
             hipLaunchKernelGGL((omnibus_c2_retain_pm_kernel<T, KM, false>), grid, block, lds, stream, g, tab, pm); \
