@@ -297,8 +297,10 @@ def test_chain_form_series_lengths():
     instantiation was deleted in round 4: it spilled and never was the default.)"""
     jobs = []
     for k, dtype, env in _CHAIN_LENGTHS:
-        argv = ['--k', str(k), '--dtype', dtype, '--ny', '256' if k > 64 else '512', '--nx', '2048',
-                '--alphas', '0.05,0.3,0.6', '--steps', '1', '--cpu-rows', '256', '--layouts', 'planar']
+        # (the oracle's search is quadratic in the series length: fewer rows for the longest series)
+        ny = '128' if k > 128 else ('256' if k > 64 else '512')
+        argv = ['--k', str(k), '--dtype', dtype, '--ny', ny, '--nx', '2048',
+                '--alphas', '0.05,0.3,0.6', '--steps', '1', '--cpu-rows', '128' if k > 128 else '256', '--layouts', 'planar']
         jobs.append(('%d %s %r' % (k, dtype, env), argv, env, 3))
     for label, lines in _bench_dense_many(jobs).items():
         for r in lines:
