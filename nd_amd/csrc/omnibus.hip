@@ -862,6 +862,20 @@ template <typename T, int KMAX, int COMP, bool BOTH>
 __device__ __forceinline__ void pm_pick(T (&v)[KMAX][4], const T *im, const int k, const int ids)
 {
     constexpr int VE = 16 / (int)sizeof(T);
+    // (round 6) a series length that is not a multiple of the 16-byte vector -- three of four lengths in float32 --
+    // leaves the lanes' runs unaligned in the image: element by element then (wave-uniform branch).  Before, such
+    // lengths took the register-staged kernel and, below the sparse regime, pass B for every pixel: 21 dates x
+    // 2048 x 4096 at alpha = 0.01 2.9 ms against 0.85 ms for 24 dates.
+    if (((k * ids) % VE) != 0) {
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            if (t < k) {
+                v[t][COMP] = im[t * ids];
+                if (BOTH) v[t][COMP + (BOTH ? 1 : 0)] = im[t * ids + 1];
+            }
+        }
+        return;
+    }
     if (ids == 1) {
 #pragma unroll
         for (int u = 0; u < KMAX / VE; ++u) {
@@ -921,14 +935,18 @@ omnibus_c2_pm_dma_kernel(const OmniGlobalArgs<T> g, const OmniTab tab, const Omn
     // ---- every transfer of the wave in flight ----
     auto stage = [&](const T *base, int vi) {
         const int wpp = k * pm.ids[vi];                     // elements per pixel in memory
-        const int bytes = np * wpp * (int)sizeof(T);        // multiple of 16 (host checks k)
+        const int bytes = np * wpp * (int)sizeof(T);        // a multiple of 16 for whole spans of 64 pixels
         const unsigned char *src = reinterpret_cast<const unsigned char *>(base + px0 * wpp);
         unsigned char *dst = reinterpret_cast<unsigned char *>(img + pm.img_off[vi]);
-        for (int c0 = 0; c0 < bytes; c0 += 1024) {
+        const int bytes16 = bytes & ~15;
+        for (int c0 = 0; c0 < bytes16; c0 += 1024) {
             const int eb = c0 + lane * 16;
-            if (eb < bytes)
+            if (eb < bytes16)
                 __builtin_amdgcn_global_load_lds((glb_u8_t *)(src + eb), (lds_u8_t *)(dst + c0), 16, 0, kNtAux);
         }
+        // (the last span of a variable whose series length is not a multiple of the vector: up to three words more)
+        if (bytes16 < bytes && bytes16 + lane * 4 < bytes)
+            __builtin_amdgcn_global_load_lds((glb_u8_t *)(src + bytes16 + lane * 4), (lds_u8_t *)(dst + bytes16), 4, 0, kNtAux);
     };
     if (!DIRECT) {
         stage(g.c11, 0);
@@ -3893,7 +3911,15 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
             const char *e = getenv("ND_AMD_PM_FORM");        // 1 = always the register-staged form
             return e ? atoi(e) : 0;
         }();
-        const bool dma_ok = pm_form != 1 && (k % VE) == 0 &&
+        // (round 6: any series length -- the spans of 64 pixels are 16-byte pieces whatever k is; lanes whose runs
+        //  are not 16-byte aligned in the image read it element by element, pm_pick.  ND_AMD_PM_ANYK=0: as before,
+        //  multiples of the vector only)
+        static const bool pm_anyk = [] {
+            const char *e = getenv("ND_AMD_PM_ANYK");
+            return e ? atoi(e) != 0 : true;
+        }();
+        const bool kvec = (k % VE) == 0;
+        const bool dma_ok = pm_form != 1 && (kvec || pm_anyk) &&
                             (((uintptr_t)c11 | (uintptr_t)c22 | (uintptr_t)c12re) & 15) == 0 &&
                             (pm.c12_joint || ((uintptr_t)c12im & 15) == 0);
         const bool fused_pm = dma_ok && !stats && !exact_flags && k <= 32 && dense_env <= 64 && alpha < fused_alpha;
@@ -3948,7 +3974,7 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                 // dense_chain behind the staging, C11 / C22 straight into registers and only C12 through
                 // LDS: at every threshold below the sparse regime (2.0 ms; the streaming search on full
                 // LDS images: 2.05 / 2.37 ms at alpha = 1e-4 / 0.01, dense_chain on full images: 2.5 ms)
-                if (fused_form_pm != 0 && k <= 24 && pm_direct_env && pm_ids[0] == 1 && pm_ids[3] == 1) {
+                if (fused_form_pm != 0 && k <= 24 && pm_direct_env && pm_ids[0] == 1 && pm_ids[3] == 1 && kvec) {
                     OmniPmDmaArgs<T> dd = dm;
                     dd.img_off[1] = 0;
                     dd.img_off[2] = 64 * (int)k * dd.ids[1];
@@ -3960,8 +3986,9 @@ static int omnibus_c2_impl(const void *c11, const void *c12re, const void *c12im
                     else
                         hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 24, false, true, true>), gridw, blockw, lds_c12, stream, g, tab, dd, ss0);
                 } else
-                if ((fused_form_pm == 2 || (fused_form_pm != 0 && alpha > 0.02)) && k <= 24) {
-                    // dense_chain behind the LDS-DMA staging: the form for the thresholds in between
+                if ((fused_form_pm == 2 || (fused_form_pm != 0 && alpha > 0.02) || !kvec) && k <= 24) {
+                    // dense_chain behind the LDS-DMA staging: the form for the thresholds in between (and, at every
+                    // low threshold, for the series lengths that are not a multiple of the vector)
                     if (k <= 8)
                         hipLaunchKernelGGL((omnibus_c2_pm_dma_kernel<T, 8, false, true>), gridw, blockw, lds_dma, stream, g, tab, dm, ss0);
                     else if (k <= 16)

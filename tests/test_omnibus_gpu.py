@@ -159,28 +159,34 @@ def test_minimal_workspace_gathers_from_planes(oracle, device, dtype):
 
 
 @pytest.mark.parametrize('dtype,k', [(np.float32, 24), (np.float32, 7), (np.float32, 16), (np.float64, 12),
-                                     (np.float64, 5)])
+                                     (np.float64, 5), (np.float32, 21), (np.float32, 22), (np.float32, 23),
+                                     (np.float32, 10), (np.float32, 2), (np.float32, 3), (np.float64, 11)])
 def test_pixel_major_kernel_equals_planar(oracle, device, dtype, k):
     """nd_amd_omnibus_c2_pixel_major: variables in the reference's (y, x, time) layout, C12 as one
-    interleaved complex tensor or as two real ones; ragged raster sizes; z / P output; equal to the
-    oracle and to the planar entry point."""
+    interleaved complex tensor or as two real ones; ragged raster sizes (last spans of fewer than 64 pixels);
+    z / P output; every threshold regime; series lengths that are and are not a multiple of the 16-byte vector
+    (round 6: the latter read the LDS image element by element instead of taking the register-staged kernel);
+    equal to the oracle and to the planar entry point."""
     import torch
     from nd_amd import kernels
     from tests import synth as tsynth
     for ny, nx in [(1, 1), (3, 70), (33, 257), (64, 64)]:
         planes = tsynth.omnibus_stack(seed=ny * nx + k, k=k, ny=ny, nx=nx, dtype=dtype, change_frac=0.3)
         yxt = [np.ascontiguousarray(np.moveaxis(p, 0, -1)) for p in planes]
-        want, zw, pw = oracle.change_detection_planes(yxt, 0.9, 9, njobs=4, stats=True)
         dev = [torch.from_numpy(a).to(device) for a in yxt]
-        got = kernels.change_detection_pixel_major(dev[0], dev[1], dev[2], dev[3], alpha=0.9, n=9)
-        assert got is not None
-        np.testing.assert_array_equal(got.cpu().numpy(), want)
         c12 = torch.complex(dev[1], dev[2])
-        res = kernels.change_detection_pixel_major(dev[0], c12.real, c12.imag, dev[3], alpha=0.9, n=9,
-                                                   stats=True)
-        np.testing.assert_array_equal(res[0].cpu().numpy(), want)
-        np.testing.assert_allclose(res[1].cpu().numpy(), zw, rtol=1e-5, equal_nan=True)
-        np.testing.assert_allclose(res[2].cpu().numpy(), pw, rtol=1e-5, atol=1e-7, equal_nan=True)
+        for alpha in (0.9, 0.01, 0.3):
+            want, zw, pw = oracle.change_detection_planes(yxt, alpha, 9, njobs=4, stats=True)
+            got = kernels.change_detection_pixel_major(dev[0], dev[1], dev[2], dev[3], alpha=alpha, n=9)
+            assert got is not None
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
+            got = kernels.change_detection_pixel_major(dev[0], c12.real, c12.imag, dev[3], alpha=alpha, n=9)
+            np.testing.assert_array_equal(got.cpu().numpy(), want)
+            res = kernels.change_detection_pixel_major(dev[0], c12.real, c12.imag, dev[3], alpha=alpha, n=9,
+                                                       stats=True)
+            np.testing.assert_array_equal(res[0].cpu().numpy(), want)
+            np.testing.assert_allclose(res[1].cpu().numpy(), zw, rtol=1e-5, equal_nan=True)
+            np.testing.assert_allclose(res[2].cpu().numpy(), pw, rtol=1e-5, atol=1e-7, equal_nan=True)
     # not that layout / too long a series: declined
     t = torch.zeros((4, 5, 30), device=device)
     assert kernels.change_detection_pixel_major(t, t, t, t, alpha=0.9) is None
