@@ -1988,7 +1988,17 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
         const char *e = getenv("ND_AMD_C3_FUSED_ALPHA");
         return e ? atof(e) : 0.75;
     }();
-    const bool fused = pm_ids == nullptr && k >= 2 && k <= kDenseMax && k <= kTabArgs && alpha < fused_alpha && g.off32;
+    // (round 6) the whole-series test's screen is unusable where omega2 leaves [0, 1] (the default n = 1 on a series of
+    // more than a few dates): pass A then evaluates that test exactly and lists only what fires, as the dual-pol entry
+    // point does (omnibus.hip, exact_flags) -- instead of handing every pixel to pass B.  ND_AMD_EXACT_FLAGS=0: as before.
+    static const bool exact_flags_env = [] {
+        const char *e = getenv("ND_AMD_EXACT_FLAGS");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool exact_flags = exact_flags_env && pm_ids == nullptr && k >= 2 &&
+                             !((htab[(size_t)k].zlo > -INFINITY) || (htab[(size_t)k].zhi < INFINITY));
+    const bool fused = pm_ids == nullptr && k >= 2 && k <= kDenseMax && k <= kTabArgs && alpha < fused_alpha && g.off32 &&
+                       !exact_flags;
     if (pm_ids != nullptr) {
         // the reference's layout: LDS images folded in place, in the sparse regime (omnibus_c3_pm_kernel)
         constexpr int VE = 16 / (int)sizeof(T);
@@ -2050,7 +2060,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
             ND_C3_PM(16);
 #undef ND_C3_PM
     } else
-    if (!fused && !stats && c3_retain_ok<T>(w, g)) {
+    if (!fused && !stats && !exact_flags && c3_retain_ok<T>(w, g)) {
         // the sparse design with the candidates' series handed over from registers (omnibus_c3_retain_kernel)
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
         if (int rc = c3_launch_retain(w, g, tab, ws, stream)) return rc;
@@ -2058,7 +2068,7 @@ static int omnibus_c3_impl(const void *const planes[9], int64_t ny, int64_t nx, 
     if (!fused || stats) {
         // the sparse design -- or, with a fused search, only the z / P rasters of it
         KernelTimer timer(ND_AMD_KERNEL_OMNIBUS_GLOBAL, stream);
-        if (stats)
+        if (stats || exact_flags)
             hipLaunchKernelGGL((omnibus_c3_global_kernel<T, true>), dim3((unsigned)nblocks),
                                dim3(kC3Threads), 0, stream, g, tab);
         else
