@@ -96,13 +96,17 @@ const char *nd_amd_last_error(void);
  *              *min_bytes, the smallest size the call accepts; anything in
  *              between trades speed on change-rich rasters for memory.
  * njobs has no equivalent: the whole raster is one launch.
- * Series length: any k >= 1; parity-tested up to k = 130.  The first call
+ * Series length: any k >= 1; parity-tested up to k = 193.  The first call
  * with a new (k, n_looks, alpha, dtype) tabulates one pair of decision bounds
  * per sub-series length on the host (O(k^2) work, cached); their safety
  * margin grows with k (see omni_bounds) so that very long series stay exact.
  * Fast forms of the regimes in which most pixels change (alpha below ~0.9;
  * chosen by threshold, series length and a device-side sample of the data)
- * cover k <= 128; longer series are still exact but search pixel by pixel.
+ * cover k <= 192 (as do those of the sparse regime); longer series are still
+ * exact but search pixel by pixel.  Where no screen can decide the test over
+ * the whole series (omega2 outside [0, 1]: the reference's default n_looks = 1
+ * on more than a few dates) that one test is evaluated exactly for every pixel
+ * in the first pass, and only the pixels it fires for are searched.
  * ---------------------------------------------------------------------- */
 size_t nd_amd_omnibus_c2_workspace_bytes(int dtype, int64_t ny, int64_t nx, int64_t k,
                                          size_t *min_bytes);
@@ -302,7 +306,8 @@ int nd_amd_nlmeans3d(const void *arr, void *out, int dtype,
  * (order C11, C12re, C12im, C22).  date_stride = 1 for a real (y, x, time)
  * array; 2, with c12im == c12re + 1, for the two halves of an interleaved
  * complex C12 (read once).  Every threshold up to k = 24 dates (float32;
- * float64: 12).  Longer series (up to 192 dates, a multiple of 4 -- float64:
+ * float64: 12), whatever the length (lengths that are not a multiple of the
+ * 16-byte vector read the staged spans element by element).  Longer series (up to 192 dates, a multiple of 4 -- float64:
  * of 2 --, 16-byte aligned variables) in the sparse regime, alpha >= 0.75:
  * the series is folded out of LDS images instead of being retained, and the
  * search reads a listed pixel's series where it lies.  Everything else
